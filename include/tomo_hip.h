@@ -1,0 +1,149 @@
+/*
+ * tomo_hip.h -- C ABI of libtomo_hip.so, the MI355X (gfx950) engine for the hot path of
+ * jtschwar/tomo_TV: parallel-beam forward projection, voxel-driven back-projection, SIRT/SART
+ * updates and the 3-D TV kernels, behind the reference's `tomoengine` / `ctvlib` method surface.
+ *
+ * This is the drop-in boundary: every entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  Plain pointers and sizes only.  Host arrays use the
+ * reference's layouts:
+ *     volume    float32 [Nslice][Ny][Nz]                 (container/Matrix3D.cpp:20-23)
+ *     sinogram  float32 [Nslice][Nproj*Nray], index angle*Nray+ray   (gpu/reconstructor.py:54-56)
+ * Device-resident state lives inside the opaque engine (slab-interleaved layout).
+ *
+ * Every function returns 0 on success or a tomo_status code; tomo_last_error() gives the text.
+ * One engine = one device slab of slices; calls on one engine must be serialised by the caller.
+ */
+#ifndef TOMO_HIP_H
+#define TOMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tomo_engine tomo_engine;
+
+enum tomo_status { TOMO_OK = 0, TOMO_ERR_ARG = 1, TOMO_ERR_HIP = 2, TOMO_ERR_STATE = 3, TOMO_ERR_GEOMETRY = 4 };
+
+/* volumes held by the engine (tomoengine.hpp:44: recon, temp_recon, original_volume, yk, recon_old) */
+enum tomo_volume { TOMO_VOL_RECON = 0, TOMO_VOL_TEMP = 1, TOMO_VOL_ORIGINAL = 2, TOMO_VOL_YK = 3, TOMO_VOL_RECON_OLD = 4,
+                   TOMO_VOL_COUNT = 5 };
+/* sinograms held by the engine (tomoengine.hpp:53: b = measured, g = re-projection) */
+enum tomo_sinogram { TOMO_SINO_B = 0, TOMO_SINO_G = 1 };
+
+/* slots of the device scalar buffer (doubles); each holds THIS slab's partial sum */
+enum tomo_scalar { TOMO_S_DD = 0,      /* sum (A x - b)^2            data_distance  */
+                   TOMO_S_DIFF = 1,    /* sum (recon - temp)^2       matrix_2norm   */
+                   TOMO_S_TV = 2,      /* sum sqrt(eps + |grad|^2)   tv / tv_gd / tv_fgp return value */
+                   TOMO_S_GNORM = 3,   /* sum g^2 of the TV gradient (one tv_gd inner iteration) */
+                   TOMO_S_RMSE = 4,    /* sum (recon - original)^2   rmse           */
+                   TOMO_S_COST = 5,    /* Poisson-ML cost            poisson_ML     */
+                   TOMO_S_L1 = 6,      /* sum |recon|                l1_norm        */
+                   TOMO_S_COUNT = 16 };
+
+const char *tomo_last_error(void);
+
+/* GPU count; replaces tomofusion/__init__.py:10-18 (pycuda device_count). */
+int tomo_device_count(int *count);
+
+/* Host-only system matrix: drop-in for parallelRay(Nside, angles) of tomofusion/cpu/utils/pytvlib.py:8-121.
+ * angles_rad[i] must be angle_deg*pi/180 evaluated in double.  Writes up to cap entries of (row, col, val)
+ * as float32 in parallelRay's generation order and the entry count to *nnz (call with cap = 0 to size). */
+int tomo_system_matrix(int nray, int nproj, const double *angles_rad, int64_t cap,
+                       float *rows, float *cols, float *vals, int64_t *nnz);
+
+/* tomoengine(Nslice, Nray, angles) -- gpu/utils/tomoengine.cpp:48-84.  Builds the line-intersection system
+ * matrix of parallelRay for these angles and uploads its ray (CSR) and per-angle voxel tables. */
+int tomo_create(int nslice, int nray, int nproj, const double *angles_rad, int device, tomo_engine **out);
+
+/* ctvlib(Nslice, Nray, Nproj) + load_A(A) -- cpu/utils/ctvlib.cpp:28-48, 309-315.  A given as the three
+ * float32 rows of parallelRay's output.  The matrix must have at most two rays of one angle per pixel. */
+int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const float *rows, const float *cols,
+                            const float *vals, int device, tomo_engine **out);
+
+int tomo_destroy(tomo_engine *e);
+
+/* Run all work of this engine on an existing HIP stream (hipStream_t), e.g. torch's current stream. */
+int tomo_set_stream(tomo_engine *e, void *hip_stream);
+int tomo_synchronize(tomo_engine *e);
+int tomo_get_device(tomo_engine *e, int *device);                       /* tomoengine.cpp:92-95 get_gpu_id */
+int tomo_get_dims(tomo_engine *e, int *nslice, int *nray, int *nproj, int64_t *nnz);
+
+/* ---- data in / out ------------------------------------------------------------------------------- */
+int tomo_set_tilt_series(tomo_engine *e, const float *b);               /* tomoengine.cpp:101 setTiltSeries */
+int tomo_get_sinogram(tomo_engine *e, int which, float *out);           /* :454-458 get_projections / get_model_projections */
+int tomo_set_volume(tomo_engine *e, int vol, const float *data);        /* all slices at once */
+int tomo_get_volume(tomo_engine *e, int vol, float *data);
+int tomo_set_slice(tomo_engine *e, int vol, int s, const float *img);   /* :104-106 setOriginalVolume / setRecon */
+int tomo_get_slice(tomo_engine *e, int vol, int s, float *img);         /* :452 getRecon */
+int tomo_restart_recon(tomo_engine *e);                                 /* :462-468 restart_recon */
+int tomo_copy_volume(tomo_engine *e, int dst, int src);                 /* :404 copy_recon = (TEMP <- RECON) */
+
+/* ---- projector -------------------------------------------------------------------------------------- */
+int tomo_forward_projection(tomo_engine *e, int vol, int sino);         /* :416-427 forwardProjection; :109-126 create_projections */
+int tomo_back_projection(tomo_engine *e, int sino, int vol);            /* :279-291 back_projection: vol = A^T sino */
+int tomo_lipschitz(tomo_engine *e, float *L);                           /* ctvlib.cpp:194-202 lipschits; tomoengine.cpp:369-371 */
+int tomo_row_inner_product(tomo_engine *e);                             /* ctvlib.cpp:234-242 normalization */
+
+/* ---- reconstruction steps --------------------------------------------------------------------------- */
+/* ctvlib::SIRT(beta): x = max(0, x + beta A^T (b - A x))   ctvlib.cpp:205-221.  vol = RECON or YK. */
+int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter);
+/* tomoengine::SIRT(nIter) (ASTRA SIRT, min-constraint 0): x = max(0, x + C A^T R (b - A x))  tomoengine.cpp:181-205 */
+int tomo_sirt(tomo_engine *e, int vol, int niter);
+/* tomoengine::SART(beta, nIter): nIter sweeps of per-angle updates, order[] = angle permutation or NULL
+ * (sequential)  tomoengine.cpp:151-179 */
+int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *order);
+/* ctvlib::ART(beta): row-action Kaczmarz sweep + positivity  ctvlib.cpp:137-155 */
+int tomo_art(tomo_engine *e, float beta);
+/* tomoengine::poisson_ML(lambda): cost accumulates in TOMO_S_COST  tomoengine.cpp:231-246, 293-315 */
+int tomo_poisson_ml(tomo_engine *e, float lambda);
+int tomo_positivity(tomo_engine *e, int vol);                           /* ctvlib.cpp:224-231 */
+int tomo_soft_threshold(tomo_engine *e, int vol, float lambda);         /* matrix_ops.cu:64-75 */
+int tomo_fista_momentum(tomo_engine *e, float beta);                    /* tomoengine.cpp:381-384 */
+
+/* ---- scalar reductions: partial sums of this slab land in the device scalar buffer ------------------ */
+int tomo_data_distance_sq(tomo_engine *e, int vol);                     /* tomoengine.cpp:410-413 -> TOMO_S_DD (also fills G) */
+int tomo_diff_norm_sq(tomo_engine *e, int a, int b, int slot);          /* :407 matrix_2norm, :433 rmse */
+int tomo_l1_norm(tomo_engine *e, int vol);                              /* :436 l1_norm -> TOMO_S_L1 */
+int tomo_read_scalars(tomo_engine *e, double *out, int count);          /* synchronises the stream */
+int tomo_bind_scalar_buffer(tomo_engine *e, void *device_doubles);      /* >= TOMO_S_COUNT doubles, e.g. a torch tensor */
+
+/* ---- 3-D total variation ---------------------------------------------------------------------------- */
+/* Slices of a slab have neighbours on other ranks: two device buffers of Nray*Nray floats hold the slice
+ * below the first local slice (lo) and above the last (hi).  tomo_halo_local fills them from this slab
+ * (periodic wrap = single-rank behaviour of ctvlib.cpp:348,421-422); a distributed caller packs, exchanges
+ * (mpi_ctvlib.cpp:400-422) and leaves the received planes in the bound buffers. */
+int tomo_bind_halo(tomo_engine *e, void *device_lo, void *device_hi);
+int tomo_halo_pack(tomo_engine *e, int field, int last, void *device_dst); /* field: tomo_volume or TOMO_FIELD_* */
+int tomo_halo_local(tomo_engine *e, int field);
+enum tomo_field { TOMO_FIELD_FGP_D = 100, TOMO_FIELD_FGP_P1 = 101 };
+/* global-edge flags for the non-periodic FGP stencil (tv_fgp.cu:57,81) */
+int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last);
+
+/* step forms (use the halo buffers as they are) */
+int tomo_tv_partial(tomo_engine *e, int vol, float eps);                /* tv_gd.cu:27-47 -> TOMO_S_TV */
+int tomo_tv_grad(tomo_engine *e, float eps);                            /* ctvlib.cpp:415-449 -> TOMO_S_GNORM */
+int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp);             /* ctvlib.cpp:452-458 (+461 when clamp) */
+int tomo_fgp_begin(tomo_engine *e);                                     /* tv_fgp.cu:216-227 */
+int tomo_fgp_obj(tomo_engine *e, float lambda);                         /* :44-65 + :143-154 */
+int tomo_fgp_grad(tomo_engine *e, float lambda);                        /* :67-115 */
+int tomo_fgp_end(tomo_engine *e, int iters);                            /* :272 */
+
+/* whole-call forms for a single slab (= the reference's single-GPU calls) */
+int tomo_tv(tomo_engine *e, int vol, float eps);                        /* tomoengine.cpp:439-442 tv_3D -> TOMO_S_TV */
+int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps);         /* :445 tv_gd_3D; TV before descent -> TOMO_S_TV */
+int tomo_tv_fgp(tomo_engine *e, int iters, float lambda);               /* :448-450 tv_fgp_3D; TV of input -> TOMO_S_TV */
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------------
+ * While enabled, every launch of the named kernel is bracketed by HIP events on the engine's stream;
+ * tomo_profile_read synchronises, returns launch count and summed device time, and resets the log. */
+enum tomo_kernel_id { TOMO_K_BP_ANGLE = 0, TOMO_K_FP_ANGLE = 1, TOMO_K_TV_GRAD = 2, TOMO_K_TV_UPDATE = 3,
+                      TOMO_K_FGP_OBJ = 4, TOMO_K_FGP_GRAD = 5 };
+int tomo_profile_enable(tomo_engine *e, int kernel, int on);
+int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOMO_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of ``libtomo_hip.so`` (C ABI: ``include/tomo_hip.h``).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing an engine raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtomo_hip.so")
+
+# enum mirrors (include/tomo_hip.h)
+VOL_RECON, VOL_TEMP, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD = 0, 1, 2, 3, 4
+SINO_B, SINO_G = 0, 1
+S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 16
+FIELD_FGP_D, FIELD_FGP_P1 = 100, 101
+K_BP_ANGLE, K_FP_ANGLE, K_TV_GRAD, K_TV_UPDATE, K_FGP_OBJ, K_FGP_GRAD = 0, 1, 2, 3, 4, 5
+
+_i, _i64, _f, _p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> argtypes; every function returns int status except tomo_last_error
+SIGNATURES = {
+    "tomo_device_count": [ctypes.POINTER(_i)],
+    "tomo_system_matrix": [_i, _i, _p, _i64, _p, _p, _p, ctypes.POINTER(_i64)],
+    "tomo_create": [_i, _i, _i, _p, _i, _pp],
+    "tomo_create_from_matrix": [_i, _i, _i, _i64, _p, _p, _p, _i, _pp],
+    "tomo_destroy": [_p],
+    "tomo_set_stream": [_p, _p],
+    "tomo_synchronize": [_p],
+    "tomo_get_device": [_p, ctypes.POINTER(_i)],
+    "tomo_get_dims": [_p, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i64)],
+    "tomo_set_tilt_series": [_p, _p],
+    "tomo_get_sinogram": [_p, _i, _p],
+    "tomo_set_volume": [_p, _i, _p],
+    "tomo_get_volume": [_p, _i, _p],
+    "tomo_set_slice": [_p, _i, _i, _p],
+    "tomo_get_slice": [_p, _i, _i, _p],
+    "tomo_restart_recon": [_p],
+    "tomo_copy_volume": [_p, _i, _i],
+    "tomo_forward_projection": [_p, _i, _i],
+    "tomo_back_projection": [_p, _i, _i],
+    "tomo_lipschitz": [_p, ctypes.POINTER(_f)],
+    "tomo_row_inner_product": [_p],
+    "tomo_sirt_landweber": [_p, _i, _f, _i],
+    "tomo_sirt": [_p, _i, _i],
+    "tomo_sart": [_p, _i, _f, _i, _p],
+    "tomo_art": [_p, _f],
+    "tomo_poisson_ml": [_p, _f],
+    "tomo_positivity": [_p, _i],
+    "tomo_soft_threshold": [_p, _i, _f],
+    "tomo_fista_momentum": [_p, _f],
+    "tomo_data_distance_sq": [_p, _i],
+    "tomo_diff_norm_sq": [_p, _i, _i, _i],
+    "tomo_l1_norm": [_p, _i],
+    "tomo_read_scalars": [_p, _p, _i],
+    "tomo_bind_scalar_buffer": [_p, _p],
+    "tomo_bind_halo": [_p, _p, _p],
+    "tomo_halo_pack": [_p, _i, _i, _p],
+    "tomo_halo_local": [_p, _i],
+    "tomo_set_slab_edges": [_p, _i, _i],
+    "tomo_tv_partial": [_p, _i, _f],
+    "tomo_tv_grad": [_p, _f],
+    "tomo_tv_update": [_p, _f, _i],
+    "tomo_fgp_begin": [_p],
+    "tomo_fgp_obj": [_p, _f],
+    "tomo_fgp_grad": [_p, _f],
+    "tomo_fgp_end": [_p, _i],
+    "tomo_tv": [_p, _i, _f],
+    "tomo_tv_gd": [_p, _i, _f, _f],
+    "tomo_tv_fgp": [_p, _i, _f],
+    "tomo_profile_enable": [_p, _i, _i],
+    "tomo_profile_read": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
+}
+
+_lib = None
+
+
+class TomoError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtomo_hip.so; raises if it is absent (the product has no CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TomoError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tomo_tv_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.tomo_last_error.restype = ctypes.c_char_p
+    L.tomo_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError here = header/library mismatch
+        fn.restype = _i
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().tomo_last_error()
+        raise TomoError(f"libtomo_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_count():
+    n = _i(0)
+    check(load().tomo_device_count(ctypes.byref(n)))
+    return n.value

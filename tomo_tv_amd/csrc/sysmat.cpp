@@ -1,0 +1,239 @@
+// sysmat.cpp -- host-side system-matrix builder and table construction (no device code).
+//
+// Produces the line-intersection matrix that the reference's CPU path builds in Python
+// (tomofusion/cpu/utils/pytvlib.py:8-121, parallelRay): ray j of angle i is the centre line through
+// offset_j*(cos t, sin t) with direction (-sin t, cos t); A[i*N+j, pixel] = chord length in that pixel.
+// The reference sorts all 2(N+1) grid crossings per ray; here the x-grid and y-grid crossing families are
+// each monotone in the ray parameter, so they are merged in O(N), many rays at a time on host threads.
+// Epsilon handling (snap, duplicate-point and boundary-ray rules) follows pytvlib.py:38-44,63-92,124-130
+// so that the float32 weights equal parallelRay's.
+#include "sysmat.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace tomo {
+
+static inline double snap10(double v) { return std::fabs(v) < 1e-10 ? 0.0 : v; }
+
+// entries of one ray in path order; returns count
+static int trace_ray(int N, const double *grid, double x0, double y0, double a, double b, double half,
+                     double *qx, double *qy, uint32_t *cols, float *vals)
+{
+    const int M = N + 1;
+    int n = 0;
+    // the two crossing families, each walked in increasing t
+    int ix = (a > 0) ? 0 : M - 1, dx = (a > 0) ? 1 : -1, nxl = (a != 0.0) ? M : 0;
+    int iy = (b > 0) ? 0 : M - 1, dy = (b > 0) ? 1 : -1, nyl = (b != 0.0) ? M : 0;
+    double tx = 0, ty = 0;
+    if (nxl) tx = (grid[ix] - x0) / a;
+    if (nyl) ty = (grid[iy] - y0) / b;
+    while (nxl > 0 || nyl > 0) {
+        bool take_x;
+        if (nxl == 0) take_x = false;
+        else if (nyl == 0) take_x = true;
+        else take_x = (tx <= ty);
+        double px, py;
+        if (take_x) {
+            px = grid[ix]; py = b * tx + y0;
+            ix += dx; --nxl;
+            if (nxl) tx = (grid[ix] - x0) / a;
+        } else {
+            px = a * ty + x0; py = grid[iy];
+            iy += dy; --nyl;
+            if (nyl) ty = (grid[iy] - y0) / b;
+        }
+        if (px >= -half && px <= half && py >= -half && py <= half) {
+            // duplicate rule: a point is dropped when its successor lies within 1e-8 in both coordinates
+            if (n > 0 && std::fabs(px - qx[n - 1]) <= 1e-8 && std::fabs(py - qy[n - 1]) <= 1e-8) {
+                qx[n - 1] = px; qy[n - 1] = py;
+            } else {
+                qx[n] = px; qy[n] = py; ++n;
+            }
+        }
+    }
+    int numvals = n - 1;
+    if (numvals <= 0) return 0;
+    if ((b == 0.0 && std::fabs(y0 - half) < 1e-15) || (a == 0.0 && std::fabs(x0 - half) < 1e-15)) return 0;
+    for (int k = 0; k < numvals; ++k) {
+        double ex = qx[k + 1] - qx[k], ey = qy[k + 1] - qy[k];
+        double len = std::sqrt(ex * ex + ey * ey);
+        double mx = snap10(0.5 * (qx[k] + qx[k + 1]));
+        double my = snap10(0.5 * (qy[k] + qy[k + 1]));
+        double pix = std::floor(half - my) * N + std::floor(mx + half);
+        cols[k] = (uint32_t)(int64_t)(float)pix;
+        vals[k] = (float)len;
+    }
+    return numvals;
+}
+
+void build_parallel_ray(int N, int P, const double *angles_rad, Coo &out)
+{
+    const int M = N + 1;
+    std::vector<double> grid(M), offs(N);
+    for (int m = 0; m < M; ++m) grid[m] = (m == M - 1) ? N * 0.5 : -N * 0.5 + m * ((N * 0.5 + N * 0.5) / (double)N);
+    {
+        double start = -((double)N - 1.0) / 2.0, stop = ((double)N - 1.0) / 2.0;
+        double step = (N > 1) ? (stop - start) / (double)(N - 1) : 0.0;
+        for (int j = 0; j < N; ++j) offs[j] = (j == N - 1 && N > 1) ? stop : start + j * step;
+    }
+    const double half = N / 2.0;
+    const int64_t nrays = (int64_t)N * P;
+    unsigned hw = std::thread::hardware_concurrency();
+    int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, nrays / 64));
+    std::vector<std::vector<uint32_t>> tcols(nth);
+    std::vector<std::vector<float>> tvals(nth);
+    std::vector<uint32_t> count(nrays, 0);
+    auto work = [&](int t) {
+        int64_t r0 = nrays * t / nth, r1 = nrays * (t + 1) / nth;
+        std::vector<double> qx(2 * M), qy(2 * M);
+        std::vector<uint32_t> c(2 * M);
+        std::vector<float> v(2 * M);
+        tcols[t].reserve((size_t)((r1 - r0) * 1.3 * N));
+        tvals[t].reserve((size_t)((r1 - r0) * 1.3 * N));
+        for (int64_t r = r0; r < r1; ++r) {
+            int i = (int)(r / N), j = (int)(r % N);
+            double ang = angles_rad[i];
+            double ca = std::cos(ang), sa = std::sin(ang);
+            double x0 = ca * offs[j], y0 = sa * offs[j];
+            if (std::fabs(x0) < 1e-8) x0 = 0.0;
+            if (std::fabs(y0) < 1e-8) y0 = 0.0;
+            double a = snap10(-sa), b = snap10(ca);
+            int n = trace_ray(N, grid.data(), x0, y0, a, b, half, qx.data(), qy.data(), c.data(), v.data());
+            count[r] = (uint32_t)n;
+            tcols[t].insert(tcols[t].end(), c.begin(), c.begin() + n);
+            tvals[t].insert(tvals[t].end(), v.begin(), v.begin() + n);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    out.nrow = nrays;
+    out.ncol = (int64_t)N * N;
+    out.ptr.assign(nrays + 1, 0);
+    for (int64_t r = 0; r < nrays; ++r) out.ptr[r + 1] = out.ptr[r] + count[r];
+    out.col.resize(out.ptr[nrays]);
+    out.val.resize(out.ptr[nrays]);
+    for (int t = 0; t < nth; ++t) {
+        int64_t r0 = nrays * t / nth;
+        std::memcpy(out.col.data() + out.ptr[r0], tcols[t].data(), tcols[t].size() * sizeof(uint32_t));
+        std::memcpy(out.val.data() + out.ptr[r0], tvals[t].data(), tvals[t].size() * sizeof(float));
+    }
+}
+
+// ctvlib::loadA (cpu/utils/ctvlib.cpp:309-315): coeffRef(row, col) = val.  Entries arrive as float32 triplets.
+bool coo_from_triplets(int64_t nrow, int64_t ncol, int64_t nnz, const float *rows, const float *cols,
+                       const float *vals, Coo &out, std::string &err)
+{
+    out.nrow = nrow; out.ncol = ncol;
+    out.ptr.assign(nrow + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) {
+        int64_t r = (int64_t)rows[k], c = (int64_t)cols[k];
+        if (r < 0 || r >= nrow || c < 0 || c >= ncol || rows[k] != (float)r || cols[k] != (float)c) {
+            err = "load_A: entry " + std::to_string(k) + " has row/col outside the matrix";
+            return false;
+        }
+        out.ptr[r + 1]++;
+    }
+    for (int64_t r = 0; r < nrow; ++r) out.ptr[r + 1] += out.ptr[r];
+    out.col.resize(nnz); out.val.resize(nnz);
+    std::vector<int64_t> fill(out.ptr.begin(), out.ptr.end() - 1);
+    for (int64_t k = 0; k < nnz; ++k) {
+        int64_t pos = fill[(int64_t)rows[k]]++;
+        out.col[pos] = (uint32_t)(int64_t)cols[k];
+        out.val[pos] = vals[k];
+    }
+    return true;
+}
+
+// Sort every row by column (the order Eigen's RowMajor storage iterates: ctvlib.hpp:22); a repeated
+// (row, col) keeps the last assignment.
+void sort_rows(Coo &m)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, m.nrow / 256));
+    std::vector<uint32_t> keep(m.nrow, 0);
+    auto work = [&](int t) {
+        int64_t r0 = m.nrow * t / nth, r1 = m.nrow * (t + 1) / nth;
+        std::vector<std::pair<uint32_t, uint32_t>> key;
+        std::vector<float> tmp;
+        for (int64_t r = r0; r < r1; ++r) {
+            int64_t b = m.ptr[r], e = m.ptr[r + 1];
+            int n = (int)(e - b);
+            key.resize(n); tmp.resize(n);
+            for (int k = 0; k < n; ++k) { key[k] = {m.col[b + k], (uint32_t)k}; tmp[k] = m.val[b + k]; }
+            std::sort(key.begin(), key.end());
+            int o = 0;
+            for (int k = 0; k < n; ++k) {
+                if (k + 1 < n && key[k + 1].first == key[k].first) continue;
+                m.col[b + o] = key[k].first; m.val[b + o] = tmp[key[k].second]; ++o;
+            }
+            keep[r] = (uint32_t)o;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    // compact if duplicates were dropped
+    bool dense = true;
+    for (int64_t r = 0; r < m.nrow; ++r) if ((int64_t)keep[r] != m.ptr[r + 1] - m.ptr[r]) { dense = false; break; }
+    if (dense) return;
+    int64_t o = 0;
+    std::vector<int64_t> nptr(m.nrow + 1, 0);
+    for (int64_t r = 0; r < m.nrow; ++r) {
+        int64_t b = m.ptr[r];
+        for (uint32_t k = 0; k < keep[r]; ++k) { m.col[o] = m.col[b + k]; m.val[o] = m.val[b + k]; ++o; }
+        nptr[r + 1] = o;
+    }
+    m.ptr.swap(nptr);
+    m.col.resize(o); m.val.resize(o);
+}
+
+// Derived tables (all fp32, accumulated in the order the oracle / Eigen would):
+//   rowsum[r] = A_r . 1, rowinner[r] = A_r . A_r            (ascending column)
+//   cell[i][p] = up to two (ray-of-angle-i, weight) pairs through pixel p, ascending ray
+//   colsum_all[p] = sum_r A[r,p]                            (ascending row)
+//   lipschitz = max_p (A^T (A 1))_p                          (ctvlib.cpp:194-202)
+bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err)
+{
+    const int64_t npix = (int64_t)N * N;
+    t.rowsum.assign(m.nrow, 0.f);
+    t.rowinner.assign(m.nrow, 0.f);
+    for (int64_t r = 0; r < m.nrow; ++r) {
+        float s = 0.f, q = 0.f;
+        for (int64_t k = m.ptr[r]; k < m.ptr[r + 1]; ++k) { s += m.val[k]; q += m.val[k] * m.val[k]; }
+        t.rowsum[r] = s; t.rowinner[r] = q;
+    }
+    t.cell.assign((size_t)P * npix, Cell{0u, 0.f, 0u, 0.f});
+    t.colsum_all.assign(npix, 0.f);
+    std::vector<float> ata1(npix, 0.f);
+    for (int64_t r = 0; r < m.nrow; ++r) {
+        int i = (int)(r / N);
+        uint32_t j = (uint32_t)(r % N);
+        for (int64_t k = m.ptr[r]; k < m.ptr[r + 1]; ++k) {
+            uint32_t p = m.col[k];
+            float w = m.val[k];
+            t.colsum_all[p] += w;
+            ata1[p] += w * t.rowsum[r];
+            if (w == 0.f) continue;  // a zero weight carries nothing into a voxel update
+            Cell &c = t.cell[(size_t)i * npix + p];
+            if (c.w0 == 0.f) { c.r0 = j; c.w0 = w; }
+            else if (c.w1 == 0.f) { c.r1 = j; c.w1 = w; }
+            else {
+                err = "system matrix has more than two rays of angle " + std::to_string(i) + " through pixel " +
+                      std::to_string(p) + " (unsupported geometry)";
+                return false;
+            }
+        }
+    }
+    float L = 0.f;
+    for (int64_t p = 0; p < npix; ++p) L = std::max(L, ata1[p]);
+    t.lipschitz = L;
+    return true;
+}
+
+}  // namespace tomo

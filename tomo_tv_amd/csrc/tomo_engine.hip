@@ -1,0 +1,822 @@
+// tomo_engine.hip -- engine state + C ABI (include/tomo_hip.h) over the kernels in kernels.hip.h.
+//
+// Mirrors the method surface of the reference's `tomoengine` (tomofusion/gpu/utils/tomoengine.{hpp,cpp}) and
+// `ctvlib` (tomofusion/cpu/utils/ctvlib.{hpp,cpp}); each entry point cites the lines it replaces in the header.
+// Unlike the reference (host-resident volume, cudaMalloc + H2D + D2H inside every call) all fields stay
+// resident in HBM for the life of the engine.
+#include "../../include/tomo_hip.h"
+#include "kernels.hip.h"
+#include "sysmat.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tomo;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (call);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(TOMO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+#define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); HIPCHK(hipSetDevice((e)->device)); } while (0)
+
+enum { PROF_MAX_KERNELS = 8, PROF_MAX_EVENTS = 8192 };
+
+struct ProfSlot {
+    bool on = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t used = 0;
+};
+
+struct tomo_engine {
+    int nx = 0, n = 0, np = 0, sx = 0, vec = 1, device = 0;
+    int64_t npix = 0, nrows = 0, nnz = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // tables
+    uint32_t *d_rptr = nullptr;
+    uint2 *d_rent = nullptr;
+    float *d_rowsum = nullptr, *d_rowinner = nullptr, *d_colsum_all = nullptr;
+    CellD *d_cell = nullptr;
+    float lipschitz = 0.f;
+    // fields
+    float *vol[TOMO_VOL_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *sino_b = nullptr, *sino_g = nullptr, *sino_r = nullptr;
+    float *tvg = nullptr;                         // TV gradient tensor; doubles as FGP "D"
+    float *fgp_p[3] = {nullptr, nullptr, nullptr};
+    float *stage = nullptr;
+    size_t stage_bytes = 0;
+    // scalars
+    double *d_scal = nullptr, *d_scal_own = nullptr, *d_part = nullptr;
+    // halos
+    float *halo_lo = nullptr, *halo_hi = nullptr, *halo_lo_own = nullptr, *halo_hi_own = nullptr;
+    int is_first = 1, is_last = 1;
+    ProfSlot prof[PROF_MAX_KERNELS];
+    size_t vol_elems() const { return (size_t)npix * sx; }
+    size_t sino_elems() const { return (size_t)nrows * sx; }
+};
+
+static int dev_alloc(void **p, size_t bytes, bool zero, hipStream_t st)
+{
+    HIPCHK(hipMalloc(p, bytes ? bytes : 4));
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes ? bytes : 4, st));
+    return TOMO_OK;
+}
+
+static int get_vol(tomo_engine *e, int id, float **out)
+{
+    if (id < 0 || id >= TOMO_VOL_COUNT) return fail(TOMO_ERR_ARG, "bad volume id");
+    if (!e->vol[id]) {
+        int rc = dev_alloc((void **)&e->vol[id], e->vol_elems() * sizeof(float), true, e->stream);
+        if (rc) return rc;
+    }
+    *out = e->vol[id];
+    return TOMO_OK;
+}
+
+static int get_sino(tomo_engine *e, float **slot, float **out)
+{
+    if (!*slot) {
+        int rc = dev_alloc((void **)slot, e->sino_elems() * sizeof(float), true, e->stream);
+        if (rc) return rc;
+    }
+    *out = *slot;
+    return TOMO_OK;
+}
+
+static int get_scratch(tomo_engine *e, float **slot, float **out)
+{
+    if (!*slot) {
+        int rc = dev_alloc((void **)slot, e->vol_elems() * sizeof(float), true, e->stream);
+        if (rc) return rc;
+    }
+    *out = *slot;
+    return TOMO_OK;
+}
+
+static int ensure_stage(tomo_engine *e, size_t bytes)
+{
+    if (e->stage_bytes >= bytes) return TOMO_OK;
+    if (e->stage) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->stage)); e->stage = nullptr; }
+    HIPCHK(hipMalloc((void **)&e->stage, bytes));
+    e->stage_bytes = bytes;
+    return TOMO_OK;
+}
+
+// ---- profiling brackets (bench.py roofline: HIP events on the launch stream) --------------------------
+struct ProfScope {
+    tomo_engine *e; int k; hipEvent_t stop = nullptr;
+    ProfScope(tomo_engine *e_, int k_) : e(e_), k(k_)
+    {
+        ProfSlot &p = e->prof[k];
+        if (!p.on) return;
+        if (p.used + 2 > p.ev.size()) {
+            if (p.ev.size() >= PROF_MAX_EVENTS) return;
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            p.ev.push_back(a); p.ev.push_back(b);
+        }
+        (void)hipEventRecord(p.ev[p.used], e->stream);
+        stop = p.ev[p.used + 1];
+        p.used += 2;
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, e->stream); }
+};
+
+// ---- reductions ------------------------------------------------------------------------------------------
+static int reduce_begin(tomo_engine *e) { HIPCHK(hipMemsetAsync(e->d_part, 0, NPART * sizeof(double), e->stream)); return TOMO_OK; }
+static int reduce_end(tomo_engine *e, int slot)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part, e->d_scal + slot);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+static int grid_1d(int64_t n4) { int64_t b = (n4 + 255) / 256; return (int)std::min<int64_t>(std::max<int64_t>(b, 1), 4096); }
+
+// ---- projector launches -------------------------------------------------------------------------------------
+template <int MODE>
+static int launch_fp(tomo_engine *e, const float *x, int row0, int nrows, const float *b, float *out)
+{
+    int nchunk = e->sx / (64 * e->vec);
+    dim3 grid((unsigned)((int64_t)nrows * nchunk)), block(256);
+    switch (e->vec) {
+    case 4: hipLaunchKernelGGL((k_fp_rows<4, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx); break;
+    case 2: hipLaunchKernelGGL((k_fp_rows<2, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx); break;
+    default: hipLaunchKernelGGL((k_fp_rows<1, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx); break;
+    }
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+constexpr int BP_PPW = 4;
+
+static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_angle, float beta)
+{
+    ProfScope ps(e, TOMO_K_BP_ANGLE);
+    int nchunk = e->sx / (64 * e->vec);
+    int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
+    int64_t waves = (int64_t)ngroups * nchunk;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const CellD *cell = e->d_cell + (size_t)angle * e->npix;
+    switch (e->vec) {
+    case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups); break;
+    case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups); break;
+    default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups); break;
+    }
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
+{
+    int nchunk = e->sx / (64 * e->vec);
+    int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
+    int64_t waves = (int64_t)ngroups * nchunk;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (e->vec) {
+    case 4: hipLaunchKernelGGL((k_bp_all<4, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups); break;
+    case 2: hipLaunchKernelGGL((k_bp_all<2, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups); break;
+    default: hipLaunchKernelGGL((k_bp_all<1, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups); break;
+    }
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+// ---- creation ----------------------------------------------------------------------------------------------
+static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out)
+{
+    Tables t;
+    std::string err;
+    sort_rows(m);
+    if (!build_tables(m, e->n, e->np, t, err)) { delete e; return fail(TOMO_ERR_GEOMETRY, err); }
+    e->nnz = m.ptr[m.nrow];
+    if (e->nnz >= (int64_t)0xFFFFFFFFu) { delete e; return fail(TOMO_ERR_ARG, "matrix too large for 32-bit entry offsets"); }
+    e->lipschitz = t.lipschitz;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+    std::vector<uint32_t> ptr32(m.nrow + 1);
+    for (int64_t r = 0; r <= m.nrow; ++r) ptr32[r] = (uint32_t)m.ptr[r];
+    std::vector<uint2> ent(e->nnz ? e->nnz : 1);
+    for (int64_t k = 0; k < e->nnz; ++k) { uint32_t bits; std::memcpy(&bits, &m.val[k], 4); ent[k] = make_uint2(m.col[k], bits); }
+    int rc;
+    if ((rc = dev_alloc((void **)&e->d_rptr, ptr32.size() * 4, false, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->d_rent, ent.size() * sizeof(uint2), false, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->d_rowsum, t.rowsum.size() * 4, false, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->d_rowinner, t.rowinner.size() * 4, false, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->d_colsum_all, t.colsum_all.size() * 4, false, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->d_cell, t.cell.size() * sizeof(CellD), false, e->stream))) return rc;
+    HIPCHK(hipMemcpy(e->d_rptr, ptr32.data(), ptr32.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_rent, ent.data(), (size_t)e->nnz * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_rowsum, t.rowsum.data(), t.rowsum.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_rowinner, t.rowinner.data(), t.rowinner.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_colsum_all, t.colsum_all.data(), t.colsum_all.size() * 4, hipMemcpyHostToDevice));
+    static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
+    HIPCHK(hipMemcpy(e->d_cell, t.cell.data(), t.cell.size() * sizeof(CellD), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc((void **)&e->d_scal_own, TOMO_S_COUNT * sizeof(double), true, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->d_part, NPART * sizeof(double), true, e->stream))) return rc;
+    e->d_scal = e->d_scal_own;
+    if ((rc = dev_alloc((void **)&e->halo_lo_own, e->npix * sizeof(float), true, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->halo_hi_own, e->npix * sizeof(float), true, e->stream))) return rc;
+    e->halo_lo = e->halo_lo_own; e->halo_hi = e->halo_hi_own;
+    float *tmp;
+    if ((rc = get_vol(e, TOMO_VOL_RECON, &tmp))) return rc;
+    if ((rc = get_sino(e, &e->sino_b, &tmp))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = e;
+    return TOMO_OK;
+}
+
+static tomo_engine *new_engine(int nslice, int nray, int nproj, int device)
+{
+    tomo_engine *e = new tomo_engine();
+    e->nx = nslice; e->n = nray; e->np = nproj; e->device = device;
+    e->sx = ((nslice + 63) / 64) * 64;
+    e->vec = (e->sx % 256 == 0) ? 4 : (e->sx % 128 == 0) ? 2 : 1;
+    e->npix = (int64_t)nray * nray;
+    e->nrows = (int64_t)nray * nproj;
+    return e;
+}
+
+static int check_dims(int nslice, int nray, int nproj)
+{
+    if (nslice <= 0 || nray <= 0 || nproj <= 0) return fail(TOMO_ERR_ARG, "Nslice, Nray and Nproj must be positive");
+    if (nray > 4096) return fail(TOMO_ERR_ARG, "Nray > 4096 not supported (float32 index storage limit of parallelRay)");
+    return TOMO_OK;
+}
+
+extern "C" {
+
+const char *tomo_last_error(void) { return g_err.c_str(); }
+
+int tomo_device_count(int *count)
+{
+    if (!count) return fail(TOMO_ERR_ARG, "null count");
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *count = n;
+    return TOMO_OK;
+}
+
+int tomo_system_matrix(int nray, int nproj, const double *angles_rad, int64_t cap, float *rows, float *cols,
+                       float *vals, int64_t *nnz)
+{
+    if (!angles_rad || !nnz) return fail(TOMO_ERR_ARG, "null argument");
+    int rc = check_dims(1, nray, nproj);
+    if (rc) return rc;
+    Coo m;
+    build_parallel_ray(nray, nproj, angles_rad, m);
+    *nnz = m.ptr[m.nrow];
+    if (cap == 0) return TOMO_OK;
+    if (cap < *nnz || !rows || !cols || !vals) return fail(TOMO_ERR_ARG, "output capacity too small");
+    for (int64_t r = 0; r < m.nrow; ++r)
+        for (int64_t k = m.ptr[r]; k < m.ptr[r + 1]; ++k) { rows[k] = (float)r; cols[k] = (float)m.col[k]; vals[k] = m.val[k]; }
+    return TOMO_OK;
+}
+
+int tomo_create(int nslice, int nray, int nproj, const double *angles_rad, int device, tomo_engine **out)
+{
+    if (!angles_rad || !out) return fail(TOMO_ERR_ARG, "null argument");
+    int rc = check_dims(nslice, nray, nproj);
+    if (rc) return rc;
+    tomo_engine *e = new_engine(nslice, nray, nproj, device);
+    Coo m;
+    build_parallel_ray(nray, nproj, angles_rad, m);
+    return finish_create(e, m, out);
+}
+
+int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const float *rows, const float *cols,
+                            const float *vals, int device, tomo_engine **out)
+{
+    if (!rows || !cols || !vals || !out) return fail(TOMO_ERR_ARG, "null argument");
+    int rc = check_dims(nslice, nray, nproj);
+    if (rc) return rc;
+    Coo m;
+    std::string err;
+    if (!coo_from_triplets((int64_t)nray * nproj, (int64_t)nray * nray, nnz, rows, cols, vals, m, err))
+        return fail(TOMO_ERR_ARG, err);
+    tomo_engine *e = new_engine(nslice, nray, nproj, device);
+    return finish_create(e, m, out);
+}
+
+int tomo_destroy(tomo_engine *e)
+{
+    if (!e) return TOMO_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void *ptrs[] = {e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->sino_b, e->sino_g,
+                    e->sino_r, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+                    e->halo_lo_own, e->halo_hi_own};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < TOMO_VOL_COUNT; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
+    for (auto &p : e->prof) for (auto ev : p.ev) (void)hipEventDestroy(ev);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return TOMO_OK;
+}
+
+int tomo_set_stream(tomo_engine *e, void *hip_stream)
+{
+    NEED(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream) { HIPCHK(hipStreamDestroy(e->stream)); e->own_stream = false; }
+    e->stream = (hipStream_t)hip_stream;
+    return TOMO_OK;
+}
+
+int tomo_synchronize(tomo_engine *e) { NEED(e); HIPCHK(hipStreamSynchronize(e->stream)); return TOMO_OK; }
+int tomo_get_device(tomo_engine *e, int *device) { if (!e || !device) return fail(TOMO_ERR_ARG, "null"); *device = e->device; return TOMO_OK; }
+int tomo_get_dims(tomo_engine *e, int *nslice, int *nray, int *nproj, int64_t *nnz)
+{
+    if (!e) return fail(TOMO_ERR_ARG, "null engine");
+    if (nslice) *nslice = e->nx;
+    if (nray) *nray = e->n;
+    if (nproj) *nproj = e->np;
+    if (nnz) *nnz = e->nnz;
+    return TOMO_OK;
+}
+
+// ---- data in / out ---------------------------------------------------------------------------------------
+static int upload(tomo_engine *e, const float *host, float *dst, int64_t m)
+{
+    size_t bytes = (size_t)e->nx * m * sizeof(float);
+    int rc = ensure_stage(e, bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->stage, host, bytes, hipMemcpyHostToDevice, e->stream));
+    dim3 grid((unsigned)((m + 31) / 32), (unsigned)((e->sx + 31) / 32)), block(256);
+    hipLaunchKernelGGL(k_transpose_in, grid, block, 0, e->stream, e->stage, dst, e->nx, m, e->sx);
+    LAUNCHCHK();
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+static int download(tomo_engine *e, const float *src, float *host, int64_t m)
+{
+    size_t bytes = (size_t)e->nx * m * sizeof(float);
+    int rc = ensure_stage(e, bytes);
+    if (rc) return rc;
+    dim3 grid((unsigned)((m + 31) / 32), (unsigned)((e->sx + 31) / 32)), block(256);
+    hipLaunchKernelGGL(k_transpose_out, grid, block, 0, e->stream, src, e->stage, e->nx, m, e->sx);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(host, e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+int tomo_set_tilt_series(tomo_engine *e, const float *b)
+{
+    NEED(e);
+    if (!b) return fail(TOMO_ERR_ARG, "null tilt series");
+    return upload(e, b, e->sino_b, e->nrows);
+}
+
+int tomo_get_sinogram(tomo_engine *e, int which, float *out)
+{
+    NEED(e);
+    if (!out) return fail(TOMO_ERR_ARG, "null output");
+    float *src;
+    int rc = which == TOMO_SINO_B ? get_sino(e, &e->sino_b, &src) : which == TOMO_SINO_G ? get_sino(e, &e->sino_g, &src)
+                                                                                          : fail(TOMO_ERR_ARG, "bad sinogram id");
+    if (rc) return rc;
+    return download(e, src, out, e->nrows);
+}
+
+int tomo_set_volume(tomo_engine *e, int vol, const float *data)
+{
+    NEED(e);
+    float *dst; int rc = get_vol(e, vol, &dst); if (rc) return rc;
+    if (!data) return fail(TOMO_ERR_ARG, "null volume");
+    return upload(e, data, dst, e->npix);
+}
+
+int tomo_get_volume(tomo_engine *e, int vol, float *data)
+{
+    NEED(e);
+    float *src; int rc = get_vol(e, vol, &src); if (rc) return rc;
+    if (!data) return fail(TOMO_ERR_ARG, "null volume");
+    return download(e, src, data, e->npix);
+}
+
+int tomo_set_slice(tomo_engine *e, int vol, int s, const float *img)
+{
+    NEED(e);
+    float *dst; int rc = get_vol(e, vol, &dst); if (rc) return rc;
+    if (s < 0 || s >= e->nx || !img) return fail(TOMO_ERR_ARG, "slice index out of range");
+    if ((rc = ensure_stage(e, e->npix * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpyAsync(e->stage, img, e->npix * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_scatter_slice, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, e->stage, dst, e->npix, e->sx, s);
+    LAUNCHCHK();
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+int tomo_get_slice(tomo_engine *e, int vol, int s, float *img)
+{
+    NEED(e);
+    float *src; int rc = get_vol(e, vol, &src); if (rc) return rc;
+    if (s < 0 || s >= e->nx || !img) return fail(TOMO_ERR_ARG, "slice index out of range");
+    if ((rc = ensure_stage(e, e->npix * sizeof(float)))) return rc;
+    hipLaunchKernelGGL(k_gather_slice, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, src, e->stage, e->npix, e->sx, s);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(img, e->stage, e->npix * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+int tomo_restart_recon(tomo_engine *e)
+{
+    NEED(e);
+    HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_RECON], 0, e->vol_elems() * sizeof(float), e->stream));
+    if (e->vol[TOMO_VOL_YK]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_YK], 0, e->vol_elems() * sizeof(float), e->stream));
+    if (e->vol[TOMO_VOL_RECON_OLD]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_RECON_OLD], 0, e->vol_elems() * sizeof(float), e->stream));
+    return TOMO_OK;
+}
+
+int tomo_copy_volume(tomo_engine *e, int dst, int src)
+{
+    NEED(e);
+    float *d, *s; int rc;
+    if ((rc = get_vol(e, dst, &d)) || (rc = get_vol(e, src, &s))) return rc;
+    if (d != s) HIPCHK(hipMemcpyAsync(d, s, e->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    return TOMO_OK;
+}
+
+// ---- projector ------------------------------------------------------------------------------------------------
+int tomo_forward_projection(tomo_engine *e, int vol, int sino)
+{
+    NEED(e);
+    float *x, *g; int rc;
+    if ((rc = get_vol(e, vol, &x))) return rc;
+    if ((rc = sino == TOMO_SINO_B ? get_sino(e, &e->sino_b, &g) : get_sino(e, &e->sino_g, &g))) return rc;
+    return launch_fp<FP_STORE>(e, x, 0, (int)e->nrows, nullptr, g);
+}
+
+int tomo_back_projection(tomo_engine *e, int sino, int vol)
+{
+    NEED(e);
+    float *x, *g; int rc;
+    if ((rc = get_vol(e, vol, &x))) return rc;
+    if ((rc = sino == TOMO_SINO_B ? get_sino(e, &e->sino_b, &g) : get_sino(e, &e->sino_g, &g))) return rc;
+    return launch_bp_all(e, x, g, nullptr, 0.f, 1.f, 0);
+}
+
+int tomo_lipschitz(tomo_engine *e, float *L) { if (!e || !L) return fail(TOMO_ERR_ARG, "null"); *L = e->lipschitz; return TOMO_OK; }
+int tomo_row_inner_product(tomo_engine *e) { if (!e) return fail(TOMO_ERR_ARG, "null engine"); return TOMO_OK; /* built with the tables */ }
+
+// ---- reconstruction steps -----------------------------------------------------------------------------------------
+int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter)
+{
+    NEED(e);
+    float *x, *r; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
+    for (int it = 0; it < niter; ++it) {
+        if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, e->sino_b, r))) return rc;
+        if ((rc = launch_bp_all(e, x, r, nullptr, 1.f, beta, 1))) return rc;
+    }
+    return TOMO_OK;
+}
+
+int tomo_sirt(tomo_engine *e, int vol, int niter)
+{
+    NEED(e);
+    float *x, *r; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
+    for (int it = 0; it < niter; ++it) {
+        if ((rc = launch_fp<FP_RESID_NORM>(e, x, 0, (int)e->nrows, e->sino_b, r))) return rc;
+        if ((rc = launch_bp_all(e, x, r, e->d_colsum_all, 1.f, 1.f, 1))) return rc;
+    }
+    return TOMO_OK;
+}
+
+int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *order)
+{
+    NEED(e);
+    float *x, *r; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
+    if (order) {
+        std::vector<char> seen(e->np, 0);
+        for (int q = 0; q < e->np; ++q) {
+            if (order[q] < 0 || order[q] >= e->np || seen[order[q]]) return fail(TOMO_ERR_ARG, "SART order is not a permutation of the angles");
+            seen[order[q]] = 1;
+        }
+    }
+    for (int it = 0; it < niter; ++it)
+        for (int q = 0; q < e->np; ++q) {
+            int i = order ? order[q] : q;
+            {
+                ProfScope ps(e, TOMO_K_FP_ANGLE);
+                if ((rc = launch_fp<FP_RESID_NORM>(e, x, i * e->n, e->n, e->sino_b, r))) return rc;
+            }
+            if ((rc = launch_bp_angle(e, x, i, r + (size_t)i * e->n * e->sx, beta))) return rc;
+        }
+    return TOMO_OK;
+}
+
+int tomo_art(tomo_engine *e, float beta)
+{
+    NEED(e);
+    float *x = e->vol[TOMO_VOL_RECON];
+    hipLaunchKernelGGL(k_art, dim3(e->sx / 64), dim3(64), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowinner, beta, (int)e->nrows, e->sx);
+    LAUNCHCHK();
+    return tomo_positivity(e, TOMO_VOL_RECON);
+}
+
+int tomo_poisson_ml(tomo_engine *e, float lambda)
+{
+    NEED(e);
+    float *x = e->vol[TOMO_VOL_RECON], *r; int rc;
+    if ((rc = get_sino(e, &e->sino_r, &r))) return rc;
+    if ((rc = reduce_begin(e))) return rc;
+    if ((rc = launch_fp<FP_POISSON>(e, x, 0, (int)e->nrows, e->sino_b, r))) return rc;
+    if ((rc = reduce_end(e, TOMO_S_COST))) return rc;
+    return launch_bp_all(e, x, r, nullptr, 1.f, -(lambda / e->lipschitz), 1);
+}
+
+int tomo_positivity(tomo_engine *e, int vol)
+{
+    NEED(e);
+    float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
+    int64_t n4 = e->vol_elems() / 4;
+    hipLaunchKernelGGL(k_clamp, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, n4);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_soft_threshold(tomo_engine *e, int vol, float lambda)
+{
+    NEED(e);
+    float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
+    int64_t n4 = e->vol_elems() / 4;
+    hipLaunchKernelGGL(k_soft_threshold, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, lambda, n4);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_fista_momentum(tomo_engine *e, float beta)
+{
+    NEED(e);
+    float *x, *yk, *old; int rc;
+    if ((rc = get_vol(e, TOMO_VOL_RECON, &x)) || (rc = get_vol(e, TOMO_VOL_YK, &yk)) || (rc = get_vol(e, TOMO_VOL_RECON_OLD, &old))) return rc;
+    int64_t n4 = e->vol_elems() / 4;
+    hipLaunchKernelGGL(k_momentum, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (f4 *)yk, (f4 *)old, beta, n4);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+// ---- scalars --------------------------------------------------------------------------------------------------------
+int tomo_data_distance_sq(tomo_engine *e, int vol)
+{
+    NEED(e);
+    float *x, *g; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_g, &g))) return rc;
+    if ((rc = reduce_begin(e))) return rc;
+    if ((rc = launch_fp<FP_DD>(e, x, 0, (int)e->nrows, e->sino_b, g))) return rc;
+    return reduce_end(e, TOMO_S_DD);
+}
+
+int tomo_diff_norm_sq(tomo_engine *e, int a, int b, int slot)
+{
+    NEED(e);
+    if (slot < 0 || slot >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
+    float *pa, *pb; int rc;
+    if ((rc = get_vol(e, a, &pa)) || (rc = get_vol(e, b, &pb))) return rc;
+    if ((rc = reduce_begin(e))) return rc;
+    int64_t n4 = e->vol_elems() / 4;
+    hipLaunchKernelGGL(k_sqdiff, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const f4 *)pa, (const f4 *)pb, e->d_part, n4);
+    LAUNCHCHK();
+    return reduce_end(e, slot);
+}
+
+int tomo_l1_norm(tomo_engine *e, int vol)
+{
+    NEED(e);
+    float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
+    if ((rc = reduce_begin(e))) return rc;
+    int64_t n4 = e->vol_elems() / 4;
+    hipLaunchKernelGGL(k_l1, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const f4 *)x, e->d_part, n4);
+    LAUNCHCHK();
+    return reduce_end(e, TOMO_S_L1);
+}
+
+int tomo_read_scalars(tomo_engine *e, double *out, int count)
+{
+    NEED(e);
+    if (!out || count < 0 || count > TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar count");
+    HIPCHK(hipMemcpyAsync(out, e->d_scal, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+int tomo_bind_scalar_buffer(tomo_engine *e, void *device_doubles)
+{
+    NEED(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->d_scal = device_doubles ? (double *)device_doubles : e->d_scal_own;
+    return TOMO_OK;
+}
+
+// ---- TV -----------------------------------------------------------------------------------------------------------------
+static int field_ptr(tomo_engine *e, int field, float **out)
+{
+    if (field == TOMO_FIELD_FGP_D) return get_scratch(e, &e->tvg, out);
+    if (field == TOMO_FIELD_FGP_P1) return get_scratch(e, &e->fgp_p[0], out);
+    return get_vol(e, field, out);
+}
+
+int tomo_bind_halo(tomo_engine *e, void *device_lo, void *device_hi)
+{
+    NEED(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->halo_lo = device_lo ? (float *)device_lo : e->halo_lo_own;
+    e->halo_hi = device_hi ? (float *)device_hi : e->halo_hi_own;
+    return TOMO_OK;
+}
+
+int tomo_halo_pack(tomo_engine *e, int field, int last, void *device_dst)
+{
+    NEED(e);
+    float *x; int rc; if ((rc = field_ptr(e, field, &x))) return rc;
+    if (!device_dst) return fail(TOMO_ERR_ARG, "null destination");
+    hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, x, (float *)device_dst, (int)e->npix, e->sx, last ? e->nx - 1 : 0);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_halo_local(tomo_engine *e, int field)
+{
+    int rc;
+    if ((rc = tomo_halo_pack(e, field, 1, e->halo_lo))) return rc;   // below slice 0 sits the last slice
+    return tomo_halo_pack(e, field, 0, e->halo_hi);                  // above the last slice sits slice 0
+}
+
+int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last)
+{
+    if (!e) return fail(TOMO_ERR_ARG, "null engine");
+    e->is_first = is_first ? 1 : 0; e->is_last = is_last ? 1 : 0;
+    return TOMO_OK;
+}
+
+static int tv_grid(tomo_engine *e)
+{
+    int64_t items = e->npix * (e->sx / 64);
+    return (int)std::min<int64_t>((items + 3) / 4, 256 * 16);
+}
+
+int tomo_tv_partial(tomo_engine *e, int vol, float eps)
+{
+    NEED(e);
+    float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
+    if ((rc = reduce_begin(e))) return rc;
+    Halo h{e->halo_lo, e->halo_hi};
+    hipLaunchKernelGGL(k_tv_value, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx);
+    LAUNCHCHK();
+    return reduce_end(e, TOMO_S_TV);
+}
+
+int tomo_tv_grad(tomo_engine *e, float eps)
+{
+    NEED(e);
+    float *x = e->vol[TOMO_VOL_RECON], *g; int rc;
+    if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
+    if ((rc = reduce_begin(e))) return rc;
+    Halo h{e->halo_lo, e->halo_hi};
+    {
+        ProfScope ps(e, TOMO_K_TV_GRAD);
+        hipLaunchKernelGGL(k_tv_grad, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx);
+    }
+    LAUNCHCHK();
+    return reduce_end(e, TOMO_S_GNORM);
+}
+
+int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp)
+{
+    NEED(e);
+    float *x = e->vol[TOMO_VOL_RECON], *g; int rc;
+    if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
+    int64_t n4 = e->vol_elems() / 4;
+    {
+        ProfScope ps(e, TOMO_K_TV_UPDATE);
+        hipLaunchKernelGGL(k_tv_update, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4);
+    }
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_fgp_begin(tomo_engine *e)
+{
+    NEED(e);
+    float *d, *p; int rc;
+    if ((rc = get_scratch(e, &e->tvg, &d))) return rc;
+    HIPCHK(hipMemsetAsync(d, 0, e->vol_elems() * sizeof(float), e->stream));
+    for (int i = 0; i < 3; ++i) {
+        if ((rc = get_scratch(e, &e->fgp_p[i], &p))) return rc;
+        HIPCHK(hipMemsetAsync(p, 0, e->vol_elems() * sizeof(float), e->stream));
+    }
+    return TOMO_OK;
+}
+
+int tomo_fgp_obj(tomo_engine *e, float lambda)
+{
+    NEED(e);
+    if (!e->tvg || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_begin has not been called");
+    ProfScope ps(e, TOMO_K_FGP_OBJ);
+    hipLaunchKernelGGL(k_fgp_obj, dim3(tv_grid(e)), dim3(256), 0, e->stream, e->vol[TOMO_VOL_RECON], e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->halo_lo, e->is_first, lambda, e->n, e->nx, e->sx);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_fgp_grad(tomo_engine *e, float lambda)
+{
+    NEED(e);
+    if (!e->tvg || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_begin has not been called");
+    float multip = 1.0f / (26.0f * lambda);
+    ProfScope ps(e, TOMO_K_FGP_GRAD);
+    hipLaunchKernelGGL(k_fgp_grad, dim3(tv_grid(e)), dim3(256), 0, e->stream, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->halo_hi, e->is_last, multip, e->n, e->nx, e->sx);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_fgp_end(tomo_engine *e, int iters)
+{
+    NEED(e);
+    if (!e->tvg) return fail(TOMO_ERR_STATE, "tomo_fgp_begin has not been called");
+    (void)iters;  // D is the zero-filled buffer when no iteration ran, exactly like d_update (tv_fgp.cu:223,272)
+    HIPCHK(hipMemcpyAsync(e->vol[TOMO_VOL_RECON], e->tvg, e->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    return TOMO_OK;
+}
+
+int tomo_tv(tomo_engine *e, int vol, float eps)
+{
+    int rc;
+    if ((rc = tomo_halo_local(e, vol))) return rc;
+    return tomo_tv_partial(e, vol, eps);
+}
+
+int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps)
+{
+    int rc;
+    if ((rc = tomo_tv(e, TOMO_VOL_RECON, eps))) return rc;
+    for (int g = 0; g < ng; ++g) {
+        if (g > 0 && (rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc;
+        if ((rc = tomo_tv_grad(e, eps))) return rc;
+        if ((rc = tomo_tv_update(e, dPOCS, g == ng - 1))) return rc;
+    }
+    if (ng <= 0) return tomo_positivity(e, TOMO_VOL_RECON);
+    return TOMO_OK;
+}
+
+int tomo_tv_fgp(tomo_engine *e, int iters, float lambda)
+{
+    int rc;
+    if ((rc = tomo_tv(e, TOMO_VOL_RECON, 1e-6f))) return rc;    // tv_fgp.cu:170-189,231-238
+    if ((rc = tomo_fgp_begin(e))) return rc;
+    int f = e->is_first, l = e->is_last;
+    e->is_first = e->is_last = 1;
+    for (int i = 0; i < iters; ++i) {
+        if ((rc = tomo_fgp_obj(e, lambda)) || (rc = tomo_fgp_grad(e, lambda))) break;
+    }
+    e->is_first = f; e->is_last = l;
+    if (rc) return rc;
+    return tomo_fgp_end(e, iters);
+}
+
+// ---- measurement ------------------------------------------------------------------------------------------------------------
+int tomo_profile_enable(tomo_engine *e, int kernel, int on)
+{
+    NEED(e);
+    if (kernel < 0 || kernel >= PROF_MAX_KERNELS) return fail(TOMO_ERR_ARG, "bad kernel id");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->prof[kernel].on = on != 0;
+    e->prof[kernel].used = 0;
+    return TOMO_OK;
+}
+
+int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms)
+{
+    NEED(e);
+    if (kernel < 0 || kernel >= PROF_MAX_KERNELS || !launches || !total_ms) return fail(TOMO_ERR_ARG, "bad argument");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    ProfSlot &p = e->prof[kernel];
+    double tot = 0;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        tot += ms;
+    }
+    *launches = (int64_t)(p.used / 2);
+    *total_ms = tot;
+    p.used = 0;
+    return TOMO_OK;
+}
+
+}  // extern "C"

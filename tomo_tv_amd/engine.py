@@ -1,0 +1,505 @@
+"""Host-side mirror of the reference's native engine classes, over the C ABI of ``libtomo_hip.so``.
+
+* ``tomoengine``     -- method table of tomofusion/gpu/utils/tomoengine.cpp:487-534 (what ``TomoGPU`` and
+  ``tomofusion/pytvlib.py`` call).
+* ``multigpuengine`` -- tomofusion/gpu/utils/multigpuengine.cpp:385-421; here one process per GPU, each owning a
+  contiguous slab of x-slices (``distributed.py``), instead of OpenMP threads over host memory.
+* ``ctvlib``         -- method table of tomofusion/cpu/utils/ctvlib.cpp:486-520 (``load_A``, ``SIRT(beta)``, ``ART``,
+  ``lipschits`` ...), running on the GPU.
+
+Same method names, argument meaning and return values as the reference.  Scalar-returning methods synchronise.
+All arithmetic happens in HIP kernels; there is no CPU path (``_lib.load`` raises without the library).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COST, S_COUNT, S_DD, S_DIFF, S_GNORM, S_L1, S_RMSE, S_TV, SINO_B,
+                   SINO_G, VOL_ORIGINAL, VOL_RECON, VOL_RECON_OLD, VOL_TEMP, VOL_YK, check)
+from .distributed import SlabComm, slab_partition
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class _SlabBackend:
+    """The per-slab primitives: thin wrappers over the C ABI.  (tests substitute this class to exercise the
+    distributed composition on CPU/gloo; the product always uses this one.)"""
+
+    def __init__(self, nslice, nray, nproj, angles_rad=None, A=None, device=0):
+        self.L = _lib.load()
+        self.nslice, self.nray, self.nproj, self.device = nslice, nray, nproj, device
+        h = ctypes.c_void_p()
+        if A is not None:
+            A = np.asarray(A)
+            rows, cols, vals = _f32c(A[0]), _f32c(A[1]), _f32c(A[2])
+            check(self.L.tomo_create_from_matrix(nslice, nray, nproj, rows.size, _ptr(rows), _ptr(cols), _ptr(vals),
+                                                 device, ctypes.byref(h)))
+        else:
+            ang = np.ascontiguousarray(angles_rad, dtype=np.float64)
+            check(self.L.tomo_create(nslice, nray, nproj, _ptr(ang), device, ctypes.byref(h)))
+        self.h = h
+        self._scal_t = self._halo_lo = self._halo_hi = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tomo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # generic call: self.c("tv_grad", eps) -> tomo_tv_grad(h, eps)
+    def c(self, name, *args):
+        check(getattr(self.L, "tomo_" + name)(self.h, *args))
+
+    def scalars(self):
+        out = np.zeros(S_COUNT, np.float64)
+        self.c("read_scalars", _ptr(out), S_COUNT)
+        return out
+
+    # ---- torch plumbing for the distributed path (device tensors the collectives operate on) ----------
+    def enable_torch(self):
+        import torch
+        torch.cuda.set_device(self.device)
+        dev = torch.device("cuda", self.device)
+        self.c("set_stream", ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        self._scal_t = torch.zeros(S_COUNT, dtype=torch.float64, device=dev)
+        npix = self.nray * self.nray
+        self._halo_lo = torch.zeros(npix, dtype=torch.float32, device=dev)
+        self._halo_hi = torch.zeros(npix, dtype=torch.float32, device=dev)
+        self._send_lo = torch.zeros(npix, dtype=torch.float32, device=dev)
+        self._send_hi = torch.zeros(npix, dtype=torch.float32, device=dev)
+        self.c("bind_scalar_buffer", ctypes.c_void_p(self._scal_t.data_ptr()))
+        self.c("bind_halo", ctypes.c_void_p(self._halo_lo.data_ptr()), ctypes.c_void_p(self._halo_hi.data_ptr()))
+
+    def scalar_tensor(self, slot):
+        return self._scal_t[slot:slot + 1]
+
+    def pack_planes(self, field):
+        self.c("halo_pack", field, 0, ctypes.c_void_p(self._send_lo.data_ptr()))
+        self.c("halo_pack", field, 1, ctypes.c_void_p(self._send_hi.data_ptr()))
+        return self._send_lo, self._send_hi
+
+    def halo_tensors(self):
+        return self._halo_lo, self._halo_hi
+
+    def new_plane(self):
+        import torch
+        return torch.zeros(self.nray * self.nray, dtype=torch.float32, device=self._halo_lo.device)
+
+    def slice_to_tensor(self, vol, s):
+        import torch
+        img = np.empty((self.nray, self.nray), np.float32)
+        self.c("get_slice", vol, s, _ptr(img))
+        return torch.from_numpy(img).to(self._halo_lo.device)
+
+
+class _EngineBase:
+    """Shared implementation; ``comm`` is None for one slab = whole volume."""
+
+    _backend_cls = _SlabBackend
+
+    def _setup(self, Nslice, Nray, Nproj, angles_rad=None, A=None, device=None, comm=None):
+        self.Nslice_, self.Ny, self.Nz, self.Nproj = int(Nslice), int(Nray), int(Nray), int(Nproj)
+        self.Nrow, self.Ncol = self.Ny * self.Nproj, self.Ny * self.Nz
+        self.comm = comm
+        if comm is not None:
+            self.first, self.nloc = slab_partition(self.Nslice_, comm.world, comm.rank)
+            if self.nloc == 0:
+                raise ValueError("more ranks than slices")
+        else:
+            self.first, self.nloc = 0, self.Nslice_
+        self.gpuID = 0 if device is None else int(device)
+        self.be = self._backend_cls(self.nloc, self.Ny, self.Nproj, angles_rad=angles_rad, A=A, device=self.gpuID)
+        if comm is not None:
+            self.be.enable_torch()
+            self.be.c("set_slab_edges", int(comm.rank == 0), int(comm.rank == comm.world - 1))
+        self.momentum = False
+        self.tv_eps = 1e-6          # tv_gd.cu:29,54 (GPU path); ctvlib facade overrides to 1e-8
+        self.projOrder = "sequential"
+        self._order_rng = np.random.default_rng(0)
+        self.L_A = None
+        self.L_Aml = None
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    def _scalar(self, slot):
+        """Global value of a partial-sum slot."""
+        if self.comm is None:
+            return float(self.be.scalars()[slot])
+        t = self.be.scalar_tensor(slot)
+        self.comm.allreduce_sum(t)
+        return float(t.item())
+
+    def _exchange(self, field):
+        lo, hi = self.be.pack_planes(field)
+        hlo, hhi = self.be.halo_tensors()
+        self.comm.exchange_planes(lo, hi, hlo, hhi)
+
+    def _target(self):
+        return VOL_YK if self.momentum else VOL_RECON
+
+    def Nslice(self):
+        return self.Nslice_
+
+    def Nray(self):
+        return self.Ny
+
+    # ---- data ------------------------------------------------------------------------------------------
+    def set_tilt_series(self, b):
+        """(Nslice, Nray*Nproj), index angle*Nray+ray.  tomoengine.cpp:101."""
+        b = np.asarray(b)
+        if b.shape != (self.Nslice_, self.Nrow):
+            raise ValueError(f"tilt series must have shape {(self.Nslice_, self.Nrow)}, got {b.shape}")
+        loc = _f32c(b[self.first:self.first + self.nloc])
+        self.be.c("set_tilt_series", _ptr(loc))
+
+    def _owner(self, s):
+        if s < 0 or s >= self.Nslice_:
+            raise IndexError(f"slice {s} out of range [0, {self.Nslice_})")
+        if self.comm is None:
+            return 0
+        base, rem = divmod(self.Nslice_, self.comm.world)
+        return s // (base + 1) if s < rem * (base + 1) else rem + (s - rem * (base + 1)) // base
+
+    def _set_slice(self, vol, img, s):
+        img = _f32c(img)
+        if img.shape != (self.Ny, self.Nz):
+            raise ValueError(f"slice must have shape {(self.Ny, self.Nz)}")
+        if self.first <= s < self.first + self.nloc:
+            self.be.c("set_slice", vol, s - self.first, _ptr(img))
+        else:
+            self._owner(s)
+
+    def _get_slice(self, vol, s):
+        owner = self._owner(s)
+        if self.comm is None:
+            img = np.empty((self.Ny, self.Nz), np.float32)
+            self.be.c("get_slice", vol, s, _ptr(img))
+            return img
+        if self.comm.rank == owner:
+            t = self.be.slice_to_tensor(vol, s - self.first)
+        else:
+            t = self.be.new_plane().view(self.Ny, self.Nz)
+        self.comm.broadcast(t, owner)
+        return t.cpu().numpy()
+
+    def set_recon(self, img, s):
+        self._set_slice(VOL_RECON, img, s)
+
+    def get_recon(self, s):
+        return self._get_slice(VOL_RECON, s)
+
+    def set_original_volume(self, img, s):
+        self._set_slice(VOL_ORIGINAL, img, s)
+
+    def initialize_initial_volume(self):
+        pass  # volumes are allocated on first use
+
+    initialize_original_volume = initialize_initial_volume
+
+    def initialize_recon_copy(self):
+        pass
+
+    def initialize_tv_recon(self):
+        pass
+
+    def set_volume(self, vol, which=VOL_RECON):
+        """Bulk form of set_recon / set_original_volume: (Nslice, Ny, Nz)."""
+        vol = np.asarray(vol)
+        if vol.shape != (self.Nslice_, self.Ny, self.Nz):
+            raise ValueError("bad volume shape")
+        loc = _f32c(vol[self.first:self.first + self.nloc])
+        self.be.c("set_volume", which, _ptr(loc))
+
+    def get_volume_local(self, which=VOL_RECON):
+        out = np.empty((self.nloc, self.Ny, self.Nz), np.float32)
+        self.be.c("get_volume", which, _ptr(out))
+        return out
+
+    def get_volume(self, which=VOL_RECON):
+        loc = self.get_volume_local(which)
+        if self.comm is None or self.comm.world == 1:
+            return loc
+        import torch
+        parts = [None] * self.comm.world
+        self.comm.dist.all_gather_object(parts, loc, group=self.comm.group)
+        return np.concatenate(parts, axis=0)
+
+    def _sino(self, which):
+        out = np.empty((self.nloc, self.Nrow), np.float32)
+        self.be.c("get_sinogram", which, _ptr(out))
+        if self.comm is None or self.comm.world == 1:
+            return out
+        parts = [None] * self.comm.world
+        self.comm.dist.all_gather_object(parts, out, group=self.comm.group)
+        return np.concatenate(parts, axis=0)
+
+    def get_projections(self):
+        return self._sino(SINO_B)
+
+    def get_model_projections(self):
+        return self._sino(SINO_G)
+
+    def restart_recon(self):
+        self.be.c("restart_recon")
+
+    def copy_recon(self):
+        self.be.c("copy_volume", VOL_TEMP, VOL_RECON)
+
+    def create_projections(self):
+        """b = A * original_volume.  tomoengine.cpp:109-126 / ctvlib.cpp:101-115."""
+        self.be.c("forward_projection", VOL_ORIGINAL, SINO_B)
+
+    def forward_projection(self):
+        """g = A * recon.  tomoengine.cpp:416-427."""
+        self.be.c("forward_projection", VOL_RECON, SINO_G)
+
+    def back_projection_of_tilt_series(self):
+        """recon = A^T b (used by tests / Lipschitz checks)."""
+        self.be.c("back_projection", SINO_B, VOL_RECON)
+
+    def positivity(self):
+        self.be.c("positivity", VOL_RECON)
+
+    # ---- scalars -----------------------------------------------------------------------------------------
+    def matrix_2norm(self):
+        self.be.c("diff_norm_sq", VOL_RECON, VOL_TEMP, S_DIFF)
+        return float(np.sqrt(self._scalar(S_DIFF)))
+
+    def rmse(self):
+        self.be.c("diff_norm_sq", VOL_RECON, VOL_ORIGINAL, S_RMSE)
+        return float(np.sqrt(self._scalar(S_RMSE) / (self.Nslice_ * self.Ny * self.Nz)))
+
+    def l1_norm(self):
+        self.be.c("l1_norm", VOL_RECON)
+        return self._scalar(S_L1)
+
+    def _data_distance_raw(self):
+        self.be.c("data_distance_sq", VOL_RECON)
+        return float(np.sqrt(self._scalar(S_DD)))
+
+    # ---- TV ----------------------------------------------------------------------------------------------------
+    def _tv_of(self, vol, eps):
+        if self.comm is None:
+            self.be.c("tv", vol, eps)
+        else:
+            self._exchange(vol)
+            self.be.c("tv_partial", vol, eps)
+        return self._scalar(S_TV)
+
+    def tv(self):
+        return self._tv_of(VOL_RECON, self.tv_eps)
+
+    def original_tv(self):
+        return self._tv_of(VOL_ORIGINAL, self.tv_eps)
+
+    def tv_gd(self, ng, dPOCS):
+        """ng steps of x -= dPOCS * g/||g|| then clamp; returns TV before descent (tv_gd.cu:141-218)."""
+        ng = int(ng)
+        if self.comm is None:
+            self.be.c("tv_gd", ng, float(dPOCS), self.tv_eps)
+            return self._scalar(S_TV)
+        tv0 = self._tv_of(VOL_RECON, self.tv_eps)
+        for g in range(ng):
+            if g > 0:
+                self._exchange(VOL_RECON)
+            self.be.c("tv_grad", self.tv_eps)
+            self.comm.allreduce_sum(self.be.scalar_tensor(S_GNORM))   # stays on the device
+            self.be.c("tv_update", float(dPOCS), int(g == ng - 1))
+        if ng <= 0:
+            self.be.c("positivity", VOL_RECON)
+        return tv0
+
+    def tv_fgp(self, ng, lam):
+        """FGP-TV prox on recon (tv_fgp.cu:192-281); returns TV of the input."""
+        ng, lam = int(ng), float(lam)
+        if self.comm is None:
+            self.be.c("tv_fgp", ng, lam)
+            return self._scalar(S_TV)
+        tv0 = self._tv_of(VOL_RECON, 1e-6)
+        self.be.c("fgp_begin")
+        for _ in range(ng):
+            self._exchange(FIELD_FGP_P1)
+            self.be.c("fgp_obj", lam)
+            self._exchange(FIELD_FGP_D)
+            self.be.c("fgp_grad", lam)
+        self.be.c("fgp_end", ng)
+        return tv0
+
+    def soft_threshold(self, lam):
+        self.be.c("soft_threshold", self._target(), float(lam))
+        self.be.c("positivity", self._target())
+
+    # ---- FISTA (tomoengine.cpp:350-384) ---------------------------------------------------------------------------
+    def initialize_fista(self):
+        self.momentum = True
+        self.be.c("copy_volume", VOL_YK, VOL_RECON)
+        self.be.c("copy_volume", VOL_RECON_OLD, VOL_RECON)
+        self.L_A = self.get_lipschitz()
+
+    def get_lipschitz(self):
+        L = ctypes.c_float(0)
+        check(self.be.L.tomo_lipschitz(self.be.h, ctypes.byref(L)))
+        return float(L.value)
+
+    def remove_momentum(self):
+        self.momentum = False
+
+    def fista_momentum(self, beta):
+        self.be.c("fista_momentum", float(beta))
+
+    def synchronize(self):
+        self.be.c("synchronize")
+
+
+class tomoengine(_EngineBase):
+    """``tomoengine(Nslice, Nray, angles_rad)`` -- tomofusion/gpu/utils/tomoengine.cpp:48-84."""
+
+    def __init__(self, Nslice, Nray, pyAngles=None, device=None, comm=None):
+        ang = np.zeros(1) if pyAngles is None else np.ascontiguousarray(pyAngles, dtype=np.float64).ravel()
+        self._setup(Nslice, Nray, ang.size, angles_rad=ang, device=device, comm=comm)
+
+    # GPU selection (tomoengine.cpp:87-95): the device is fixed at construction in this build
+    def set_gpu(self, gpu_id):
+        if int(gpu_id) != self.gpuID:
+            raise _lib.TomoError("set_gpu after construction is not supported: pass device= to the constructor")
+
+    def get_gpu_id(self):
+        return self.gpuID
+
+    # initialisers of the ASTRA objects (tomoengine.cpp:151-254): state only
+    def initialize_SIRT(self):
+        pass
+
+    def initialize_SART(self, order="sequential"):
+        if order not in ("sequential", "random"):
+            raise ValueError("SART projection order must be 'sequential' or 'random'")
+        self.projOrder = order
+
+    def initialize_FP(self):
+        pass
+
+    def initialize_BP(self):
+        pass
+
+    def initialize_CGLS(self):
+        raise NotImplementedError("CGLS is outside this round's hot-path scope (SURVEY.md section 8f rank 1)")
+
+    def initialize_FBP(self, filter_name="ram-lak"):
+        raise NotImplementedError("FBP/WBP is outside this round's hot-path scope (SURVEY.md section 8f rank 2)")
+
+    def initialize_poisson_ML(self):
+        """tomoengine.cpp:231-246: L = max(A^T A 1); normalise the tilt series by its maximum if > 1."""
+        self.L_Aml = self.get_lipschitz()
+        b = self.get_projections()
+        m = float(b.max())
+        if m > 1:
+            self.set_tilt_series(b / m)
+
+    def SIRT(self, nIter=1):
+        """ASTRA SIRT with min-constraint 0 on recon, or on yk under momentum (tomoengine.cpp:189-205)."""
+        self.be.c("sirt", self._target(), int(nIter))
+
+    def SART(self, beta=1.0, nIter=1):
+        """Nproj*nIter single-angle updates, relaxation beta, min-constraint 0 (tomoengine.cpp:162-179)."""
+        if self.projOrder == "random":
+            order = np.ascontiguousarray(self._order_rng.permutation(self.Nproj), dtype=np.int32)
+            if self.comm is not None and self.comm.world > 1:   # every rank must sweep the same order
+                import torch
+                t = torch.from_numpy(order.astype(np.int64)).to(self.be.halo_tensors()[0].device)
+                self.comm.broadcast(t, 0)
+                order = np.ascontiguousarray(t.cpu().numpy(), dtype=np.int32)
+            self.be.c("sart", VOL_RECON, float(beta), int(nIter), _ptr(order))
+        else:
+            self.be.c("sart", VOL_RECON, float(beta), int(nIter), None)
+
+    def poisson_ML(self, lam):
+        self.be.c("poisson_ml", float(lam))
+        return self._scalar(S_COST)
+
+    def data_distance(self):
+        """||A recon - b||_2, un-normalised (tomoengine.cpp:410-413)."""
+        return self._data_distance_raw()
+
+
+class multigpuengine(tomoengine):
+    """Slab-sharded engine: construct it in every rank of a ``torchrun`` job with the GLOBAL sizes.
+
+    Replaces the OpenMP-thread-per-GPU class of tomofusion/gpu/utils/multigpuengine.cpp (host-resident volume,
+    dynamic per-slice scheduling, TV on one GPU) by static device-resident slabs + RCCL."""
+
+    def __init__(self, Nslice, Nray, pyAngles=None, group=None):
+        import torch
+        comm = SlabComm(group)
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        super().__init__(Nslice, Nray, pyAngles, device=dev, comm=comm)
+
+    def get_gpu_ids(self):
+        import torch
+        ids = [None] * self.comm.world
+        self.comm.dist.all_gather_object(ids, self.gpuID, group=self.comm.group)
+        return ids
+
+    def is_multi_gpu_enabled(self):
+        return self.comm.world > 1
+
+    def print_gpu_usage(self):
+        if self.comm.rank == 0:
+            print(f"{self.comm.world} ranks, one GPU each; slab of rank 0: {self.nloc} of {self.Nslice_} slices")
+
+
+class ctvlib(_EngineBase):
+    """``ctvlib(Nslice, Nray, Nproj)`` + ``load_A`` -- tomofusion/cpu/utils/ctvlib.cpp:28-48, 309-315, on the GPU."""
+
+    def __init__(self, Nslice, Nray, Nproj, device=None, comm=None):
+        self._ctor = (int(Nslice), int(Nray), int(Nproj), device, comm)
+        self.be = None
+
+    def load_A(self, A):
+        Nslice, Nray, Nproj, device, comm = self._ctor
+        if self.be is not None:
+            self.be.close()
+        self._setup(Nslice, Nray, Nproj, A=A, device=device, comm=comm)
+        self.tv_eps = 1e-8  # ctvlib.cpp:339,408
+
+    def row_inner_product(self):
+        self.be.c("row_inner_product")
+
+    def lipschits(self):
+        return self.get_lipschitz()
+
+    def SIRT(self, beta):
+        """Landweber step + positivity (ctvlib.cpp:205-221)."""
+        self.be.c("sirt_landweber", VOL_RECON, float(beta), 1)
+
+    def ART(self, beta):
+        self.be.c("art", float(beta))
+
+    def data_distance(self):
+        """||A recon - b||_2 / (Nslice*Nrow)  (ctvlib.cpp:272-276)."""
+        return self._data_distance_raw() / (self.Nslice_ * self.Nrow)
+
+    def tv_gd(self, ng, dPOCS):  # void in the reference (ctvlib.cpp:406); the TV value is returned as a courtesy
+        return super().tv_gd(ng, dPOCS)
+
+
+def system_matrix(Nside, angles_deg):
+    """Drop-in for ``parallelRay(Nside, angles)`` (tomofusion/cpu/utils/pytvlib.py:8-121): float32 (3, nnz)."""
+    L = _lib.load()
+    ang = np.ascontiguousarray(np.asarray(angles_deg, dtype=np.float64) * np.pi / 180)
+    nnz = ctypes.c_int64(0)
+    check(L.tomo_system_matrix(int(Nside), ang.size, _ptr(ang), 0, None, None, None, ctypes.byref(nnz)))
+    A = np.empty((3, nnz.value), np.float32)
+    check(L.tomo_system_matrix(int(Nside), ang.size, _ptr(ang), nnz.value, _ptr(A[0]), _ptr(A[1]), _ptr(A[2]),
+                               ctypes.byref(nnz)))
+    return A
