@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SART+TV (one ASD-POCS outer iteration) at 512^3 x 90 tilts per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one ASD-POCS outer iteration (examples/sim_ASD.py:66-94): copy_recon, one SART sweep over all
+tilts, step norm, data distance (a full forward projection), copy_recon, 10 TV gradient-descent steps, step
+norm.  Synthetic phantom + tilt series are resident in HBM before the timed region.  N > 1: one rank per GPU,
+each owns a 512-slice slab (weak scaling); the only cross-rank traffic is scalar all-reduces and TV halo planes.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def asd_pocs_step(t, st):
+    """One outer iteration, state dict st carries beta / dPOCS (defaults of gpu/reconstructor.py:158-161)."""
+    t.copy_recon()
+    t.SART(st["beta"], 1)
+    st["beta"] *= 0.9985
+    if st["i"] == 0:
+        st["dPOCS"] = t.matrix_2norm() * 0.2
+        dp = st["dPOCS"] / 0.2
+    else:
+        dp = t.matrix_2norm()
+    dd = t.data_distance() / st["norm"]
+    t.copy_recon()
+    tv = t.tv_gd(10, st["dPOCS"])
+    dg = t.matrix_2norm()
+    if dg > dp * 0.95 and dd > 0.025:
+        st["dPOCS"] *= 0.95
+    st["i"] += 1
+    return dd, tv
+
+
+def cpu_baseline(n, nproj, budget_s=20.0):
+    """The C oracle (OpenMP over slices, like ctvlib.cpp:207) on a bounded sample of the same workload."""
+    import oracle
+    from tomo_tv_amd.phantom import ellipsoids, tilt_angles
+    threads = oracle.num_threads()
+    ns = max(8, 2 * threads)
+    ang = tilt_angles(nproj)
+    A = oracle.parallel_ray(n, ang)
+    ref = oracle.ctvlib(ns, n, nproj)
+    ref.load_A(A)
+    ref.original_volume = ellipsoids(ns, n)
+    ref.create_projections()
+    ref.initialize_recon_copy()
+    ref.tv_eps = 1e-6
+    st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(ns * n * nproj)}
+    # the oracle has the same method names, so the same step function drives it
+    ref.data_distance_n = ref.data_distance
+    class _Shim:
+        def __getattr__(self, k):
+            return getattr(ref, k)
+        def data_distance(self):
+            return ref.data_distance(normalize=False)
+    shim = _Shim()
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        asd_pocs_step(shim, st)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 5:
+            break
+    vox = ns * n * n
+    return {"value": vox * iters / el / 1e9, "unit": "Gvoxel-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} ASD-POCS iterations on a {ns}x{n}x{n} slab, {nproj} tilts (oracle/tomo_oracle.c, OpenMP over slices)",
+            "iters_per_s_full_volume_equiv": iters / el * ns / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=512, help="Nray = Ny = Nz")
+    ap.add_argument("--nslice", type=int, default=512, help="slices per GPU")
+    ap.add_argument("--nproj", type=int, default=90)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from tomo_tv_amd import _lib
+    from tomo_tv_amd._lib import K_BP_ANGLE, VOL_ORIGINAL
+    from tomo_tv_amd.engine import multigpuengine, tomoengine
+    from tomo_tv_amd.phantom import ellipsoids, tilt_angles
+    import ctypes
+
+    n, nproj, nloc = args.n, args.nproj, args.nslice
+    ang = np.deg2rad(tilt_angles(nproj))
+    comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        t = multigpuengine(nloc * world, n, ang)
+        comm = t.comm
+    else:
+        t = tomoengine(nloc, n, ang, device=0)
+    # synthetic data: every rank's slab is the same seeded phantom (weak scaling: identical per-GPU work)
+    vol = ellipsoids(nloc, n)
+    t.be.c("set_volume", VOL_ORIGINAL, vol.ctypes.data_as(ctypes.c_void_p))
+    del vol
+    t.create_projections()
+    t.initialize_SART("sequential")
+    t.restart_recon()
+    st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
+
+    def sync():
+        t.synchronize()
+        if comm is not None:
+            comm.barrier()
+
+    for _ in range(args.warmup):
+        asd_pocs_step(t, st)
+    sync()
+    _lib.check(t.be.L.tomo_profile_enable(t.be.h, K_BP_ANGLE, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dd, tv = asd_pocs_step(t, st)
+    sync()
+    el = time.perf_counter() - t0
+    launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.check(t.be.L.tomo_profile_read(t.be.h, K_BP_ANGLE, ctypes.byref(launches), ctypes.byref(total_ms)))
+    _lib.check(t.be.L.tomo_profile_enable(t.be.h, K_BP_ANGLE, 0))
+    if comm is not None:
+        import torch
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        comm.allreduce_max(tt)
+        el = float(tt.item())
+
+    if rank == 0:
+        vox_total = nloc * world * n * n
+        # one SART single-angle BP update streams the slab once in, once out, and reads
+        # that angle's residual rows:  8 V + 4 Nx N bytes per launch (V = voxels of the slab)
+        bp_bytes = 8.0 * nloc * n * n + 4.0 * nloc * n
+        avg_ms = total_ms.value / max(launches.value, 1)
+        achieved = bp_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "SART+TV Gvoxel-updates/s (ASD-POCS outer iterations x voxels, 512^3 x 90 tilts per GPU)",
+            "value": vox_total * args.steps / el / 1e9,
+            "unit": "Gvoxel-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "iters_per_s": args.steps / el,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"ASD-POCS iteration (SART sweep beta0=0.25 + 10 TV-GD steps), {nloc}x{n}x{n} voxels per GPU, "
+                                   f"{nproj} tilts -70..70 deg (BASELINE configs[2] shape; headline SART+TV 512^3x90)",
+                       "slices_per_gpu": nloc, "nray": n, "nproj": nproj, "sharding": f"tilt-axis slabs x{world}"},
+            "final_dd": dd, "final_tv": tv,
+            "roofline": {"kernel": "k_bp_angle (voxel-driven single-angle SART back-projection update)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": int(launches.value), "avg_ms": avg_ms, "algorithmic_bytes_per_launch": bp_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, nproj)
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,16 +17,21 @@ def ellipsoids(nx, n, seed=1234, k=20, dtype=np.float32):
     vol = np.zeros((nx, n, n), np.float32)
     yy, zz = np.meshgrid(gy, gy, indexing="ij")
     cyl = (yy * yy + zz * zz) <= 0.95 ** 2
-    for s in range(nx):
-        sl = np.zeros((n, n), np.float32)
-        for e in range(k):
+    for e in range(k):
+        # bounding box of the ellipse footprint in (y, z): only those pixels are tested
+        jy = np.nonzero(np.abs(gy - c[e, 1]) <= r[e, 1])[0]
+        jz = np.nonzero(np.abs(gy - c[e, 2]) <= r[e, 2])[0]
+        if jy.size == 0 or jz.size == 0:
+            continue
+        ys, zs = slice(jy[0], jy[-1] + 1), slice(jz[0], jz[-1] + 1)
+        q = ((yy[ys, zs] - c[e, 1]) / r[e, 1]) ** 2 + ((zz[ys, zs] - c[e, 2]) / r[e, 2]) ** 2
+        for s in range(nx):
             dx = (gx[s] - c[e, 0]) / r[e, 0]
             rem = 1.0 - dx * dx
             if rem <= 0:
                 continue
-            m = ((yy - c[e, 1]) / r[e, 1]) ** 2 + ((zz - c[e, 2]) / r[e, 2]) ** 2 <= rem
-            sl[m] += a[e]
-        vol[s] = np.clip(sl, 0, 1) * cyl
+            vol[s, ys, zs] += np.where(q <= rem, np.float32(a[e]), np.float32(0))
+    vol = np.clip(vol, 0, 1) * cyl[None]
     return vol.astype(dtype)
 
 

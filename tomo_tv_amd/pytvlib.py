@@ -1,0 +1,97 @@
+"""String -> method dispatch, mirroring tomofusion/pytvlib.py:5-39 (GPU engines) and
+tomofusion/cpu/utils/pytvlib.py:171-213 (ctvlib harness helpers).  File IO helpers of the reference
+(HDF5/TIFF, pytvlib.py:57-162) are out of this build's scope."""
+import numpy as np
+
+from .engine import system_matrix
+
+
+def initialize_algorithm(tomo, alg, initAlg=""):
+    """tomofusion/pytvlib.py:5-19."""
+    a = alg.lower()
+    if a == "sirt":
+        tomo.initialize_SIRT()
+    elif a == "cgls":
+        tomo.initialize_CGLS()
+    elif a == "fista":
+        tomo.initialize_fista()
+    elif a in ("poisson_ml", "kl-divergence"):
+        tomo.initialize_poisson_ML()
+    elif a in ("sart", "asd-pocs"):
+        tomo.initialize_SART(initAlg if initAlg else "sequential")
+    elif a in ("fbp", "wbp"):
+        tomo.initialize_FBP(initAlg)
+    tomo.initialize_FP()
+
+
+def run(tomo, alg, beta=1, niter=1):
+    """tomofusion/pytvlib.py:21-31 (plus the 'asd-pocs' -> SART branch the reference lacks, quirk Q8)."""
+    a = alg.lower()
+    if a in ("sirt", "fista"):
+        tomo.SIRT(niter)
+    elif a == "cgls":
+        tomo.CGLS(niter)
+    elif a in ("sart", "asd-pocs"):
+        tomo.SART(beta, niter)
+    elif a in ("fbp", "wbp"):
+        tomo.FBP(True)
+    elif a in ("poisson_ml", "kl-divergence"):
+        return tomo.poisson_ML(beta)
+
+
+def wbp_filters():
+    return ["ram-lak", "shepp-logan", "hamming", "cosine", "parzen", "lanczos", "triangular", "gaussian",
+            "blackman", "nuttall", "blackman-harris", "kaiser"]
+
+
+def sart_orders():
+    return ["sequential", "random"]
+
+
+def check_hip():
+    """Replaces check_cuda (tomofusion/pytvlib.py:42-51): raise unless a HIP device and the library exist."""
+    from . import _lib
+    if _lib.device_count() == 0:
+        raise _lib.TomoError("no HIP device visible")
+
+
+# ---- ctvlib harness helpers (tomofusion/cpu/utils/pytvlib.py) ---------------------------------------------
+def parallelRay(Nside, angles):
+    """cpu/utils/pytvlib.py:8-121; angles in degrees; returns float32 (3, nnz) [row, col, val]."""
+    return system_matrix(Nside, angles)
+
+
+def initialize_ctvlib(tomo, alg, Nray, tiltAngles):
+    """cpu/utils/pytvlib.py:178-189 (angleStart == 0 branch)."""
+    tomo.load_A(parallelRay(Nray, np.asarray(tiltAngles)))
+    if alg in ("ART", "randART"):
+        tomo.row_inner_product()
+
+
+def run_ctvlib(tomo, alg, beta=1):
+    """cpu/utils/pytvlib.py:171-176."""
+    if alg == "SIRT":
+        tomo.SIRT(beta)
+    elif alg == "ART":
+        tomo.ART(beta)
+    else:
+        raise NotImplementedError(f"{alg}: only the Landweber SIRT and ART branches are on the hot path")
+
+
+def create_projections(tomo, original_volume):
+    """cpu/utils/pytvlib.py:191-206 without the noise branch."""
+    tomo.initialize_original_volume()
+    for s in range(original_volume.shape[0]):
+        tomo.set_original_volume(original_volume[s], s)
+    tomo.create_projections()
+
+
+def pack_tilt_series(tiltSeries):
+    """(Nslice, Nray, Nangles) -> (Nslice, Nray*Nangles) with index angle*Nray+ray
+    (gpu/reconstructor.py:54-56, cpu/utils/pytvlib.py:208-213)."""
+    ts = np.asarray(tiltSeries)
+    return np.ascontiguousarray(ts.transpose(0, 2, 1)).reshape(ts.shape[0], -1)
+
+
+def load_exp_tilt_series(tomo, tiltSeries):
+    tomo.set_tilt_series(pack_tilt_series(tiltSeries))

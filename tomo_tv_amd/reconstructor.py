@@ -1,0 +1,141 @@
+"""``TomoGPU`` -- the public reconstruction API of tomofusion/gpu/reconstructor.py:11-215 on the HIP engine.
+
+Same constructor and driver methods (``sirt``, ``sart``, ``fista``, ``asd_pocs``, ``kl_divergence``, ``get_recon``);
+the matplotlib/Tk viewers of the reference are not part of the hot path.  Broken reference drivers are implemented
+to the semantics of their canonical loops:
+``fista`` is the textbook x_k = prox_TV(SIRT(y_k)) + momentum, ``asd_pocs`` follows examples/sim_ASD.py:66-94.
+"""
+import numpy as np
+
+from . import _lib, pytvlib
+from ._lib import VOL_RECON, VOL_YK
+from .engine import multigpuengine, tomoengine
+
+
+def device_count():
+    """List of visible GPU ids (tomofusion/__init__.py:10-18)."""
+    return list(range(_lib.device_count()))
+
+
+def determine_gpu_config(gpu_id=-1):
+    """tomofusion/__init__.py:21-34; 'multigpu' here means: running under torch.distributed with >1 rank."""
+    if len(device_count()) == 0:
+        raise ValueError("An AMD GPU is needed for this package!")
+    try:
+        import torch.distributed as dist
+        if gpu_id < 0 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return "multigpu"
+    except ImportError:
+        pass
+    return "singleconfig"
+
+
+class TomoGPU:
+
+    def __init__(self, tiltAngles, tiltSeries=None, gpu_id=-1, verbose=False):
+        """tiltAngles in degrees, tiltSeries (Nslice, Nray, Nangles) with axis 0 = tilt axis."""
+        pytvlib.check_hip()
+        tiltAngles = np.asarray(tiltAngles, dtype=np.float64)
+        self.Nslice, self.Nray, self.Nangles = tiltSeries.shape
+        if tiltAngles.size != self.Nangles:
+            raise ValueError("tiltAngles and tiltSeries disagree on the number of projections")
+        config = determine_gpu_config(gpu_id)
+        if config == "singleconfig":
+            self.tomo = tomoengine(self.Nslice, self.Nray, np.deg2rad(tiltAngles), device=max(gpu_id, 0))
+        else:
+            self.tomo = multigpuengine(self.Nslice, self.Nray, np.deg2rad(tiltAngles))
+        self.verbose = verbose
+        self.set_tilt_series(tiltSeries)
+        self.recon = None
+        self.cost = None
+
+    def set_tilt_series(self, tiltSeries):
+        self.Nslice, self.Nray, self.Nangles = tiltSeries.shape
+        self.recon = None
+        self.tomo.set_tilt_series(pytvlib.pack_tilt_series(tiltSeries))
+
+    # ---- drivers (gpu/reconstructor.py:61-192) ---------------------------------------------------------
+    def _run_iterative(self, alg, Niter, show_convergence=True):
+        self.cost = np.zeros(Niter)
+        self.tomo.restart_recon()
+        for i in range(Niter):
+            pytvlib.run(self.tomo, alg)
+            if show_convergence:
+                self.cost[i] = self.tomo.data_distance()
+        return self.cost
+
+    def sart(self, Niter=150, init="sequential", show_convergence=True):
+        if init not in pytvlib.sart_orders():
+            init = "sequential"
+        pytvlib.initialize_algorithm(self.tomo, "SART", init)
+        return self._run_iterative("SART", Niter, show_convergence)
+
+    def sirt(self, Niter=150, show_convergence=True):
+        pytvlib.initialize_algorithm(self.tomo, "SIRT")
+        return self._run_iterative("SIRT", Niter, show_convergence)
+
+    def kl_divergence(self, Niter=100, lambda_param=0.1):
+        self.tomo.restart_recon()
+        pytvlib.initialize_algorithm(self.tomo, "kl-divergence")
+        self.cost = np.zeros(Niter)
+        for i in range(Niter):
+            self.cost[i] = pytvlib.run(self.tomo, "kl-divergence", lambda_param)
+        return self.cost
+
+    def fista(self, Niter=100, momentum=True, lambda_param=0.1, nTViter=10, show_convergence=True):
+        """gpu/reconstructor.py:121-155 with the TV prox actually feeding the iterate (quirk Q6)."""
+        t = self.tomo
+        pytvlib.initialize_algorithm(t, "fista")
+        if not momentum:
+            t.remove_momentum()
+        self.cost = np.zeros(Niter)
+        t0 = 1.0
+        for k in range(Niter):
+            pytvlib.run(t, "fista")                       # gradient step on yk (or recon without momentum)
+            if momentum:
+                t.be.c("copy_volume", VOL_RECON, VOL_YK)  # prox acts on the stepped point ...
+            t.tv_fgp(nTViter, lambda_param)
+            if momentum:
+                t.be.c("copy_volume", VOL_YK, VOL_RECON)  # ... and its result is what momentum extrapolates
+                tk = 0.5 * (1 + np.sqrt(1 + 4 * t0 ** 2))
+                t.fista_momentum((t0 - 1) / tk)
+                t0 = tk
+            if show_convergence:
+                self.cost[k] = 0.5 * t.data_distance() ** 2 + lambda_param * t.tv()
+        return self.cost
+
+    def asd_pocs(self, Niter=100, eps=0.025, beta0=0.25, beta_reduce=0.9985, r_max=0.95, nTViter=10, alpha=0.2,
+                 alpha_reduce=0.95, show_convergence=True, normalize_dd=True, init="sequential"):
+        """examples/sim_ASD.py:66-94 == demo.ipynb cell 25 (the reference method itself is broken, quirk Q7).
+
+        ``normalize_dd``: divide the data distance by Nslice*Nrow as the CPU path does (ctvlib.cpp:275), which is
+        what the default ``eps`` presumes (quirk Q5)."""
+        t = self.tomo
+        pytvlib.initialize_algorithm(t, "asd-pocs", init)
+        t.initialize_recon_copy()
+        t.restart_recon()
+        beta = beta0
+        self.dd_vec, self.tv_vec = np.zeros(Niter), np.zeros(Niter)
+        dPOCS = 0.0
+        norm = float(t.Nslice_ * t.Nrow) if normalize_dd else 1.0
+        for i in range(Niter):
+            t.copy_recon()
+            pytvlib.run(t, "sart", beta)
+            beta *= beta_reduce
+            if i == 0:
+                dPOCS = t.matrix_2norm() * alpha
+                dp = dPOCS / alpha
+            else:
+                dp = t.matrix_2norm()
+            self.dd_vec[i] = t.data_distance() / norm
+            t.copy_recon()
+            self.tv_vec[i] = t.tv_gd(nTViter, dPOCS)
+            dg = t.matrix_2norm()
+            if dg > dp * r_max and self.dd_vec[i] > eps:
+                dPOCS *= alpha_reduce
+        return self.dd_vec, self.tv_vec
+
+    def get_recon(self):
+        """(Nslice, Nray, Nray) float64 like the reference (gpu/reconstructor.py:207-215)."""
+        self.recon = self.tomo.get_volume(VOL_RECON).astype(np.float64)
+        return self.recon
