@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--nslice", type=int, default=512, help="slices per GPU")
     ap.add_argument("--nproj", type=int, default=90)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tomo_set_option), repeatable")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,7 +99,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from tomo_tv_amd import _lib
-    from tomo_tv_amd._lib import K_BP_ANGLE, VOL_ORIGINAL
+    from tomo_tv_amd._lib import K_BP_ANGLE, K_SART_FUSED, VOL_ORIGINAL
     from tomo_tv_amd.engine import multigpuengine, tomoengine
     from tomo_tv_amd.phantom import ellipsoids, tilt_angles
     import ctypes
@@ -121,6 +122,9 @@ def main():
     del vol
     t.create_projections()
     t.initialize_SART("sequential")
+    for o in args.opt:
+        k, v = o.split("=")
+        t.set_option(k, int(v))
     t.restart_recon()
     st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
 
@@ -132,15 +136,20 @@ def main():
     for _ in range(args.warmup):
         asd_pocs_step(t, st)
     sync()
-    _lib.check(t.be.L.tomo_profile_enable(t.be.h, K_BP_ANGLE, 1))
+    kernels = {"k_sart_fused": K_SART_FUSED, "k_bp_angle": K_BP_ANGLE, "k_fp_angle": 1}
+    for kid in kernels.values():
+        _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         dd, tv = asd_pocs_step(t, st)
     sync()
     el = time.perf_counter() - t0
-    launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0)
-    _lib.check(t.be.L.tomo_profile_read(t.be.h, K_BP_ANGLE, ctypes.byref(launches), ctypes.byref(total_ms)))
-    _lib.check(t.be.L.tomo_profile_enable(t.be.h, K_BP_ANGLE, 0))
+    prof = {}
+    for name, kid in kernels.items():
+        launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0)
+        _lib.check(t.be.L.tomo_profile_read(t.be.h, kid, ctypes.byref(launches), ctypes.byref(total_ms)))
+        _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 0))
+        prof[name] = (int(launches.value), float(total_ms.value))
     if comm is not None:
         import torch
         tt = torch.tensor([el], dtype=torch.float64, device="cuda")
@@ -149,11 +158,21 @@ def main():
 
     if rank == 0:
         vox_total = nloc * world * n * n
-        # one SART single-angle BP update streams the slab once in, once out, and reads
-        # that angle's residual rows:  8 V + 4 Nx N bytes per launch (V = voxels of the slab)
-        bp_bytes = 8.0 * nloc * n * n + 4.0 * nloc * n
-        avg_ms = total_ms.value / max(launches.value, 1)
-        achieved = bp_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # Algorithmic bytes per launch (SURVEY.md section 8d, V = voxels of this GPU's slab, fp32):
+        #   k_bp_angle   single-angle voxel update: slab in + slab out + that angle's residual rows = 8V + 4 Nx N
+        #   k_sart_fused BP(a_k)+FP(a_k+1): slab in + slab out + residual rows in + b rows in + residual rows out
+        #                = 8V + 12 Nx N
+        V = float(nloc) * n * n
+        alg_bytes = {"k_bp_angle": 8.0 * V + 4.0 * nloc * n, "k_sart_fused": 8.0 * V + 12.0 * nloc * n,
+                     "k_fp_angle": 4.0 * V + 8.0 * nloc * n}
+        roofs = {}
+        for name, (cnt, tot) in prof.items():
+            avg_ms = tot / cnt if cnt else 0.0
+            ach = alg_bytes[name] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofs[name] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": cnt, "avg_ms": avg_ms,
+                           "total_ms": tot, "algorithmic_bytes_per_launch": alg_bytes[name]}
+        dominant = max(roofs.values(), key=lambda r: r["total_ms"])
         out = {
             "metric": "SART+TV Gvoxel-updates/s (ASD-POCS outer iterations x voxels, 512^3 x 90 tilts per GPU)",
             "value": vox_total * args.steps / el / 1e9,
@@ -172,10 +191,9 @@ def main():
                                    f"{nproj} tilts -70..70 deg (BASELINE configs[2] shape; headline SART+TV 512^3x90)",
                        "slices_per_gpu": nloc, "nray": n, "nproj": nproj, "sharding": f"tilt-axis slabs x{world}"},
             "final_dd": dd, "final_tv": tv,
-            "roofline": {"kernel": "k_bp_angle (voxel-driven single-angle SART back-projection update)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launches": int(launches.value), "avg_ms": avg_ms, "algorithmic_bytes_per_launch": bp_bytes},
+            "roofline": dominant,
+            "roofline_bp_angle": roofs["k_bp_angle"],
+            "roofline_fp_angle": roofs["k_fp_angle"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, nproj)

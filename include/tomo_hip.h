@@ -135,11 +135,15 @@ int tomo_tv(tomo_engine *e, int vol, float eps);                        /* tomoe
 int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps);         /* :445 tv_gd_3D; TV before descent -> TOMO_S_TV */
 int tomo_tv_fgp(tomo_engine *e, int iters, float lambda);               /* :448-450 tv_fgp_3D; TV of input -> TOMO_S_TV */
 
+/* Engine options.  "sart_fused" (default 1): run a SART sweep as FP(a0), [BP(a_k)+FP(a_k+1)] fused steps, BP(a_last)
+ * instead of separate FP/BP launches per angle (same arithmetic per voxel; 8 instead of 12 bytes per voxel-angle). */
+int tomo_set_option(tomo_engine *e, const char *name, int value);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------
  * While enabled, every launch of the named kernel is bracketed by HIP events on the engine's stream;
  * tomo_profile_read synchronises, returns launch count and summed device time, and resets the log. */
 enum tomo_kernel_id { TOMO_K_BP_ANGLE = 0, TOMO_K_FP_ANGLE = 1, TOMO_K_TV_GRAD = 2, TOMO_K_TV_UPDATE = 3,
-                      TOMO_K_FGP_OBJ = 4, TOMO_K_FGP_GRAD = 5 };
+                      TOMO_K_FGP_OBJ = 4, TOMO_K_FGP_GRAD = 5, TOMO_K_SART_FUSED = 6 };
 int tomo_profile_enable(tomo_engine *e, int kernel, int on);
 int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms);
 

@@ -1,0 +1,49 @@
+"""Run by test_gpu_distributed.py in a child process: world_size-1 RCCL group exercising the torch plumbing of the
+slab engine (torch-owned scalar/halo buffers bound into the C ABI, engine on torch's stream, all-reduce on the
+device scalar between the TV gradient and update kernels)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+os.environ.setdefault("RANK", "0")
+os.environ.setdefault("WORLD_SIZE", "1")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from tomo_tv_amd.engine import multigpuengine, tomoengine  # noqa: E402
+from tomo_tv_amd.phantom import ellipsoids  # noqa: E402
+from tomo_tv_amd._lib import VOL_ORIGINAL  # noqa: E402
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+N, P, Nx = 32, 7, 70
+ang = np.deg2rad(np.linspace(-60, 60, P))
+x = ellipsoids(Nx, N, seed=5)
+res = []
+for cls in (tomoengine, multigpuengine):
+    t = cls(Nx, N, ang)
+    t.set_volume(x, VOL_ORIGINAL)
+    t.create_projections()
+    t.copy_recon()
+    t.SART(0.5, 1)
+    out = [t.matrix_2norm(), t.data_distance(), t.tv()]
+    t.copy_recon()
+    out.append(t.tv_gd(5, 0.2))
+    out.append(t.matrix_2norm())
+    v1 = t.get_volume()
+    out.append(t.tv_fgp(4, 0.05))
+    v2 = t.get_volume()
+    out.append(t.rmse())
+    res.append((np.array(out), v1, v2, t.get_recon(Nx - 1)))
+(a, a1, a2, a3), (b, b1, b2, b3) = res
+assert np.allclose(a, b, rtol=1e-6), (a, b)
+assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(a3, b3)
+assert t.is_multi_gpu_enabled() is False and t.get_gpu_ids() == [0]
+dist.destroy_process_group()
+print("NCCL_WORLD1_OK")

@@ -1,0 +1,193 @@
+"""CPU stand-in for the per-slab C-ABI backend, used ONLY by the gloo tests.
+
+The product's distributed composition (tomo_tv_amd/engine.py: which partial sums are all-reduced, when halo planes
+are exchanged, how slabs are partitioned) is backend-agnostic.  This double implements the per-slab primitives with
+numpy + the oracle so that composition can be exercised with world_size 2 on a CPU-only box.  It is test
+infrastructure: nothing in tomo_tv_amd imports it.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+import oracle
+from tomo_tv_amd._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COUNT, S_DD, S_GNORM, S_TV, SINO_B, SINO_G, VOL_ORIGINAL,
+                              VOL_RECON, VOL_TEMP)
+
+
+def _arr(ptr, shape):
+    n = int(np.prod(shape))
+    addr = ptr.value if isinstance(ptr, ctypes.c_void_p) else ptr
+    buf = (ctypes.c_float * n).from_address(addr)
+    return np.frombuffer(buf, dtype=np.float32).reshape(shape)
+
+
+class OracleSlabBackend:
+    def __init__(self, nslice, nray, nproj, angles_rad=None, A=None, device=0):
+        self.nslice, self.nray, self.nproj, self.device = nslice, nray, nproj, device
+        if A is None:
+            A = oracle.parallel_ray(nray, np.asarray(angles_rad) * 180 / np.pi)
+        self.t = oracle.ctvlib(nslice, nray, nproj)
+        self.t.load_A(A)
+        self.vol = {VOL_RECON: self.t.recon}
+        self.scal = torch.zeros(S_COUNT, dtype=torch.float64)
+        npix = nray * nray
+        self.halo_lo, self.halo_hi = torch.zeros(npix), torch.zeros(npix)
+        self.first_edge, self.last_edge = 1, 1
+        self.fields = {}
+        self.L = None
+        self.h = None
+
+    def _v(self, vid):
+        if vid not in self.vol:
+            self.vol[vid] = np.zeros_like(self.t.recon)
+        return self.vol[vid]
+
+    def _field(self, f):
+        if f in (FIELD_FGP_D, FIELD_FGP_P1):
+            return self.fields[f]
+        return self._v(f)
+
+    def close(self):
+        pass
+
+    def c(self, name, *args):
+        return getattr(self, "c_" + name)(*args)
+
+    # ---- torch plumbing ------------------------------------------------------------------------------
+    def enable_torch(self):
+        pass
+
+    def scalar_tensor(self, slot):
+        return self.scal[slot:slot + 1]
+
+    def scalars(self):
+        return self.scal.numpy().copy()
+
+    def pack_planes(self, field):
+        x = self._field(field)
+        return torch.from_numpy(x[0].ravel().copy()), torch.from_numpy(x[-1].ravel().copy())
+
+    def halo_tensors(self):
+        return self.halo_lo, self.halo_hi
+
+    def new_plane(self):
+        return torch.zeros(self.nray * self.nray)
+
+    def slice_to_tensor(self, vol, s):
+        return torch.from_numpy(self._v(vol)[s].copy())
+
+    # ---- primitives ------------------------------------------------------------------------------------
+    def c_set_slab_edges(self, first, last):
+        self.first_edge, self.last_edge = first, last
+
+    def c_set_tilt_series(self, ptr):
+        self.t.set_tilt_series(_arr(ptr, (self.nslice, self.nray * self.nproj)))
+
+    def c_set_volume(self, vid, ptr):
+        self._v(vid)[:] = _arr(ptr, self.t.recon.shape)
+
+    def c_get_volume(self, vid, ptr):
+        _arr(ptr, self.t.recon.shape)[:] = self._v(vid)
+
+    def c_copy_volume(self, dst, src):
+        self._v(dst)[:] = self._v(src)
+
+    def c_restart_recon(self):
+        self.t.recon[:] = 0
+
+    def c_positivity(self, vid):
+        np.maximum(self._v(vid), 0, out=self._v(vid))
+
+    def c_sart(self, vid, beta, niter, order):
+        assert vid == VOL_RECON and order is None
+        self.t.SART(beta, niter)
+
+    def c_data_distance_sq(self, vid):
+        self.t.forward_projection()
+        d = (self.t.g.astype(np.float64) - self.t.b) if False else (self.t.g - self.t.b)
+        self.scal[S_DD] = float((d.astype(np.float64) ** 2).sum())
+
+    def c_diff_norm_sq(self, a, b, slot):
+        d = self._v(a) - self._v(b)
+        self.scal[slot] = float((d.astype(np.float64) ** 2).sum())
+
+    # ---- stencils on [halo_lo | slab | halo_hi] ---------------------------------------------------------
+    def _ext(self, x):
+        n = self.nray
+        lo = self.halo_lo.numpy().reshape(1, n, n)
+        hi = self.halo_hi.numpy().reshape(1, n, n)
+        return np.concatenate([lo, x, hi], axis=0).astype(np.float32)
+
+    def c_tv_partial(self, vid, eps):
+        e = self._ext(self._v(vid))
+        c, ip = e[1:-1], e[2:]
+        eps = np.float32(eps)
+        t = np.sqrt(eps + (c - ip) ** 2 + (c - np.roll(c, -1, 1)) ** 2 + (c - np.roll(c, -1, 2)) ** 2)
+        self.scal[S_TV] = float(t.astype(np.float64).sum())
+
+    def c_tv_grad(self, eps):
+        e = self._ext(self.t.recon)
+        eps = np.float32(eps)
+        c, ip, im = e[1:-1], e[2:], e[:-2]
+        jp = lambda v: np.roll(v, -1, 1)  # noqa: E731
+        jm = lambda v: np.roll(v, 1, 1)   # noqa: E731
+        kp = lambda v: np.roll(v, -1, 2)  # noqa: E731
+        km = lambda v: np.roll(v, 1, 2)   # noqa: E731
+        three = np.float32(3.0)
+        v1n = three * c - ip - jp(c) - kp(c)
+        v1d = np.sqrt(eps + (c - ip) ** 2 + (c - jp(c)) ** 2 + (c - kp(c)) ** 2)
+        v2n = c - im
+        v2d = np.sqrt(eps + (im - c) ** 2 + (im - jp(im)) ** 2 + (im - kp(im)) ** 2)
+        b = jm(c)
+        v3n = c - b
+        v3d = np.sqrt(eps + (b - jm(ip)) ** 2 + (b - c) ** 2 + (b - kp(b)) ** 2)
+        d = km(c)
+        v4n = c - d
+        v4d = np.sqrt(eps + (d - km(ip)) ** 2 + (d - jp(d)) ** 2 + (d - c) ** 2)
+        self.g = (v1n / v1d + v2n / v2d + v3n / v3d + v4n / v4d).astype(np.float32)
+        self.scal[S_GNORM] = float((self.g.astype(np.float64) ** 2).sum())
+
+    def c_tv_update(self, dPOCS, clamp):
+        nrm = np.float32(np.sqrt(float(self.scal[S_GNORM])))
+        self.t.recon -= (np.float32(dPOCS) * self.g) / nrm
+        if clamp:
+            np.maximum(self.t.recon, 0, out=self.t.recon)
+
+    def c_fgp_begin(self):
+        z = lambda: np.zeros_like(self.t.recon)  # noqa: E731
+        self.fields = {FIELD_FGP_D: z(), FIELD_FGP_P1: z(), "P2": z(), "P3": z()}
+
+    def c_fgp_obj(self, lam):
+        n = self.nray
+        P1, P2, P3 = self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"]
+        lo = np.zeros((1, n, n), np.float32) if self.first_edge else self.halo_lo.numpy().reshape(1, n, n)
+        v1 = np.concatenate([lo, P1[:-1]], axis=0)
+        v2 = np.zeros_like(P2)
+        v2[:, 1:, :] = P2[:, :-1, :]
+        v3 = np.zeros_like(P3)
+        v3[:, :, 1:] = P3[:, :, :-1]
+        d = self.t.recon - np.float32(lam) * (P1 + P2 + P3 - v1 - v2 - v3)
+        self.fields[FIELD_FGP_D] = np.maximum(d, 0).astype(np.float32)
+
+    def c_fgp_grad(self, lam):
+        n = self.nray
+        D = self.fields[FIELD_FGP_D]
+        P1, P2, P3 = self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"]
+        multip = np.float32(1.0) / (np.float32(26.0) * np.float32(lam))
+        if self.last_edge:
+            nxt = np.concatenate([D[1:], D[-1:]], axis=0)      # D - D = 0 on the last global slice
+        else:
+            nxt = np.concatenate([D[1:], self.halo_hi.numpy().reshape(1, n, n)], axis=0)
+        v1 = D - nxt
+        v2 = np.zeros_like(D)
+        v2[:, :-1, :] = D[:, :-1, :] - D[:, 1:, :]
+        v3 = np.zeros_like(D)
+        v3[:, :, :-1] = D[:, :, :-1] - D[:, :, 1:]
+        a, b, c = P1 + multip * v1, P2 + multip * v2, P3 + multip * v3
+        den = a * a + b * b + c * c
+        sq = np.where(den > 1, np.float32(1.0) / np.sqrt(np.maximum(den, np.float32(1e-30))), np.float32(1.0)).astype(np.float32)
+        self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"] = a * sq, b * sq, c * sq
+
+    def c_fgp_end(self, iters):
+        self.t.recon[:] = self.fields[FIELD_FGP_D]

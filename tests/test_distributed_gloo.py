@@ -1,0 +1,138 @@
+"""world_size-2 (and 3) gloo runs of the slab-sharded composition in tomo_tv_amd/engine.py on CPU.
+
+The per-slab kernels are replaced by tests/slab_double.py (numpy + oracle); what is under test is the product's
+host logic: slab partition, which scalars are all-reduced, the ring halo exchange before every TV stencil pass, slice
+ownership / broadcast in get_recon.  The sharded result must equal the single-process oracle.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, N, P, Nx, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from slab_double import OracleSlabBackend
+        from tomo_tv_amd import engine
+        from tomo_tv_amd.distributed import SlabComm
+        from tomo_tv_amd.phantom import ellipsoids
+
+        class ShardedEngine(engine.tomoengine):
+            _backend_cls = OracleSlabBackend
+
+        ang = np.linspace(-65, 65, P)
+        x = ellipsoids(Nx, N, seed=21)
+        full = oracle.ctvlib(Nx, N, P)
+        full.load_A(oracle.parallel_ray(N, ang))
+        full.original_volume = x.copy()
+        full.create_projections()
+
+        t = ShardedEngine(Nx, N, ang * np.pi / 180, comm=SlabComm())
+        t.tv_eps = full.tv_eps = 1e-6
+        t.set_tilt_series(full.b)               # every rank passes the GLOBAL array; each keeps its slab
+        res = {}
+        t.copy_recon()
+        t.SART(0.5, 1)
+        res["dp"] = t.matrix_2norm()
+        res["dd"] = t.data_distance()
+        res["tv"] = t.tv()
+        t.copy_recon()
+        res["tv0"] = t.tv_gd(4, 0.3)
+        res["dg"] = t.matrix_2norm()
+        vol_gd = t.get_volume()
+        res["tv_fgp0"] = t.tv_fgp(3, 0.05)
+        vol_fgp = t.get_volume()
+        mid = t.get_recon(Nx // 2)              # collective: broadcast from the owner
+        first, nloc = t.first, t.nloc
+        parts = [None] * world
+        dist.all_gather_object(parts, (first, nloc))
+
+        if rank == 0:
+            full.copy_recon()
+            full.SART(0.5, 1)
+            want = {"dp": full.matrix_2norm(), "dd": full.data_distance(normalize=False), "tv": full.tv()}
+            full.copy_recon()
+            want["tv0"] = full.tv_gd(4, 0.3)
+            want["dg"] = full.matrix_2norm()
+            ref_gd = full.recon.copy()
+            want["tv_fgp0"] = full.tv_fgp(3, 0.05)
+            ref_fgp = full.recon.copy()
+            np.savez(out_path, keys=np.array(sorted(want)), got=np.array([res[k] for k in sorted(want)]),
+                     want=np.array([want[k] for k in sorted(want)]), vol_gd=vol_gd, ref_gd=ref_gd, vol_fgp=vol_fgp,
+                     ref_fgp=ref_fgp, mid=mid, parts=np.array(parts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Nx", [(2, 6), (2, 7), (3, 8)])
+def test_sharded_equals_single_process(tmp_path, world, Nx):
+    N, P = 16, 5
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, P, Nx, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert np.allclose(r["got"], r["want"], rtol=1e-6), dict(zip(r["keys"], zip(r["got"], r["want"])))
+    assert np.allclose(r["vol_gd"], r["ref_gd"], rtol=0, atol=2e-6)
+    assert np.allclose(r["vol_fgp"], r["ref_fgp"], rtol=0, atol=2e-6)
+    assert np.array_equal(r["mid"], r["vol_fgp"][Nx // 2])
+    parts = r["parts"]
+    assert parts[0][0] == 0 and sum(p[1] for p in parts) == Nx
+    assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+
+
+def test_slab_partition_covers_and_balances():
+    from tomo_tv_amd.distributed import slab_partition
+    for n in (1, 7, 8, 64, 1000, 1024):
+        for w in (1, 2, 3, 8):
+            if w > n:
+                continue
+            spans = [slab_partition(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][0] + spans[-1][1] == n
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            counts = [c for _, c in spans]
+            assert max(counts) - min(counts) <= 1
+
+
+def test_owner_lookup_matches_partition():
+    from tomo_tv_amd.distributed import slab_partition
+    from tomo_tv_amd.engine import _EngineBase
+
+    class Fake(_EngineBase):
+        pass
+    for n, w in [(7, 2), (8, 3), (100, 8), (64, 8)]:
+        f = Fake()
+        f.Nslice_ = n
+        f.comm = type("C", (), {"world": w})()
+        for r in range(w):
+            first, cnt = slab_partition(n, w, r)
+            for s in range(first, first + cnt):
+                assert f._owner(s) == r
+
+
+def test_pack_tilt_series_layout():
+    from tomo_tv_amd.pytvlib import pack_tilt_series
+    ts = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)      # (Nslice, Nray, Nangles)
+    b = pack_tilt_series(ts)
+    assert b.shape == (2, 12)
+    for s in range(2):
+        assert np.array_equal(b[s], ts[s].T.ravel())                   # gpu/reconstructor.py:54-56

@@ -90,6 +90,36 @@ def test_sart_and_normalised_sirt(gpu, golden, N, P, Nx):
     assert rel_l2(dev.get_model_projections(), ref.g) < TOL
 
 
+@pytest.mark.parametrize("Nx,P,niter,order", [(8, 16, 1, "sequential"), (8, 16, 3, "sequential"), (130, 5, 2, "random"),
+                                               (256, 1, 2, "sequential")])
+def test_fused_sart_equals_separate_fp_bp(gpu, Nx, P, niter, order):
+    """The fused [BP(a_k)+FP(a_k+1)] chain performs the same per-voxel arithmetic as one FP + one BP per angle."""
+    N = 64 if Nx <= 8 else 24
+    ang = np.deg2rad(np.linspace(-70, 70, P)) if P > 1 else np.deg2rad([17.0])
+    x = ellipsoids(Nx, N, seed=3)
+    vols = []
+    for fused in (2, 1, 0):
+        dev = tomoengine(Nx, N, ang)
+        dev.set_option("sart_fused", fused)
+        dev.set_volume(x, VOL_ORIGINAL)
+        dev.create_projections()
+        dev.initialize_SART(order)
+        dev.SART(0.7, niter)
+        dev.SART(0.3, 1)                      # a second call starts from the swapped buffer
+        vols.append(dev.get_volume())
+        dd = dev.data_distance()
+    assert rel_l2(vols[0], vols[2]) < 2e-6 and rel_l2(vols[1], vols[2]) < 2e-6
+    ref = oracle.ctvlib(Nx, N, P)
+    ref.load_A(oracle.parallel_ray(N, np.rad2deg(ang)))
+    ref.original_volume = x.copy()
+    ref.create_projections()
+    if order == "sequential":
+        ref.SART(0.7, niter)
+        ref.SART(0.3, 1)
+        assert rel_l2(vols[0], ref.recon) < TOL
+        assert abs(dd - ref.data_distance(normalize=False)) <= 2e-5 * dd
+
+
 def test_sart_random_order_is_a_permutation_sweep(gpu, golden):
     N, P, Nx = 32, 9, 4
     A = golden(f"A_N{N}_P{P}.npz")
@@ -338,6 +368,38 @@ def test_ragged_slice_counts_match_oracle(gpu, Nx):
     assert rel_l2(dev.get_volume(), ref.recon) < TOL
     for s in {0, Nx - 1}:
         assert np.array_equal(dev.get_recon(s), dev.get_volume()[s])
+
+
+@pytest.mark.parametrize("N,P,Nx", [(9, 4, 5), (15, 3, 70), (33, 5, 130), (24, 5, 130)])
+def test_odd_sizes_whose_grids_round_up(gpu, N, P, Nx):
+    """Sizes where (pixels/4 x chunks) or (rays/4 x chunks) is not a multiple of the 4 waves of a workgroup."""
+    ang = np.linspace(-63.5, 58.0, P)
+    A = oracle.parallel_ray(N, ang)
+    x = ellipsoids(Nx, N, seed=13)
+    ref = oracle.ctvlib(Nx, N, P)
+    ref.load_A(A)
+    ref.original_volume = x.copy()
+    ref.create_projections()
+    for rep in range(3):                                   # stale device memory must not matter
+        dev = ctvlib(Nx, N, P)
+        dev.load_A(A)
+        pytvlib.create_projections(dev, x)
+        assert rel_l2(dev.get_projections(), ref.b) < TOL
+    dev.SIRT(1.0 / dev.lipschits())
+    r2 = oracle.ctvlib(Nx, N, P)
+    r2.load_A(A)
+    r2.set_tilt_series(ref.b)
+    r2.SIRT(1.0 / r2.lipschits())
+    assert rel_l2(dev.get_volume(), r2.recon) < TOL
+    t = tomoengine(Nx, N, ang * np.pi / 180)
+    t.set_tilt_series(ref.b)
+    t.SART(0.5, 2)
+    t.SIRT(2)
+    r2.restart_recon()
+    r2.SART(0.5, 2)
+    r2.SIRT_norm(2)
+    assert rel_l2(t.get_volume(), r2.recon) < TOL
+    assert abs(t.data_distance() - r2.data_distance(normalize=False)) <= 2e-5 * t.data_distance()
 
 
 def test_slice_set_get_roundtrip_and_errors(gpu):

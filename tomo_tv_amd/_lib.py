@@ -13,7 +13,7 @@ VOL_RECON, VOL_TEMP, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD = 0, 1, 2, 3, 4
 SINO_B, SINO_G = 0, 1
 S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 16
 FIELD_FGP_D, FIELD_FGP_P1 = 100, 101
-K_BP_ANGLE, K_FP_ANGLE, K_TV_GRAD, K_TV_UPDATE, K_FGP_OBJ, K_FGP_GRAD = 0, 1, 2, 3, 4, 5
+K_BP_ANGLE, K_FP_ANGLE, K_TV_GRAD, K_TV_UPDATE, K_FGP_OBJ, K_FGP_GRAD, K_SART_FUSED = 0, 1, 2, 3, 4, 5, 6
 
 _i, _i64, _f, _p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 _pp = ctypes.POINTER(ctypes.c_void_p)
@@ -68,6 +68,7 @@ SIGNATURES = {
     "tomo_tv": [_p, _i, _f],
     "tomo_tv_gd": [_p, _i, _f, _f],
     "tomo_tv_fgp": [_p, _i, _f],
+    "tomo_set_option": [_p, ctypes.c_char_p, _i],
     "tomo_profile_enable": [_p, _i, _i],
     "tomo_profile_read": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
 }

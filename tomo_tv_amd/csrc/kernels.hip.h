@@ -122,6 +122,28 @@ __global__ void k_gather_slice(const float *__restrict__ vol, float *__restrict_
     if (i < m) img[i] = vol[i * sx + s];
 }
 
+// ---- workgroup -> (ray, slice chunk) map for the ray-driven kernels ---------------------------------------
+// Neighbouring rays share pixels, so they should meet in one XCD's L2: workgroups b and b+8 share an XCD
+// (round-robin dispatch; speed only, never correctness).  Ray lengths fall off towards the detector edges, so
+// an XCD must not own one contiguous block of rays (the edge XCDs would idle): rays are dealt to XCDs in
+// groups of RAY_GROUP neighbours instead.
+constexpr int RAY_GROUP = 16;
+
+__device__ __forceinline__ void ray_block_map(int bid, int nb, int nrows, int &chunk, int &rowidx)
+{
+    if ((nrows % (8 * RAY_GROUP)) == 0 && (nb & 7) == 0) {
+        int xcd = bid & 7, l = bid >> 3;
+        int per = nrows >> 3;               // rays per XCD per chunk
+        chunk = l / per;
+        int li = l - chunk * per;
+        int g = li / RAY_GROUP, w = li - g * RAY_GROUP;
+        rowidx = (g * 8 + xcd) * RAY_GROUP + w;
+    } else {
+        chunk = bid / nrows;
+        rowidx = bid - chunk * nrows;
+    }
+}
+
 // ---- forward projector: ray-driven, one workgroup per (ray, slice chunk) ---------------------------
 // g[row][s] = sum_k w_k * x[col_k][s].  The four waves of a workgroup split the ray's entry list; lanes hold
 // VEC consecutive slices each.  Entry (col, w) pairs are wave-uniform: fetched by the scalar unit.
@@ -134,11 +156,9 @@ __global__ __launch_bounds__(256) void k_fp_rows(const float *__restrict__ x, co
                                                   double *__restrict__ part, int row0, int nrows, int sx)
 {
     typedef typename VecOf<VEC>::T V;
-    // XCD-aware order: consecutive rays (which share pixels) land on the same XCD's L2
-    int nb = gridDim.x, bid = blockIdx.x;
-    int v = (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid;
-    int chunk = v / nrows;
-    int row = row0 + (v - chunk * nrows);
+    int chunk, rowidx;
+    ray_block_map(blockIdx.x, gridDim.x, nrows, chunk, rowidx);
+    int row = row0 + rowidx;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     uint32_t beg = rptr[row], end = rptr[row + 1];
@@ -198,6 +218,147 @@ __global__ __launch_bounds__(256) void k_fp_rows(const float *__restrict__ x, co
     }
 }
 
+// ---- forward projector, narrow-chunk form: LPR lanes x float4 per ray, 64/LPR neighbouring rays per wave ------
+// A slice chunk is LPR*4 slices (64 for LPR = 16), so one chunk of a 512^2 volume is 67 MB: launched chunk-major
+// over ALL angles, the chunk stays resident in the 256 MB Infinity Cache after the first angle has touched it
+// (the wide form's 256-slice chunk is 268 MB and streams from HBM 90 times).  It is also the efficient form for
+// narrow slabs (64/128 slices per GPU when a volume is sharded 8 ways).  Each lane group walks its own ray;
+// entry (pixel, weight) pairs are fetched with lane-group-uniform vector loads.
+template <int LPR, int MODE>
+__global__ __launch_bounds__(256) void k_fp_rows_g(const float *__restrict__ x, const uint32_t *__restrict__ rptr,
+                                                    const uint2 *__restrict__ rent, const float *__restrict__ b,
+                                                    const float *__restrict__ rowsum, float *__restrict__ out,
+                                                    double *__restrict__ part, int row0, int nrows, int sx,
+                                                    int nchunk)
+{
+    typedef VecOf<4>::T V;
+    constexpr int R = 64 / LPR;                       // rays per wave
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPR, gl = lane - grp * LPR;
+    const int ngw = (nrows + R - 1) / R;              // ray groups per chunk
+    int64_t gw = (int64_t)blockIdx.x * 4 + wave;      // chunk-major
+    int chunk = (int)(gw / ngw);
+    if (chunk >= nchunk) return;                      // grid is rounded up to whole workgroups
+    int rowidx = (int)(gw - (int64_t)chunk * ngw) * R + grp;
+    bool valid = rowidx < nrows;
+    int row = row0 + (valid ? rowidx : 0);
+    uint32_t kb = rptr[row], ke = valid ? rptr[row + 1] : kb;
+    int off = chunk * (LPR * 4) + gl * 4;
+    const float *xp = x + off;
+    V acc = vzero<4>();
+    for (uint32_t k = kb; __any(k < ke); k += U) {
+        uint2 e[U];
+        V xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t kk = min(k + u, ke > kb ? ke - 1 : kb);
+            e[u] = (k + u < ke) ? rent[kk] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const V *>(xp + (size_t)e[u].x * sx);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += __uint_as_float(e[u].y) * xv[u];
+    }
+    double local = 0.0;
+    if (valid) {
+        size_t o = (size_t)row * sx + off;
+        if (MODE == FP_STORE) {
+            *reinterpret_cast<V *>(out + o) = acc;
+        } else {
+            V bv = *reinterpret_cast<const V *>(b + o);
+            V r;
+            if (MODE == FP_RESID) {
+                r = bv - acc;
+            } else if (MODE == FP_RESID_NORM) {
+                float rs = rowsum[row];
+                r = rs > 0.f ? (bv - acc) / rs : vzero<4>();
+            } else if (MODE == FP_DD) {
+                r = acc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { float d = acc[i] - bv[i]; local += (double)(d * d); }
+            } else {
+                const float eps = 1e-1f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a = acc[i], bb = bv[i];
+                    r[i] = (a - bb) / (a + eps);
+                    local += (double)(a - bb * logf(a + eps));
+                }
+            }
+            *reinterpret_cast<V *>(out + o) = r;
+        }
+    }
+    if (MODE == FP_DD || MODE == FP_POISSON) {
+        local = wave_sum(local);
+        if (lane == 0) atomicAdd(&part[blockIdx.x & (NPART - 1)], local);
+    }
+}
+
+// Experimental variant: one wave per ray (no split, no LDS), 4 rays per workgroup.  RESID_NORM epilogue only.
+template <int VEC, int UNR>
+__global__ __launch_bounds__(256) void k_fp_rows_w1(const float *__restrict__ x, const uint32_t *__restrict__ rptr,
+                                                     const uint2 *__restrict__ rent, const float *__restrict__ b,
+                                                     const float *__restrict__ rowsum, float *__restrict__ out,
+                                                     int row0, int nrows, int sx)
+{
+    typedef typename VecOf<VEC>::T V;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int chunk, rowidx;
+    ray_block_map(blockIdx.x * 4 + wave, gridDim.x * 4, nrows, chunk, rowidx);
+    int row = row0 + rowidx;
+    uint32_t kb = rptr[row], ke = rptr[row + 1];
+    int off = chunk * (64 * VEC) + lane * VEC;
+    const float *xp = x + off;
+    V acc = vzero<VEC>();
+#pragma unroll UNR
+    for (uint32_t k = kb; k < ke; ++k) {
+        uint2 e = rent[k];
+        float w = __uint_as_float(e.y);
+        V xv = *reinterpret_cast<const V *>(xp + (size_t)e.x * sx);
+        acc += w * xv;
+    }
+    size_t o = (size_t)row * sx + off;
+    V bv = *reinterpret_cast<const V *>(b + o);
+    float rs = rowsum[row];
+    V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
+    *reinterpret_cast<V *>(out + o) = r;
+}
+
+// Experimental variant: one wave per ray covering TWO float4 chunks (2 KB contiguous per pixel), 4 rays per workgroup.
+template <int UNR>
+__global__ __launch_bounds__(256) void k_fp_rows_w1x2(const float *__restrict__ x, const uint32_t *__restrict__ rptr,
+                                                       const uint2 *__restrict__ rent, const float *__restrict__ b,
+                                                       const float *__restrict__ rowsum, float *__restrict__ out,
+                                                       int row0, int nrows, int sx)
+{
+    typedef VecOf<4>::T V;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int chunk, rowidx;
+    ray_block_map(blockIdx.x * 4 + wave, gridDim.x * 4, nrows, chunk, rowidx);
+    int row = row0 + rowidx;
+    uint32_t kb = rptr[row], ke = rptr[row + 1];
+    int off = chunk * 512 + lane * 4;
+    const float *xp = x + off;
+    V acc0 = vzero<4>(), acc1 = vzero<4>();
+#pragma unroll UNR
+    for (uint32_t k = kb; k < ke; ++k) {
+        uint2 e = rent[k];
+        float w = __uint_as_float(e.y);
+        V x0 = *reinterpret_cast<const V *>(xp + (size_t)e.x * sx);
+        V x1 = *reinterpret_cast<const V *>(xp + (size_t)e.x * sx + 256);
+        acc0 += w * x0;
+        acc1 += w * x1;
+    }
+    size_t o = (size_t)row * sx + off;
+    float rs = rowsum[row];
+    V b0 = *reinterpret_cast<const V *>(b + o), b1 = *reinterpret_cast<const V *>(b + o + 256);
+    *reinterpret_cast<V *>(out + o) = rs > 0.f ? (b0 - acc0) / rs : vzero<4>();
+    *reinterpret_cast<V *>(out + o + 256) = rs > 0.f ? (b1 - acc1) / rs : vzero<4>();
+}
+
 // ---- voxel-driven back-projector, one angle (the SART update) ---------------------------------------
 // x[p][s] = max(0, x[p][s] + beta * (w0 r[j0][s] + w1 r[j1][s]) / (w0 + w1))
 // cell[p] = {j0, w0, j1, w1}: the (at most two) rays of this angle through pixel p.  r = this angle's
@@ -207,7 +368,7 @@ struct CellD { uint32_t r0; float w0; uint32_t r1; float w1; };
 template <int VEC, int PPW>
 __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const CellD *__restrict__ cell,
                                                    const float *__restrict__ r, float beta, int npix, int sx,
-                                                   int ngroups)
+                                                   int ngroups, int nchunk)
 {
     typedef typename VecOf<VEC>::T V;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -216,7 +377,7 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
     int chunk = gw / ngroups;
     int grp = gw - chunk * ngroups;
     int p0 = grp * PPW;
-    if (p0 >= npix) return;
+    if (p0 >= npix || chunk >= nchunk) return;   // grid is rounded up to whole workgroups
     int off = chunk * (64 * VEC) + lane * VEC;
     V xv[PPW], r0[PPW], r1[PPW];
     CellD c[PPW];
@@ -235,13 +396,193 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
             float cs = c[q].w0 + c[q].w1;
             V num = c[q].w0 * r0[q];
             num += c[q].w1 * r1[q];
-            V upd = cs > 0.f ? num / cs : vzero<VEC>();
+            V upd = num / (cs > 0.f ? cs : 1.0f);         // cs == 0 means w0 == w1 == 0, so num == 0
             V nv = xv[q] + beta * upd;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
             *reinterpret_cast<V *>(x + (size_t)p * sx + off) = nv;
         }
     }
+}
+
+// ---- fused SART step: back-projection of angle "prev" + forward projection of angle "next" ------------
+// Ray-driven over the rays of "next": every pixel on the ray first receives the pending voxel update of
+// "prev" (same arithmetic as k_bp_angle), the updated value feeds this ray's line integral, and the visit that
+// owns the pixel stores it.  The walk lists make the rays of one angle visit every pixel with exactly one
+// owner, so x_new is fully written; reads come from x_old only (ping-pong), so the 1-2 rays that share a pixel
+// never see a half-updated volume.  Per angle the slab is read once and written once: 8 B/voxel instead of the
+// 12 B/voxel of a separate FP + BP pair.  Epilogue = normalised residual of "next" (as FP_RESID_NORM).
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void k_sart_fused(const float *__restrict__ x_old, float *__restrict__ x_new,
+                                                     const uint32_t *__restrict__ wptr, const uint2 *__restrict__ went,
+                                                     const CellD *__restrict__ cell_prev,
+                                                     const float *__restrict__ r_prev, float beta,
+                                                     const float *__restrict__ b, const float *__restrict__ rowsum,
+                                                     float *__restrict__ r_out, int row0, int nrows, int sx)
+{
+    typedef typename VecOf<VEC>::T V;
+    int chunk, rowidx;
+    ray_block_map(blockIdx.x, gridDim.x, nrows, chunk, rowidx);
+    int row = row0 + rowidx;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    uint32_t beg = wptr[row], end = wptr[row + 1];
+    uint32_t seg = (end - beg + 3u) >> 2;
+    uint32_t kb = min(beg + wave * seg, end), ke = min(kb + seg, end);
+    int off = chunk * (64 * VEC) + lane * VEC;
+    const float *xp = x_old + off;
+    const float *rp = r_prev + off;
+    float *xo = x_new + off;
+    V acc = vzero<VEC>();
+    // U visits per trip, in four phases so that all table fetches and then all 3U row loads are in flight
+    // together (a visit-at-a-time loop serialises four dependent memory round trips per pixel).
+    for (uint32_t k = kb; k < ke; k += U) {
+        uint2 e[U];
+        CellD c[U];
+        V xv[U], a0[U], a1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = went[min(k + u, ke - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = cell_prev[e[u].x & 0x7fffffffu];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            size_t po = (size_t)(e[u].x & 0x7fffffffu) * sx;
+            xv[u] = *reinterpret_cast<const V *>(xp + po);
+            a0[u] = *reinterpret_cast<const V *>(rp + (size_t)c[u].r0 * sx);
+            a1[u] = *reinterpret_cast<const V *>(rp + (size_t)c[u].r1 * sx);
+        }
+        // pin the loads here: without this the optimiser sinks each visit's loads behind the previous visit's
+        // conditional store and the trip degenerates into U serial round trips
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(xv[u]), "+v"(a0[u]), "+v"(a1[u]));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool live = k + u < ke;                       // the tail repeats the last visit with no effect
+            float cs = c[u].w0 + c[u].w1;
+            V num = c[u].w0 * a0[u];
+            num += c[u].w1 * a1[u];
+            V upd = num / (cs > 0.f ? cs : 1.0f);         // cs == 0 means w0 == w1 == 0, so num == 0
+            V nv = xv[u] + beta * upd;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
+            float w = live ? __uint_as_float(e[u].y) : 0.f;
+            acc += w * nv;
+            if (live && (e[u].x & 0x80000000u)) *reinterpret_cast<V *>(xo + (size_t)(e[u].x & 0x7fffffffu) * sx) = nv;
+        }
+    }
+    __shared__ V red[3][64];
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
+        size_t o = (size_t)row * sx + off;
+        V bv = *reinterpret_cast<const V *>(b + o);
+        float rs = rowsum[row];
+        V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
+        *reinterpret_cast<V *>(r_out + o) = r;
+    }
+}
+
+// ---- segmented form of the fused step: equal-sized work items --------------------------------------------
+// A launch of one workgroup per (ray, chunk) finishes when its longest ray does, and with ~4 workgroups per CU
+// there is no second round to even things out (measured: 242 us against 187 us at the streaming rate).  Here a
+// ray's walk list is cut into segments of <= seg_len visits (host: build_segments) and ONE WAVE runs one
+// segment: many short equal items, dealt to the XCDs in groups of neighbouring rays.  Each item leaves its
+// partial line integral in partial[id][s]; k_resid_finish adds a ray's segments in order and forms the residual.
+// FUSED = false is the plain per-angle forward projection (no pending voxel update, no volume write).
+struct SegItemD { uint32_t id, kbeg, kend, pad; };
+
+template <int VEC, int U, bool FUSED>
+__global__ __launch_bounds__(64) void k_sart_seg(const float *__restrict__ x_old, float *__restrict__ x_new,
+                                                  const SegItemD *__restrict__ exec, int L,
+                                                  const uint2 *__restrict__ went, const CellD *__restrict__ cell_prev,
+                                                  const float *__restrict__ r_prev, float beta,
+                                                  float *__restrict__ partial, int sx)
+{
+    typedef typename VecOf<VEC>::T V;
+    int bid = blockIdx.x;
+    int xcd = bid & 7, l = bid >> 3;
+    int chunk = l / L;
+    int li = l - chunk * L;
+    SegItemD it = exec[xcd * L + li];
+    uint32_t kb = it.kbeg, ke = it.kend;
+    if (kb >= ke) return;  // padding item
+    int lane = threadIdx.x;
+    int off = chunk * (64 * VEC) + lane * VEC;
+    const float *xp = x_old + off;
+    V acc = vzero<VEC>();
+    for (uint32_t k = kb; k < ke; k += U) {
+        uint2 e[U];
+        V xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = went[min(k + u, ke - 1)];
+        if (FUSED) {
+            const float *rp = r_prev + off;
+            float *xo = x_new + off;
+            CellD c[U];
+            V a0[U], a1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) c[u] = cell_prev[e[u].x & 0x7fffffffu];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = *reinterpret_cast<const V *>(xp + (size_t)(e[u].x & 0x7fffffffu) * sx);
+                a0[u] = *reinterpret_cast<const V *>(rp + (size_t)c[u].r0 * sx);
+                a1[u] = *reinterpret_cast<const V *>(rp + (size_t)c[u].r1 * sx);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) asm volatile("" : "+v"(xv[u]), "+v"(a0[u]), "+v"(a1[u]));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bool live = k + u < ke;
+                float cs = c[u].w0 + c[u].w1;
+                V num = c[u].w0 * a0[u];
+                num += c[u].w1 * a1[u];
+                V upd = num / (cs > 0.f ? cs : 1.0f);
+                V nv = xv[u] + beta * upd;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
+                float w = live ? __uint_as_float(e[u].y) : 0.f;
+                acc += w * nv;
+                if (live && (e[u].x & 0x80000000u))
+                    *reinterpret_cast<V *>(xo + (size_t)(e[u].x & 0x7fffffffu) * sx) = nv;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const V *>(xp + (size_t)(e[u].x & 0x7fffffffu) * sx);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float w = (k + u < ke) ? __uint_as_float(e[u].y) : 0.f;
+                acc += w * xv[u];
+            }
+        }
+    }
+    *reinterpret_cast<V *>(partial + (size_t)it.id * sx + off) = acc;
+}
+
+// r[row][s] = (b - sum_segments partial) / rowsum   (0 where rowsum == 0); one wave per (row, chunk)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ partial,
+                                                       const uint32_t *__restrict__ row_first,
+                                                       const uint32_t *__restrict__ row_nseg,
+                                                       const float *__restrict__ b, const float *__restrict__ rowsum,
+                                                       float *__restrict__ r_out, int row0, int nrows, int nchunk, int sx)
+{
+    typedef typename VecOf<VEC>::T V;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int gw = blockIdx.x * 4 + wave;
+    if (gw >= nrows * nchunk) return;
+    int chunk = gw / nrows;
+    int row = row0 + (gw - chunk * nrows);
+    int off = chunk * (64 * VEC) + lane * VEC;
+    uint32_t first = row_first[row], ns = row_nseg[row];
+    V acc = vzero<VEC>();
+    for (uint32_t s = 0; s < ns; ++s) acc += *reinterpret_cast<const V *>(partial + (size_t)(first + s) * sx + off);
+    size_t o = (size_t)row * sx + off;
+    V bv = *reinterpret_cast<const V *>(b + o);
+    float rs = rowsum[row];
+    V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
+    *reinterpret_cast<V *>(r_out + o) = r;
 }
 
 // ---- voxel-driven back-projector, all angles (SIRT / Landweber / plain A^T / Poisson) ----------------
@@ -251,7 +592,7 @@ template <int VEC, int PPW>
 __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const CellD *__restrict__ cell,
                                                  const float *__restrict__ r, const float *__restrict__ colsum,
                                                  float alpha, float beta, int clamp, int nproj, int nray, int npix,
-                                                 int sx, int ngroups)
+                                                 int sx, int ngroups, int nchunk)
 {
     typedef typename VecOf<VEC>::T V;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -260,7 +601,7 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
     int chunk = gw / ngroups;
     int grp = gw - chunk * ngroups;
     int p0 = grp * PPW;
-    if (p0 >= npix) return;
+    if (p0 >= npix || chunk >= nchunk) return;   // grid is rounded up to whole workgroups
     int off = chunk * (64 * VEC) + lane * VEC;
     V acc[PPW];
 #pragma unroll
@@ -474,6 +815,109 @@ __global__ __launch_bounds__(256) void k_tv_grad(const float *__restrict__ x, Ha
             g[(size_t)p * sx + s] = gv;
             acc += (double)(gv * gv);
         }
+    }
+    block_accumulate(acc, part);
+}
+
+// LDS-tiled form of k_tv_grad.  The direct form re-reads every voxel from up to 7 pixel rows that lie ~N*sx
+// floats apart, which the L2 cannot hold (measured: 5x the compulsory HBM traffic), and evaluates 4 square roots
+// and 4 divisions per voxel (VALU-bound once the traffic is fixed).  Here a workgroup owns TZ z-columns x 64
+// slices and marches along y with the pixel rows y-1 .. y+2 in a 4-slot LDS ring (one-element halo in z and s):
+//  * every volume element is fetched once per workgroup column, the next row's loads fly during compute;
+//  * the four denominators of ctvlib.cpp:431-447 are one field, D(p) = sqrt(eps + sum_d (x_p - x_{p+d})^2),
+//    taken at p, p-i, p-j, p-k (same term order as the reference), so D is evaluated ONCE per voxel, its
+//    correctly-rounded reciprocal R = 1/D is shared through LDS, and the gradient is
+//    g = (3c - x_ip - x_jp - x_kp) R(p) + (c - x_im) R(p-i) + (c - x_jm) R(p-j) + (c - x_km) R(p-k).
+//    (v * (1/D) instead of v / D: at most one ulp per term away from the reference's expression.)
+constexpr int TVL_TZ = 8;          // z-columns per workgroup (2 per wave)
+constexpr int TVL_PITCH = 66;      // 64 slices + halo each side
+
+__device__ __forceinline__ float tv_ld(const float *__restrict__ x, const Halo &h, int pix, int s, int nx, int sx)
+{
+    if (s < 0) return h.lo[pix];
+    if (s >= nx) return h.hi[pix];
+    return x[(size_t)pix * sx + s];
+}
+
+__global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x, Halo h, float *__restrict__ g,
+                                                      double *__restrict__ part, float eps, int n, int nx, int sx,
+                                                      int yseg)
+{
+    __shared__ float ring[4][TVL_TZ + 2][TVL_PITCH];      // x planes; row zi = column z0-1+zi, element si = slice s0-1+si
+    __shared__ float rinv[2][TVL_TZ + 1][TVL_PITCH];      // R planes; rows zi = 0..TZ, elements si = 0..64
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nzb = (n + TVL_TZ - 1) / TVL_TZ;
+    int bz = blockIdx.x % nzb;
+    int bs = blockIdx.x / nzb;                 // slice chunk
+    int y0 = blockIdx.y * yseg;
+    int y1 = min(y0 + yseg, n);
+    int z0 = bz * TVL_TZ, s0 = bs * 64;
+    auto zcol = [&](int zi) { int z = z0 - 1 + zi; return z < 0 ? z + n : (z >= n ? z - n : z); };
+    auto yrow = [&](int y) { return y < 0 ? y + n : (y >= n ? y - n : y); };
+    float v0, v1, v2, vh;
+    auto fetch = [&](int y) {                  // rows (wave, wave+4, wave+8) x column lane+1, + halo columns
+        int yy = yrow(y);
+        int s = s0 + lane;
+        v0 = tv_ld(x, h, yy * n + zcol(wave), s, nx, sx);
+        v1 = tv_ld(x, h, yy * n + zcol(wave + 4), s, nx, sx);
+        v2 = (wave + 8 < TVL_TZ + 2) ? tv_ld(x, h, yy * n + zcol(wave + 8), s, nx, sx) : 0.f;
+        vh = 0.f;
+        if (wave == 3 && lane < 2 * (TVL_TZ + 2)) {
+            int zi = lane >> 1, side = lane & 1;
+            vh = tv_ld(x, h, yy * n + zcol(zi), side ? s0 + 64 : s0 - 1, nx, sx);
+        }
+    };
+    auto stash = [&](int slot) {
+        ring[slot][wave][lane + 1] = v0;
+        ring[slot][wave + 4][lane + 1] = v1;
+        if (wave + 8 < TVL_TZ + 2) ring[slot][wave + 8][lane + 1] = v2;
+        if (wave == 3 && lane < 2 * (TVL_TZ + 2)) ring[slot][lane >> 1][(lane & 1) ? 65 : 0] = vh;
+    };
+    // R of the plane in slot a, whose +y neighbour plane is in slot b
+    auto compute_r = [&](int a, int b, int rslot) {
+        for (int e = threadIdx.x; e < (TVL_TZ + 1) * 65; e += 256) {
+            int zi = e / 65, si = e - zi * 65;
+            float c = ring[a][zi][si];
+            float d1 = c - ring[a][zi][si + 1];
+            float d2 = c - ring[b][zi][si];
+            float d3 = c - ring[a][zi + 1][si];
+            float D = sqrtf(eps + d1 * d1 + d2 * d2 + d3 * d3);
+            rinv[rslot][zi][si] = 1.0f / D;
+        }
+    };
+    fetch(y0 - 1); stash(0);
+    fetch(y0);     stash(1);
+    fetch(y0 + 1); stash(2);
+    __syncthreads();
+    compute_r(0, 1, 0);                        // R(y0-1)
+    double acc = 0.0;
+    const int si = lane + 1;
+    const int s = s0 + lane;
+    for (int y = y0; y < y1; ++y) {
+        int t = y - y0;
+        int m0 = t & 3, m1 = (t + 1) & 3, m2 = (t + 2) & 3, m3 = (t + 3) & 3;   // slots of y-1, y, y+1, free
+        int rc = (t + 1) & 1, rp = t & 1;                                      // R(y), R(y-1)
+        bool more = y + 1 < y1;
+        if (more) fetch(y + 2);                // in flight while this row is computed
+        compute_r(m1, m2, rc);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int zi = 1 + wave * 2 + q;
+            int z = z0 + zi - 1;
+            if (z < n && s < nx) {
+                float c = ring[m1][zi][si];
+                float v1n = 3.0f * c - ring[m1][zi][si + 1] - ring[m2][zi][si] - ring[m1][zi + 1][si];
+                float gv = v1n * rinv[rc][zi][si];
+                gv += (c - ring[m1][zi][si - 1]) * rinv[rc][zi][si - 1];
+                gv += (c - ring[m0][zi][si]) * rinv[rp][zi][si];
+                gv += (c - ring[m1][zi - 1][si]) * rinv[rc][zi - 1][si];
+                g[(size_t)(y * n + z) * sx + s] = gv;
+                acc += (double)(gv * gv);
+            }
+        }
+        if (more) stash(m3);                   // plane y+2 into the free slot
+        __syncthreads();
     }
     block_accumulate(acc, part);
 }

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -234,6 +235,110 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err)
     for (int64_t p = 0; p < npix; ++p) L = std::max(L, ata1[p]);
     t.lipschitz = L;
     return true;
+}
+
+// Walk lists (see sysmat.h).  Owner of pixel p for angle i = the first ray listed in cell[i][p]; pixels that no
+// ray of the angle crosses ("orphans", the image corners) are dealt round-robin over the angle's rays with
+// weight 0, so every ray carries about the same number of extra visits.
+void build_walk(const Coo &m, int N, int P, Tables &t)
+{
+    const int64_t npix = (int64_t)N * N;
+    const int64_t nrows = (int64_t)N * P;
+    std::vector<uint32_t> extra(nrows, 0);
+    std::vector<std::vector<uint32_t>> orphans(P);
+    for (int i = 0; i < P; ++i) {
+        const Cell *c = t.cell.data() + (size_t)i * npix;
+        uint32_t k = 0;
+        for (int64_t p = 0; p < npix; ++p)
+            if (c[p].w0 == 0.f) { orphans[i].push_back((uint32_t)p); extra[(int64_t)i * N + (k++ % N)]++; }
+    }
+    t.walk_ptr.assign(nrows + 1, 0);
+    for (int64_t r = 0; r < nrows; ++r)
+        t.walk_ptr[r + 1] = t.walk_ptr[r] + (uint32_t)(m.ptr[r + 1] - m.ptr[r]) + extra[r];
+    t.walk_pix.resize(t.walk_ptr[nrows]);
+    t.walk_w.resize(t.walk_ptr[nrows]);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), P);
+    auto work = [&](int th) {
+        for (int i = th; i < P; i += nth) {
+            const Cell *c = t.cell.data() + (size_t)i * npix;
+            for (int j = 0; j < N; ++j) {
+                int64_t r = (int64_t)i * N + j;
+                uint32_t o = t.walk_ptr[r];
+                for (int64_t k = m.ptr[r]; k < m.ptr[r + 1]; ++k) {
+                    uint32_t p = m.col[k];
+                    bool own = (m.val[k] != 0.f) && c[p].w0 != 0.f && c[p].r0 == (uint32_t)j;
+                    t.walk_pix[o] = p | (own ? 0x80000000u : 0u);
+                    t.walk_w[o] = m.val[k];
+                    ++o;
+                }
+                for (size_t q = j; q < orphans[i].size(); q += N) {
+                    t.walk_pix[o] = orphans[i][q] | 0x80000000u;
+                    t.walk_w[o] = 0.f;
+                    ++o;
+                }
+            }
+        }
+    };
+    std::vector<std::thread> thr;
+    for (int th = 1; th < nth; ++th) thr.emplace_back(work, th);
+    work(0);
+    for (auto &x : thr) x.join();
+}
+
+void build_segments(int N, int P, int seg_len, Tables &t)
+{
+    const int G = 16;  // RAY_GROUP of kernels.hip.h
+    t.seg_len = seg_len;
+    t.row_first.assign((size_t)N * P, 0);
+    t.row_nseg.assign((size_t)N * P, 0);
+    t.seg_exec_ptr.assign(P + 1, 0);
+    t.seg_exec.clear();
+    t.max_items_per_angle = 0;
+    for (int i = 0; i < P; ++i) {
+        uint32_t next_id = 0;
+        std::vector<Tables::SegItem> lists[8];
+        int ngroups = (N + G - 1) / G;
+        uint32_t maxseg_all = 0;
+        for (int j = 0; j < N; ++j) {
+            size_t r = (size_t)i * N + j;
+            uint32_t len = t.walk_ptr[r + 1] - t.walk_ptr[r];
+            uint32_t ns = (len + seg_len - 1) / seg_len;
+            t.row_first[r] = next_id;
+            t.row_nseg[r] = ns;
+            next_id += ns;
+            maxseg_all = std::max(maxseg_all, ns);
+        }
+        static const int order_mode = std::getenv("TOMO_SEG_ORDER") ? std::atoi(std::getenv("TOMO_SEG_ORDER")) : 0;
+        auto emit = [&](int g, uint32_t sidx) {
+            auto &L = lists[g & 7];
+            int j0 = g * G, j1 = std::min(N, j0 + G);
+            for (int j = j0; j < j1; ++j) {
+                size_t r = (size_t)i * N + j;
+                if (sidx >= t.row_nseg[r]) continue;
+                uint32_t kb = t.walk_ptr[r] + sidx * seg_len;
+                uint32_t ke = std::min(t.walk_ptr[r + 1], kb + (uint32_t)seg_len);
+                L.push_back({t.row_first[r] + sidx, kb, ke, 0});
+            }
+        };
+        if (order_mode == 1) {
+            // segment-major over the whole angle: the chip sweeps the image top to bottom
+            for (uint32_t sidx = 0; sidx < maxseg_all; ++sidx)
+                for (int g = 0; g < ngroups; ++g) emit(g, sidx);
+        } else {
+            // group-major: the s-th segments of neighbouring rays run side by side, one ray group after another
+            for (int g = 0; g < ngroups; ++g)
+                for (uint32_t sidx = 0; sidx < maxseg_all; ++sidx) emit(g, sidx);
+        }
+        size_t Lmax = 0;
+        for (auto &L : lists) Lmax = std::max(Lmax, L.size());
+        for (auto &L : lists) {
+            L.resize(Lmax, Tables::SegItem{0xFFFFFFFFu, 0, 0, 0});
+            t.seg_exec.insert(t.seg_exec.end(), L.begin(), L.end());
+        }
+        t.seg_exec_ptr[i + 1] = (uint32_t)t.seg_exec.size();
+        t.max_items_per_angle = std::max(t.max_items_per_angle, next_id);
+    }
 }
 
 }  // namespace tomo

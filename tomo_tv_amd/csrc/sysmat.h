@@ -21,6 +21,22 @@ struct Tables {
     std::vector<float> rowsum, rowinner, colsum_all;
     std::vector<Cell> cell;  // [P][N*N]
     float lipschitz = 0.f;
+    // "walk" lists for the fused SART step: per ray, its matrix entries plus a share of the angle's
+    // un-crossed pixels, so that the rays of one angle visit EVERY pixel and exactly one visit owns it.
+    // entry = {pixel | owner << 31, weight bits}
+    std::vector<uint32_t> walk_ptr;              // [P*N + 1]
+    std::vector<uint32_t> walk_pix;
+    std::vector<float> walk_w;
+    // Equal-sized work items over the walk lists (one wave each): a ray is cut into segments of <= seg_len
+    // visits.  Items of RAY_GROUP neighbouring rays are listed together and whole groups are dealt to the 8
+    // XCD lists, all padded to the same length, so neighbours share an L2 and every XCD gets the same work.
+    struct SegItem { uint32_t id, kbeg, kend, pad; };   // id = row_first[row] + segment number
+    int seg_len = 0;
+    std::vector<uint32_t> seg_exec_ptr;          // [P + 1] offsets (in items) into seg_exec; per angle 8*L items,
+    std::vector<SegItem> seg_exec;               //   XCD-major: item of workgroup b sits at [ (b%8)*L + b/8 ]
+    std::vector<uint32_t> row_first;             // [P*N] first partial-sum id of the row (within its angle)
+    std::vector<uint32_t> row_nseg;              // [P*N]
+    uint32_t max_items_per_angle = 0;
 };
 
 void build_parallel_ray(int N, int P, const double *angles_rad, Coo &out);
@@ -28,5 +44,7 @@ bool coo_from_triplets(int64_t nrow, int64_t ncol, int64_t nnz, const float *row
                        const float *vals, Coo &out, std::string &err);
 void sort_rows(Coo &m);
 bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err);
+void build_walk(const Coo &m, int N, int P, Tables &t);
+void build_segments(int N, int P, int seg_len, Tables &t);
 
 }  // namespace tomo

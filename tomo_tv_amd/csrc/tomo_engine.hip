@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,7 +38,7 @@ struct ProfSlot {
 };
 
 struct tomo_engine {
-    int nx = 0, n = 0, np = 0, sx = 0, vec = 1, device = 0;
+    int nx = 0, n = 0, np = 0, sx = 0, sxc = 0, vec = 1, device = 0;   // sx = row pitch, sxc = computed width
     int64_t npix = 0, nrows = 0, nnz = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -46,7 +47,17 @@ struct tomo_engine {
     uint2 *d_rent = nullptr;
     float *d_rowsum = nullptr, *d_rowinner = nullptr, *d_colsum_all = nullptr;
     CellD *d_cell = nullptr;
+    uint32_t *d_wptr = nullptr;                   // walk lists of the fused SART step
+    uint2 *d_went = nullptr;
     float lipschitz = 0.f;
+    int sart_fused = 2, sart_unroll = 8, fp_variant = 0;     // sart_fused: 0 FP+BP per angle, 1 fused per-ray, 2 fused segmented
+    int tv_lds = 1, fp_all_lpr = 16;           // all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
+    SegItemD *d_seg_exec = nullptr;
+    std::vector<uint32_t> h_seg_exec_ptr;
+    uint32_t *d_row_first = nullptr, *d_row_nseg = nullptr;
+    float *seg_partial = nullptr;
+    uint32_t max_items = 0;
+    float *sart_alt = nullptr;                    // ping-pong partner of the volume being swept
     // fields
     float *vol[TOMO_VOL_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float *sino_b = nullptr, *sino_g = nullptr, *sino_r = nullptr;
@@ -143,12 +154,25 @@ static int reduce_end(tomo_engine *e, int slot)
 static int grid_1d(int64_t n4) { int64_t b = (n4 + 255) / 256; return (int)std::min<int64_t>(std::max<int64_t>(b, 1), 4096); }
 
 // ---- projector launches -------------------------------------------------------------------------------------
+// vec_override: 0 = wide form (64*vec slices per workgroup, scalar table walk); 16 / 32 = narrow-chunk form with that
+// many lanes per ray (k_fp_rows_g)
 template <int MODE>
-static int launch_fp(tomo_engine *e, const float *x, int row0, int nrows, const float *b, float *out)
+static int launch_fp(tomo_engine *e, const float *x, int row0, int nrows, const float *b, float *out, int lpr = 0)
 {
-    int nchunk = e->sx / (64 * e->vec);
+    if (lpr == 16 || lpr == 32) {
+        int R = 64 / lpr;
+        int nchunk = e->sxc / (lpr * 4);
+        int64_t waves = (int64_t)((nrows + R - 1) / R) * nchunk;
+        dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        if (lpr == 16) hipLaunchKernelGGL((k_fp_rows_g<16, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx, nchunk);
+        else hipLaunchKernelGGL((k_fp_rows_g<32, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx, nchunk);
+        LAUNCHCHK();
+        return TOMO_OK;
+    }
+    int vec = e->vec;
+    int nchunk = e->sxc / (64 * vec);
     dim3 grid((unsigned)((int64_t)nrows * nchunk)), block(256);
-    switch (e->vec) {
+    switch (vec) {
     case 4: hipLaunchKernelGGL((k_fp_rows<4, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx); break;
     case 2: hipLaunchKernelGGL((k_fp_rows<2, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx); break;
     default: hipLaunchKernelGGL((k_fp_rows<1, MODE>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, b, e->d_rowsum, out, e->d_part, row0, nrows, e->sx); break;
@@ -162,30 +186,90 @@ constexpr int BP_PPW = 4;
 static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_angle, float beta)
 {
     ProfScope ps(e, TOMO_K_BP_ANGLE);
-    int nchunk = e->sx / (64 * e->vec);
+    int nchunk = e->sxc / (64 * e->vec);
     int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
     int64_t waves = (int64_t)ngroups * nchunk;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const CellD *cell = e->d_cell + (size_t)angle * e->npix;
     switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups); break;
-    case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups); break;
-    default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups); break;
+    case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
+    case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
+    default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
     }
     LAUNCHCHK();
     return TOMO_OK;
 }
 
+template <int U>
+static int launch_sart_fused_u(tomo_engine *e, const float *x_old, float *x_new, int prev, int next, float *r, float beta)
+{
+    int nchunk = e->sxc / (64 * e->vec);
+    dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
+    const CellD *cell = e->d_cell + (size_t)prev * e->npix;
+    const float *rp = r + (size_t)prev * e->n * e->sx;
+    switch (e->vec) {
+    case 4: hipLaunchKernelGGL((k_sart_fused<4, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->sino_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
+    case 2: hipLaunchKernelGGL((k_sart_fused<2, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->sino_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
+    default: hipLaunchKernelGGL((k_sart_fused<1, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->sino_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
+    }
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+static int launch_sart_fused(tomo_engine *e, const float *x_old, float *x_new, int prev, int next, float *r, float beta)
+{
+    ProfScope ps(e, TOMO_K_SART_FUSED);
+    return e->sart_unroll == 4 ? launch_sart_fused_u<4>(e, x_old, x_new, prev, next, r, beta)
+                               : launch_sart_fused_u<8>(e, x_old, x_new, prev, next, r, beta);
+}
+
+// segmented per-angle step: FUSED -> BP(prev) + FP(next); else plain FP(next).  Leaves the residual rows of `next` in r.
+template <bool FUSED>
+static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int prev, int next, float *r, float beta)
+{
+    int rc;
+    if (!e->seg_partial) {
+        if ((rc = dev_alloc((void **)&e->seg_partial, (size_t)std::max<uint32_t>(1, e->max_items) * e->sx * sizeof(float), true, e->stream))) return rc;
+    }
+    int nchunk = e->sxc / (64 * e->vec);
+    uint32_t b0 = e->h_seg_exec_ptr[next], b1 = e->h_seg_exec_ptr[next + 1];
+    int L = (int)((b1 - b0) / 8);
+    const SegItemD *exec = e->d_seg_exec + b0;
+    const CellD *cell = FUSED ? e->d_cell + (size_t)prev * e->npix : nullptr;
+    const float *rp = FUSED ? r + (size_t)prev * e->n * e->sx : nullptr;
+    if (L > 0) {
+        ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE);
+        dim3 grid((unsigned)(8 * (int64_t)L * nchunk)), block(64);
+        switch (e->vec) {
+        case 4: hipLaunchKernelGGL((k_sart_seg<4, 8, FUSED>), grid, block, 0, e->stream, x_old, x_new, exec, L, e->d_went, cell, rp, beta, e->seg_partial, e->sx); break;
+        case 2: hipLaunchKernelGGL((k_sart_seg<2, 8, FUSED>), grid, block, 0, e->stream, x_old, x_new, exec, L, e->d_went, cell, rp, beta, e->seg_partial, e->sx); break;
+        default: hipLaunchKernelGGL((k_sart_seg<1, 8, FUSED>), grid, block, 0, e->stream, x_old, x_new, exec, L, e->d_went, cell, rp, beta, e->seg_partial, e->sx); break;
+        }
+        LAUNCHCHK();
+    }
+    {
+        int64_t waves = (int64_t)e->n * nchunk;
+        dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        switch (e->vec) {
+        case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->sino_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+        case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->sino_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+        default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->sino_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+        }
+        LAUNCHCHK();
+    }
+    return TOMO_OK;
+}
+
 static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
 {
-    int nchunk = e->sx / (64 * e->vec);
+    int nchunk = e->sxc / (64 * e->vec);
     int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
     int64_t waves = (int64_t)ngroups * nchunk;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_bp_all<4, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups); break;
-    case 2: hipLaunchKernelGGL((k_bp_all<2, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups); break;
-    default: hipLaunchKernelGGL((k_bp_all<1, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups); break;
+    case 4: hipLaunchKernelGGL((k_bp_all<4, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups, nchunk); break;
+    case 2: hipLaunchKernelGGL((k_bp_all<2, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups, nchunk); break;
+    default: hipLaunchKernelGGL((k_bp_all<1, BP_PPW>), grid, block, 0, e->stream, x, e->d_cell, r, colsum, alpha, beta, clamp, e->np, e->n, (int)e->npix, e->sx, ngroups, nchunk); break;
     }
     LAUNCHCHK();
     return TOMO_OK;
@@ -220,6 +304,29 @@ static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out)
     HIPCHK(hipMemcpy(e->d_rowsum, t.rowsum.data(), t.rowsum.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_rowinner, t.rowinner.data(), t.rowinner.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_colsum_all, t.colsum_all.data(), t.colsum_all.size() * 4, hipMemcpyHostToDevice));
+    build_walk(m, e->n, e->np, t);
+    {
+        std::vector<uint2> went(t.walk_pix.size() ? t.walk_pix.size() : 1);
+        for (size_t k = 0; k < t.walk_pix.size(); ++k) { uint32_t bits; std::memcpy(&bits, &t.walk_w[k], 4); went[k] = make_uint2(t.walk_pix[k], bits); }
+        if ((rc = dev_alloc((void **)&e->d_wptr, t.walk_ptr.size() * 4, false, e->stream))) return rc;
+        if ((rc = dev_alloc((void **)&e->d_went, went.size() * sizeof(uint2), false, e->stream))) return rc;
+        HIPCHK(hipMemcpy(e->d_wptr, t.walk_ptr.data(), t.walk_ptr.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_went, went.data(), t.walk_pix.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    }
+    {
+        int seg_len = 32;
+        if (const char *sl = std::getenv("TOMO_SEG")) seg_len = std::max(8, std::atoi(sl));
+        build_segments(e->n, e->np, seg_len, t);
+        static_assert(sizeof(Tables::SegItem) == sizeof(SegItemD), "segment item layout");
+        e->h_seg_exec_ptr = t.seg_exec_ptr;
+        e->max_items = t.max_items_per_angle;
+        if ((rc = dev_alloc((void **)&e->d_seg_exec, std::max<size_t>(1, t.seg_exec.size()) * sizeof(SegItemD), false, e->stream))) return rc;
+        if ((rc = dev_alloc((void **)&e->d_row_first, t.row_first.size() * 4, false, e->stream))) return rc;
+        if ((rc = dev_alloc((void **)&e->d_row_nseg, t.row_nseg.size() * 4, false, e->stream))) return rc;
+        HIPCHK(hipMemcpy(e->d_seg_exec, t.seg_exec.data(), t.seg_exec.size() * sizeof(SegItemD), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_row_first, t.row_first.data(), t.row_first.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_row_nseg, t.row_nseg.data(), t.row_nseg.size() * 4, hipMemcpyHostToDevice));
+    }
     static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
     HIPCHK(hipMemcpy(e->d_cell, t.cell.data(), t.cell.size() * sizeof(CellD), hipMemcpyHostToDevice));
     if ((rc = dev_alloc((void **)&e->d_scal_own, TOMO_S_COUNT * sizeof(double), true, e->stream))) return rc;
@@ -240,8 +347,11 @@ static tomo_engine *new_engine(int nslice, int nray, int nproj, int device)
 {
     tomo_engine *e = new tomo_engine();
     e->nx = nslice; e->n = nray; e->np = nproj; e->device = device;
-    e->sx = ((nslice + 63) / 64) * 64;
-    e->vec = (e->sx % 256 == 0) ? 4 : (e->sx % 128 == 0) ? 2 : 1;
+    e->sxc = ((nslice + 63) / 64) * 64;
+    e->vec = (e->sxc % 256 == 0) ? 4 : (e->sxc % 128 == 0) ? 2 : 1;
+    int pad = 0;
+    if (const char *pp = std::getenv("TOMO_PITCH_PAD")) pad = std::atoi(pp);
+    e->sx = e->sxc + pad;
     e->npix = (int64_t)nray * nray;
     e->nrows = (int64_t)nray * nproj;
     return e;
@@ -314,7 +424,7 @@ int tomo_destroy(tomo_engine *e)
     if (!e) return TOMO_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->sino_b, e->sino_g,
+    void *ptrs[] = {e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->sino_b, e->sino_g,
                     e->sino_r, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -458,7 +568,7 @@ int tomo_forward_projection(tomo_engine *e, int vol, int sino)
     float *x, *g; int rc;
     if ((rc = get_vol(e, vol, &x))) return rc;
     if ((rc = sino == TOMO_SINO_B ? get_sino(e, &e->sino_b, &g) : get_sino(e, &e->sino_g, &g))) return rc;
-    return launch_fp<FP_STORE>(e, x, 0, (int)e->nrows, nullptr, g);
+    return launch_fp<FP_STORE>(e, x, 0, (int)e->nrows, nullptr, g, e->fp_all_lpr);
 }
 
 int tomo_back_projection(tomo_engine *e, int sino, int vol)
@@ -480,7 +590,7 @@ int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter)
     float *x, *r; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, e->sino_b, r))) return rc;
+        if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, e->sino_b, r, e->fp_all_lpr))) return rc;
         if ((rc = launch_bp_all(e, x, r, nullptr, 1.f, beta, 1))) return rc;
     }
     return TOMO_OK;
@@ -492,7 +602,7 @@ int tomo_sirt(tomo_engine *e, int vol, int niter)
     float *x, *r; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if ((rc = launch_fp<FP_RESID_NORM>(e, x, 0, (int)e->nrows, e->sino_b, r))) return rc;
+        if ((rc = launch_fp<FP_RESID_NORM>(e, x, 0, (int)e->nrows, e->sino_b, r, e->fp_all_lpr))) return rc;
         if ((rc = launch_bp_all(e, x, r, e->d_colsum_all, 1.f, 1.f, 1))) return rc;
     }
     return TOMO_OK;
@@ -510,15 +620,54 @@ int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *ord
             seen[order[q]] = 1;
         }
     }
-    for (int it = 0; it < niter; ++it)
-        for (int q = 0; q < e->np; ++q) {
-            int i = order ? order[q] : q;
+    const int64_t steps = (int64_t)niter * e->np;
+    auto angle_at = [&](int64_t k) { int q = (int)(k % e->np); return order ? order[q] : q; };
+    if (!e->sart_fused) {
+        // reference structure: one forward projection + one back-projection update per angle
+        for (int64_t k = 0; k < steps; ++k) {
+            int i = angle_at(k);
             {
                 ProfScope ps(e, TOMO_K_FP_ANGLE);
-                if ((rc = launch_fp<FP_RESID_NORM>(e, x, i * e->n, e->n, e->sino_b, r))) return rc;
+                if (e->fp_variant && e->vec == 4) {
+                    int nchunk = e->sxc / 256;
+                    dim3 grid((unsigned)((int64_t)e->n * nchunk / 4)), block(256);
+                    if (e->fp_variant == 3 && e->sxc % 512 == 0) { grid = dim3((unsigned)((int64_t)e->n * (e->sxc / 512) / 4)); hipLaunchKernelGGL((k_fp_rows_w1x2<8>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowsum, r, i * e->n, e->n, e->sx); }
+                    else if (e->fp_variant == 1) hipLaunchKernelGGL((k_fp_rows_w1<4, 8>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowsum, r, i * e->n, e->n, e->sx);
+                    else hipLaunchKernelGGL((k_fp_rows_w1<4, 16>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowsum, r, i * e->n, e->n, e->sx);
+                    LAUNCHCHK();
+                } else if ((rc = launch_fp<FP_RESID_NORM>(e, x, i * e->n, e->n, e->sino_b, r))) return rc;
             }
             if ((rc = launch_bp_angle(e, x, i, r + (size_t)i * e->n * e->sx, beta))) return rc;
         }
+        return TOMO_OK;
+    }
+    // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
+    if (steps <= 0) return TOMO_OK;
+    float *alt;
+    if ((rc = get_scratch(e, &e->sart_alt, &alt))) return rc;
+    float *cur = x;
+    const bool seg = e->sart_fused == 2;
+    if (seg) {
+        if ((rc = launch_sart_seg<false>(e, cur, nullptr, 0, angle_at(0), r, beta))) return rc;
+    } else {
+        ProfScope ps(e, TOMO_K_FP_ANGLE);
+        if ((rc = launch_fp<FP_RESID_NORM>(e, cur, angle_at(0) * e->n, e->n, e->sino_b, r))) return rc;
+    }
+    for (int64_t k = 1; k < steps; ++k) {
+        int prev = angle_at(k - 1), next = angle_at(k);
+        if (prev == next) {   // single-angle geometry: the residual rows read and written would be the same
+            if ((rc = launch_bp_angle(e, cur, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc;
+            if ((rc = launch_fp<FP_RESID_NORM>(e, cur, next * e->n, e->n, e->sino_b, r))) return rc;
+            continue;
+        }
+        if (seg) rc = launch_sart_seg<true>(e, cur, alt, prev, next, r, beta);
+        else rc = launch_sart_fused(e, cur, alt, prev, next, r, beta);
+        if (rc) return rc;
+        std::swap(cur, alt);
+    }
+    int last = angle_at(steps - 1);
+    if ((rc = launch_bp_angle(e, cur, last, r + (size_t)last * e->n * e->sx, beta))) return rc;
+    if (cur != x) { e->vol[vol] = cur; e->sart_alt = x; }   // the swept volume now lives in the partner buffer
     return TOMO_OK;
 }
 
@@ -537,7 +686,7 @@ int tomo_poisson_ml(tomo_engine *e, float lambda)
     float *x = e->vol[TOMO_VOL_RECON], *r; int rc;
     if ((rc = get_sino(e, &e->sino_r, &r))) return rc;
     if ((rc = reduce_begin(e))) return rc;
-    if ((rc = launch_fp<FP_POISSON>(e, x, 0, (int)e->nrows, e->sino_b, r))) return rc;
+    if ((rc = launch_fp<FP_POISSON>(e, x, 0, (int)e->nrows, e->sino_b, r, e->fp_all_lpr))) return rc;
     if ((rc = reduce_end(e, TOMO_S_COST))) return rc;
     return launch_bp_all(e, x, r, nullptr, 1.f, -(lambda / e->lipschitz), 1);
 }
@@ -580,7 +729,7 @@ int tomo_data_distance_sq(tomo_engine *e, int vol)
     float *x, *g; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_g, &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
-    if ((rc = launch_fp<FP_DD>(e, x, 0, (int)e->nrows, e->sino_b, g))) return rc;
+    if ((rc = launch_fp<FP_DD>(e, x, 0, (int)e->nrows, e->sino_b, g, e->fp_all_lpr))) return rc;
     return reduce_end(e, TOMO_S_DD);
 }
 
@@ -692,7 +841,14 @@ int tomo_tv_grad(tomo_engine *e, float eps)
     Halo h{e->halo_lo, e->halo_hi};
     {
         ProfScope ps(e, TOMO_K_TV_GRAD);
-        hipLaunchKernelGGL(k_tv_grad, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx);
+        if (e->tv_lds) {
+            int yseg = 32;
+            int nzb = (e->n + TVL_TZ - 1) / TVL_TZ;
+            dim3 grid((unsigned)(nzb * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+            hipLaunchKernelGGL(k_tv_grad_lds, grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg);
+        } else {
+            hipLaunchKernelGGL(k_tv_grad, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx);
+        }
     }
     LAUNCHCHK();
     return reduce_end(e, TOMO_S_GNORM);
@@ -788,6 +944,17 @@ int tomo_tv_fgp(tomo_engine *e, int iters, float lambda)
     e->is_first = f; e->is_last = l;
     if (rc) return rc;
     return tomo_fgp_end(e, iters);
+}
+
+int tomo_set_option(tomo_engine *e, const char *name, int value)
+{
+    if (!e || !name) return fail(TOMO_ERR_ARG, "null argument");
+    if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value < 0 || value > 2 ? 2 : value; return TOMO_OK; }
+    if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
+    if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_variant") == 0) { e->fp_variant = value; return TOMO_OK; }
+    if (std::strcmp(name, "sart_unroll") == 0) { e->sart_unroll = value == 4 ? 4 : 8; return TOMO_OK; }
+    return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
 
 // ---- measurement ------------------------------------------------------------------------------------------------------------

@@ -361,6 +361,10 @@ class _EngineBase:
     def synchronize(self):
         self.be.c("synchronize")
 
+    def set_option(self, name, value):
+        """Engine switches (include/tomo_hip.h: tomo_set_option), e.g. ``set_option("sart_fused", 0)``."""
+        self.be.c("set_option", name.encode(), int(value))
+
 
 class tomoengine(_EngineBase):
     """``tomoengine(Nslice, Nray, angles_rad)`` -- tomofusion/gpu/utils/tomoengine.cpp:48-84."""
