@@ -136,7 +136,7 @@ def main():
     for _ in range(args.warmup):
         asd_pocs_step(t, st)
     sync()
-    kernels = {"k_sart_fused": K_SART_FUSED, "k_bp_angle": K_BP_ANGLE, "k_fp_angle": 1}
+    kernels = {"k_sart_fused": K_SART_FUSED, "k_bp_angle": K_BP_ANGLE, "k_fp_angle": 1}   # k_sart_fused = k_sart_seg<FUSED=true>
     for kid in kernels.values():
         _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
     t0 = time.perf_counter()
@@ -172,6 +172,18 @@ def main():
             roofs[name] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": cnt, "avg_ms": avg_ms,
                            "total_ms": tot, "algorithmic_bytes_per_launch": alg_bytes[name]}
+        # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), null if absent
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            match = {"k_sart_fused": "k_sart_seg<4, 8, true>", "k_bp_angle": "k_bp_angle<4, 4>", "k_fp_angle": "k_sart_seg<4, 8, false>"}
+            if (nloc, n, nproj) == (512, 512, 90):
+                for name, key in match.items():
+                    hit = [v for k, v in pmc.items() if key in k]
+                    if hit:
+                        roofs[name]["traffic"] = hit[0]["hbm_bytes_per_launch"]
+                        roofs[name]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+        except (OSError, KeyError, ValueError):
+            pass
         dominant = max(roofs.values(), key=lambda r: r["total_ms"])
         out = {
             "metric": "SART+TV Gvoxel-updates/s (ASD-POCS outer iterations x voxels, 512^3 x 90 tilts per GPU)",
