@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--nslice", type=int, default=512, help="slices per GPU")
     ap.add_argument("--nproj", type=int, default=90)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the slab-sharded engine + RCCL even with one rank")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tomo_set_option), repeatable")
     args = ap.parse_args()
 
@@ -107,11 +108,13 @@ def main():
     n, nproj, nloc = args.n, args.nproj, args.nslice
     ang = np.deg2rad(tilt_angles(nproj))
     comm = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         t = multigpuengine(nloc * world, n, ang)
         comm = t.comm
     else:

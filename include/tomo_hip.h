@@ -28,9 +28,13 @@ enum tomo_status { TOMO_OK = 0, TOMO_ERR_ARG = 1, TOMO_ERR_HIP = 2, TOMO_ERR_STA
 
 /* volumes held by the engine (tomoengine.hpp:44: recon, temp_recon, original_volume, yk, recon_old) */
 enum tomo_volume { TOMO_VOL_RECON = 0, TOMO_VOL_TEMP = 1, TOMO_VOL_ORIGINAL = 2, TOMO_VOL_YK = 3, TOMO_VOL_RECON_OLD = 4,
-                   TOMO_VOL_COUNT = 5 };
+                   TOMO_VOL_COUNT = 5,
+                   TOMO_VOL_USER0 = 5,      /* caller-managed extra volumes (per-element tomograms of Matrix4D, multimodal.hpp) */
+                   TOMO_VOL_SLOTS = 5 + 40 };
 /* sinograms held by the engine (tomoengine.hpp:53: b = measured, g = re-projection) */
-enum tomo_sinogram { TOMO_SINO_B = 0, TOMO_SINO_G = 1 };
+enum tomo_sinogram { TOMO_SINO_B = 0, TOMO_SINO_G = 1, TOMO_SINO_R = 2 /* residual scratch */,
+                     TOMO_SINO_USER0 = 3,   /* caller-managed extra sinograms (per-element bChem, multimodal.hpp) */
+                     TOMO_SINO_SLOTS = 3 + 40 };
 
 /* slots of the device scalar buffer (doubles); each holds THIS slab's partial sum */
 enum tomo_scalar { TOMO_S_DD = 0,      /* sum (A x - b)^2            data_distance  */
@@ -72,6 +76,7 @@ int tomo_get_dims(tomo_engine *e, int *nslice, int *nray, int *nproj, int64_t *n
 
 /* ---- data in / out ------------------------------------------------------------------------------- */
 int tomo_set_tilt_series(tomo_engine *e, const float *b);               /* tomoengine.cpp:101 setTiltSeries */
+int tomo_set_sinogram(tomo_engine *e, int which, const float *b);       /* multimodal.cpp:150-151 set_haadf/chem_tilt_series */
 int tomo_get_sinogram(tomo_engine *e, int which, float *out);           /* :454-458 get_projections / get_model_projections */
 int tomo_set_volume(tomo_engine *e, int vol, const float *data);        /* all slices at once */
 int tomo_get_volume(tomo_engine *e, int vol, float *data);
@@ -91,13 +96,19 @@ int tomo_row_inner_product(tomo_engine *e);                             /* ctvli
 int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter);
 /* tomoengine::SIRT(nIter) (ASTRA SIRT, min-constraint 0): x = max(0, x + C A^T R (b - A x))  tomoengine.cpp:181-205 */
 int tomo_sirt(tomo_engine *e, int vol, int niter);
+/* the same with the measured data in any sinogram slot: multimodal::SIRT(e, s, nIter)  multimodal.cpp:339-358 */
+int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter);
 /* tomoengine::SART(beta, nIter): nIter sweeps of per-angle updates, order[] = angle permutation or NULL
  * (sequential)  tomoengine.cpp:151-179 */
 int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *order);
+int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order); /* multimodal.cpp:377-396 */
 /* ctvlib::ART(beta): row-action Kaczmarz sweep + positivity  ctvlib.cpp:137-155 */
 int tomo_art(tomo_engine *e, float beta);
 /* tomoengine::poisson_ML(lambda): cost accumulates in TOMO_S_COST  tomoengine.cpp:231-246, 293-315 */
 int tomo_poisson_ml(tomo_engine *e, float lambda);
+/* out = (A x - b)/(A x + 0.1), cost sum(Ax - b log(Ax + 0.1)) -> TOMO_S_COST   multimodal.cpp:284-292, 466-473 */
+int tomo_poisson_residual(tomo_engine *e, int vol, int sino_b, int sino_out);
+int tomo_scale_volume(tomo_engine *e, int vol, float factor);           /* multimodal.cpp:307-309 rescale_tomograms */
 int tomo_positivity(tomo_engine *e, int vol);                           /* ctvlib.cpp:224-231 */
 int tomo_soft_threshold(tomo_engine *e, int vol, float lambda);         /* matrix_ops.cu:64-75 */
 int tomo_fista_momentum(tomo_engine *e, float beta);                    /* tomoengine.cpp:381-384 */
@@ -105,6 +116,9 @@ int tomo_fista_momentum(tomo_engine *e, float beta);                    /* tomoe
 /* ---- scalar reductions: partial sums of this slab land in the device scalar buffer ------------------ */
 int tomo_data_distance_sq(tomo_engine *e, int vol);                     /* tomoengine.cpp:410-413 -> TOMO_S_DD (also fills G) */
 int tomo_diff_norm_sq(tomo_engine *e, int a, int b, int slot);          /* :407 matrix_2norm, :433 rmse */
+int tomo_sino_diff_norm_sq(tomo_engine *e, int a, int b, int slot);     /* multimodal.cpp:489 (g - bh).norm() */
+int tomo_sino_proj_max(tomo_engine *e, int sino, float *out_host);      /* multimodal.cpp:323-327: max per projection */
+int tomo_sino_proj_scale(tomo_engine *e, int sino, const float *div_host, const float *mul_host); /* b <- b/div[p]*mul[p] */
 int tomo_l1_norm(tomo_engine *e, int vol);                              /* :436 l1_norm -> TOMO_S_L1 */
 int tomo_read_scalars(tomo_engine *e, double *out, int count);          /* synchronises the stream */
 int tomo_bind_scalar_buffer(tomo_engine *e, void *device_doubles);      /* >= TOMO_S_COUNT doubles, e.g. a torch tensor */
@@ -126,6 +140,7 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps);                /* tv_gd
 int tomo_tv_grad(tomo_engine *e, float eps);                            /* ctvlib.cpp:415-449 -> TOMO_S_GNORM */
 int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp);             /* ctvlib.cpp:452-458 (+461 when clamp) */
 int tomo_fgp_begin(tomo_engine *e);                                     /* tv_fgp.cu:216-227 */
+int tomo_fgp_begin_vol(tomo_engine *e, int vol);                        /* one element of cuda_tv_fgp_4D (chemistry/.../tv_fgp.cu:192) */
 int tomo_fgp_obj(tomo_engine *e, float lambda);                         /* :44-65 + :143-154 */
 int tomo_fgp_grad(tomo_engine *e, float lambda);                        /* :67-115 */
 int tomo_fgp_end(tomo_engine *e, int iters);                            /* :272 */
@@ -134,6 +149,17 @@ int tomo_fgp_end(tomo_engine *e, int iters);                            /* :272 
 int tomo_tv(tomo_engine *e, int vol, float eps);                        /* tomoengine.cpp:439-442 tv_3D -> TOMO_S_TV */
 int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps);         /* :445 tv_gd_3D; TV before descent -> TOMO_S_TV */
 int tomo_tv_fgp(tomo_engine *e, int iters, float lambda);               /* :448-450 tv_fgp_3D; TV of input -> TOMO_S_TV */
+int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda);  /* multimodal.cpp:497 tv_fgp_4D, one element */
+
+/* ---- multimodal (ChemicalTomo) element-wise steps ---------------------------------------------------------
+ * Two engines with the same slab shape on one device and stream: `ce` carries the chemical geometry and the
+ * per-element tomograms, `he` the HAADF geometry, the model volume Sigma*x^gamma and the SIRT-updated model.
+ * Sigma (fusion_helper.py:5-32) is pixel-diagonal with one weight per element, passed as w[nel]. */
+int tomo_get_stream(tomo_engine *e, void **hip_stream);
+int tomo_mm_model(tomo_engine *ce, const int32_t *xvols, int nel, const float *w, float gamma, tomo_engine *he,
+                  int model_vol);                                       /* multimodal.cpp:425-427 */
+int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, int nel, const float *w, float gamma,
+                   float lamC_over_L, float lamH, tomo_engine *he, int upd_vol, int model_vol); /* :435-438, :471-476 */
 
 /* Engine options.  "sart_fused" (default 1): run a SART sweep as FP(a0), [BP(a_k)+FP(a_k+1)] fused steps, BP(a_last)
  * instead of separate FP/BP launches per angle (same arithmetic per voxel; 8 instead of 12 bytes per voxel-angle). */

@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(_HERE, "libtomo_hip.so")
 
 # enum mirrors (include/tomo_hip.h)
 VOL_RECON, VOL_TEMP, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD = 0, 1, 2, 3, 4
-SINO_B, SINO_G = 0, 1
+SINO_B, SINO_G, SINO_R, SINO_USER0 = 0, 1, 2, 3
+VOL_USER0 = 5
 S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 16
 FIELD_FGP_D, FIELD_FGP_P1 = 100, 101
 K_BP_ANGLE, K_FP_ANGLE, K_TV_GRAD, K_TV_UPDATE, K_FGP_OBJ, K_FGP_GRAD, K_SART_FUSED = 0, 1, 2, 3, 4, 5, 6
@@ -69,6 +70,19 @@ SIGNATURES = {
     "tomo_tv_gd": [_p, _i, _f, _f],
     "tomo_tv_fgp": [_p, _i, _f],
     "tomo_set_option": [_p, ctypes.c_char_p, _i],
+    "tomo_set_sinogram": [_p, _i, _p],
+    "tomo_sirt_data": [_p, _i, _i, _i],
+    "tomo_sart_data": [_p, _i, _i, _f, _i, _p],
+    "tomo_poisson_residual": [_p, _i, _i, _i],
+    "tomo_scale_volume": [_p, _i, _f],
+    "tomo_sino_diff_norm_sq": [_p, _i, _i, _i],
+    "tomo_sino_proj_max": [_p, _i, _p],
+    "tomo_sino_proj_scale": [_p, _i, _p, _p],
+    "tomo_fgp_begin_vol": [_p, _i],
+    "tomo_tv_fgp_vol": [_p, _i, _i, _f],
+    "tomo_get_stream": [_p, _pp],
+    "tomo_mm_model": [_p, _p, _i, _p, _f, _p, _i],
+    "tomo_mm_update": [_p, _p, _p, _i, _p, _f, _f, _f, _p, _i, _i],
     "tomo_profile_enable": [_p, _i, _i],
     "tomo_profile_read": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
 }

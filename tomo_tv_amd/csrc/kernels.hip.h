@@ -725,6 +725,80 @@ __global__ __launch_bounds__(256) void k_l1(const f4 *__restrict__ a, double *__
     block_accumulate(acc, part);
 }
 
+__global__ __launch_bounds__(256) void k_scale(f4 *__restrict__ x, float f, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) x[i] = x[i] * f;
+}
+
+// max over rays and slices of one projection (block p handles projection p)
+__global__ __launch_bounds__(256) void k_proj_max(const float *__restrict__ g, float *__restrict__ out, int n, int nx, int sx)
+{
+    __shared__ float red[256];
+    const float *base = g + (size_t)blockIdx.x * n * sx;
+    float m = -3.402823466e38f;
+    for (int64_t i = threadIdx.x; i < (int64_t)n * sx; i += 256) {
+        int s = (int)(i % sx);
+        if (s < nx) m = fmaxf(m, base[i]);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// b <- (b / div[p]) * mul[p] for projection p (the two steps of multimodal.cpp:325-326)
+__global__ __launch_bounds__(256) void k_proj_scale(float *__restrict__ g, const float *__restrict__ f, int n, int sx)
+{
+    float *base = g + (size_t)blockIdx.x * n * sx;
+    float d = f[blockIdx.x], m = f[gridDim.x + blockIdx.x];
+    for (int64_t i = threadIdx.x; i < (int64_t)n * sx; i += 256) base[i] = (base[i] / d) * m;
+}
+
+// ---- multimodal (ChemicalTomo) element-wise steps -----------------------------------------------------------
+// Sigma of fusion_helper.py:5-32 has one weight per element and pixel-diagonal structure, so
+// Sigma*x = sum_e w_e x_e and Sigma^T v = (w_e v)_e: no sparse matrix is needed.
+constexpr int MM_MAX_EL = 8;
+struct MMArgs { float *x[MM_MAX_EL]; float *u[MM_MAX_EL]; float w[MM_MAX_EL]; int nel; float gamma; };
+
+__device__ __forceinline__ f4 pow4(f4 v, float g)
+{
+    f4 r; r.x = powf(v.x, g); r.y = powf(v.y, g); r.z = powf(v.z, g); r.w = powf(v.w, g); return r;
+}
+
+__global__ __launch_bounds__(256) void k_mm_model(MMArgs a, f4 *__restrict__ model, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < a.nel; ++e) {
+            f4 v = reinterpret_cast<const f4 *>(a.x[e])[i];
+            if (a.gamma != 1.0f) v = pow4(v, a.gamma);
+            acc += a.w[e] * v;
+        }
+        model[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mm_update(MMArgs a, const f4 *__restrict__ upd, const f4 *__restrict__ model,
+                                                    float lamC_over_L, float lamH, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f4 d = {0.f, 0.f, 0.f, 0.f};
+        if (lamH != 0.f) d = upd[i] - model[i];
+        for (int e = 0; e < a.nel; ++e) {
+            f4 x = reinterpret_cast<f4 *>(a.x[e])[i];
+            f4 uc = reinterpret_cast<const f4 *>(a.u[e])[i];
+            f4 uh = a.w[e] * d;                                   // Sigma^T (updateVol - modelHAADF)
+            if (a.gamma != 1.0f) uh = (a.gamma * pow4(x, a.gamma - 1.0f)) * uh;
+            f4 v = x - (lamC_over_L * uc - lamH * uh);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            reinterpret_cast<f4 *>(a.x[e])[i] = v;
+        }
+    }
+}
+
 // ---- 3-D TV stencils ---------------------------------------------------------------------------------
 // Index map to the reference's (i, j, k): i = slice s (periodic over the GLOBAL slice count, neighbours
 // of the slab's end slices come from halo planes), j = y, k = z (periodic over N).

@@ -50,7 +50,7 @@ struct tomo_engine {
     uint32_t *d_wptr = nullptr;                   // walk lists of the fused SART step
     uint2 *d_went = nullptr;
     float lipschitz = 0.f;
-    int sart_fused = 2, sart_unroll = 8, fp_variant = 0;     // sart_fused: 0 FP+BP per angle, 1 fused per-ray, 2 fused segmented
+    int sart_fused = 2, sart_unroll = 8;     // sart_fused: 0 FP+BP per angle, 1 fused per-ray, 2 fused segmented
     int tv_lds = 1, fp_all_lpr = 16;           // all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
     SegItemD *d_seg_exec = nullptr;
     std::vector<uint32_t> h_seg_exec_ptr;
@@ -59,8 +59,10 @@ struct tomo_engine {
     uint32_t max_items = 0;
     float *sart_alt = nullptr;                    // ping-pong partner of the volume being swept
     // fields
-    float *vol[TOMO_VOL_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    float *sino_b = nullptr, *sino_g = nullptr, *sino_r = nullptr;
+    float *vol[TOMO_VOL_SLOTS] = {};
+    float *sino[TOMO_SINO_SLOTS] = {};
+    int fgp_target = TOMO_VOL_RECON;
+    float *cur_b = nullptr;                      // data sinogram of the SART call in progress
     float *tvg = nullptr;                         // TV gradient tensor; doubles as FGP "D"
     float *fgp_p[3] = {nullptr, nullptr, nullptr};
     float *stage = nullptr;
@@ -84,7 +86,7 @@ static int dev_alloc(void **p, size_t bytes, bool zero, hipStream_t st)
 
 static int get_vol(tomo_engine *e, int id, float **out)
 {
-    if (id < 0 || id >= TOMO_VOL_COUNT) return fail(TOMO_ERR_ARG, "bad volume id");
+    if (id < 0 || id >= TOMO_VOL_SLOTS) return fail(TOMO_ERR_ARG, "bad volume id");
     if (!e->vol[id]) {
         int rc = dev_alloc((void **)&e->vol[id], e->vol_elems() * sizeof(float), true, e->stream);
         if (rc) return rc;
@@ -101,6 +103,12 @@ static int get_sino(tomo_engine *e, float **slot, float **out)
     }
     *out = *slot;
     return TOMO_OK;
+}
+
+static int sino_slot(tomo_engine *e, int id, float **out)
+{
+    if (id < 0 || id >= TOMO_SINO_SLOTS) return fail(TOMO_ERR_ARG, "bad sinogram id");
+    return get_sino(e, &e->sino[id], out);
 }
 
 static int get_scratch(tomo_engine *e, float **slot, float **out)
@@ -208,9 +216,9 @@ static int launch_sart_fused_u(tomo_engine *e, const float *x_old, float *x_new,
     const CellD *cell = e->d_cell + (size_t)prev * e->npix;
     const float *rp = r + (size_t)prev * e->n * e->sx;
     switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_sart_fused<4, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->sino_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
-    case 2: hipLaunchKernelGGL((k_sart_fused<2, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->sino_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
-    default: hipLaunchKernelGGL((k_sart_fused<1, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->sino_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
+    case 4: hipLaunchKernelGGL((k_sart_fused<4, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->cur_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
+    case 2: hipLaunchKernelGGL((k_sart_fused<2, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->cur_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
+    default: hipLaunchKernelGGL((k_sart_fused<1, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->cur_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
     }
     LAUNCHCHK();
     return TOMO_OK;
@@ -251,9 +259,9 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
         int64_t waves = (int64_t)e->n * nchunk;
         dim3 grid((unsigned)((waves + 3) / 4)), block(256);
         switch (e->vec) {
-        case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->sino_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-        case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->sino_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-        default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->sino_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+        case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+        case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+        default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
         }
         LAUNCHCHK();
     }
@@ -337,7 +345,7 @@ static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out)
     e->halo_lo = e->halo_lo_own; e->halo_hi = e->halo_hi_own;
     float *tmp;
     if ((rc = get_vol(e, TOMO_VOL_RECON, &tmp))) return rc;
-    if ((rc = get_sino(e, &e->sino_b, &tmp))) return rc;
+    if ((rc = get_sino(e, &e->sino[TOMO_SINO_B], &tmp))) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
     *out = e;
     return TOMO_OK;
@@ -424,11 +432,11 @@ int tomo_destroy(tomo_engine *e)
     if (!e) return TOMO_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->sino_b, e->sino_g,
-                    e->sino_r, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < TOMO_VOL_COUNT; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
+    for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
+    for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) (void)hipFree(e->sino[i]);
     for (auto &p : e->prof) for (auto ev : p.ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -483,20 +491,22 @@ static int download(tomo_engine *e, const float *src, float *host, int64_t m)
     return TOMO_OK;
 }
 
-int tomo_set_tilt_series(tomo_engine *e, const float *b)
+int tomo_set_sinogram(tomo_engine *e, int which, const float *b)
 {
     NEED(e);
-    if (!b) return fail(TOMO_ERR_ARG, "null tilt series");
-    return upload(e, b, e->sino_b, e->nrows);
+    if (!b) return fail(TOMO_ERR_ARG, "null sinogram");
+    float *dst; int rc = sino_slot(e, which, &dst); if (rc) return rc;
+    return upload(e, b, dst, e->nrows);
 }
+
+int tomo_set_tilt_series(tomo_engine *e, const float *b) { return tomo_set_sinogram(e, TOMO_SINO_B, b); }
 
 int tomo_get_sinogram(tomo_engine *e, int which, float *out)
 {
     NEED(e);
     if (!out) return fail(TOMO_ERR_ARG, "null output");
     float *src;
-    int rc = which == TOMO_SINO_B ? get_sino(e, &e->sino_b, &src) : which == TOMO_SINO_G ? get_sino(e, &e->sino_g, &src)
-                                                                                          : fail(TOMO_ERR_ARG, "bad sinogram id");
+    int rc = sino_slot(e, which, &src);
     if (rc) return rc;
     return download(e, src, out, e->nrows);
 }
@@ -567,7 +577,7 @@ int tomo_forward_projection(tomo_engine *e, int vol, int sino)
     NEED(e);
     float *x, *g; int rc;
     if ((rc = get_vol(e, vol, &x))) return rc;
-    if ((rc = sino == TOMO_SINO_B ? get_sino(e, &e->sino_b, &g) : get_sino(e, &e->sino_g, &g))) return rc;
+    if ((rc = sino_slot(e, sino, &g))) return rc;
     return launch_fp<FP_STORE>(e, x, 0, (int)e->nrows, nullptr, g, e->fp_all_lpr);
 }
 
@@ -576,7 +586,7 @@ int tomo_back_projection(tomo_engine *e, int sino, int vol)
     NEED(e);
     float *x, *g; int rc;
     if ((rc = get_vol(e, vol, &x))) return rc;
-    if ((rc = sino == TOMO_SINO_B ? get_sino(e, &e->sino_b, &g) : get_sino(e, &e->sino_g, &g))) return rc;
+    if ((rc = sino_slot(e, sino, &g))) return rc;
     return launch_bp_all(e, x, g, nullptr, 0.f, 1.f, 0);
 }
 
@@ -588,21 +598,23 @@ int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter)
 {
     NEED(e);
     float *x, *r; int rc;
-    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, e->sino_b, r, e->fp_all_lpr))) return rc;
+        if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, e->sino[TOMO_SINO_B], r, e->fp_all_lpr))) return rc;
         if ((rc = launch_bp_all(e, x, r, nullptr, 1.f, beta, 1))) return rc;
     }
     return TOMO_OK;
 }
 
-int tomo_sirt(tomo_engine *e, int vol, int niter)
+int tomo_sirt(tomo_engine *e, int vol, int niter) { return tomo_sirt_data(e, vol, TOMO_SINO_B, niter); }
+
+int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter)
 {
     NEED(e);
-    float *x, *r; int rc;
-    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
+    float *x, *r, *b; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, sino_b, &b))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if ((rc = launch_fp<FP_RESID_NORM>(e, x, 0, (int)e->nrows, e->sino_b, r, e->fp_all_lpr))) return rc;
+        if ((rc = launch_fp<FP_RESID_NORM>(e, x, 0, (int)e->nrows, b, r, e->fp_all_lpr))) return rc;
         if ((rc = launch_bp_all(e, x, r, e->d_colsum_all, 1.f, 1.f, 1))) return rc;
     }
     return TOMO_OK;
@@ -610,9 +622,14 @@ int tomo_sirt(tomo_engine *e, int vol, int niter)
 
 int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *order)
 {
+    return tomo_sart_data(e, vol, TOMO_SINO_B, beta, niter, order);
+}
+
+int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order)
+{
     NEED(e);
     float *x, *r; int rc;
-    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_r, &r))) return rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, sino_b, &e->cur_b))) return rc;
     if (order) {
         std::vector<char> seen(e->np, 0);
         for (int q = 0; q < e->np; ++q) {
@@ -628,14 +645,7 @@ int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *ord
             int i = angle_at(k);
             {
                 ProfScope ps(e, TOMO_K_FP_ANGLE);
-                if (e->fp_variant && e->vec == 4) {
-                    int nchunk = e->sxc / 256;
-                    dim3 grid((unsigned)((int64_t)e->n * nchunk / 4)), block(256);
-                    if (e->fp_variant == 3 && e->sxc % 512 == 0) { grid = dim3((unsigned)((int64_t)e->n * (e->sxc / 512) / 4)); hipLaunchKernelGGL((k_fp_rows_w1x2<8>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowsum, r, i * e->n, e->n, e->sx); }
-                    else if (e->fp_variant == 1) hipLaunchKernelGGL((k_fp_rows_w1<4, 8>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowsum, r, i * e->n, e->n, e->sx);
-                    else hipLaunchKernelGGL((k_fp_rows_w1<4, 16>), grid, block, 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowsum, r, i * e->n, e->n, e->sx);
-                    LAUNCHCHK();
-                } else if ((rc = launch_fp<FP_RESID_NORM>(e, x, i * e->n, e->n, e->sino_b, r))) return rc;
+                if ((rc = launch_fp<FP_RESID_NORM>(e, x, i * e->n, e->n, e->cur_b, r))) return rc;
             }
             if ((rc = launch_bp_angle(e, x, i, r + (size_t)i * e->n * e->sx, beta))) return rc;
         }
@@ -651,13 +661,13 @@ int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *ord
         if ((rc = launch_sart_seg<false>(e, cur, nullptr, 0, angle_at(0), r, beta))) return rc;
     } else {
         ProfScope ps(e, TOMO_K_FP_ANGLE);
-        if ((rc = launch_fp<FP_RESID_NORM>(e, cur, angle_at(0) * e->n, e->n, e->sino_b, r))) return rc;
+        if ((rc = launch_fp<FP_RESID_NORM>(e, cur, angle_at(0) * e->n, e->n, e->cur_b, r))) return rc;
     }
     for (int64_t k = 1; k < steps; ++k) {
         int prev = angle_at(k - 1), next = angle_at(k);
         if (prev == next) {   // single-angle geometry: the residual rows read and written would be the same
             if ((rc = launch_bp_angle(e, cur, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc;
-            if ((rc = launch_fp<FP_RESID_NORM>(e, cur, next * e->n, e->n, e->sino_b, r))) return rc;
+            if ((rc = launch_fp<FP_RESID_NORM>(e, cur, next * e->n, e->n, e->cur_b, r))) return rc;
             continue;
         }
         if (seg) rc = launch_sart_seg<true>(e, cur, alt, prev, next, r, beta);
@@ -675,20 +685,125 @@ int tomo_art(tomo_engine *e, float beta)
 {
     NEED(e);
     float *x = e->vol[TOMO_VOL_RECON];
-    hipLaunchKernelGGL(k_art, dim3(e->sx / 64), dim3(64), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino_b, e->d_rowinner, beta, (int)e->nrows, e->sx);
+    hipLaunchKernelGGL(k_art, dim3(e->sx / 64), dim3(64), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino[TOMO_SINO_B], e->d_rowinner, beta, (int)e->nrows, e->sx);
     LAUNCHCHK();
     return tomo_positivity(e, TOMO_VOL_RECON);
 }
 
 int tomo_poisson_ml(tomo_engine *e, float lambda)
 {
+    int rc;
+    if ((rc = tomo_poisson_residual(e, TOMO_VOL_RECON, TOMO_SINO_B, TOMO_SINO_R))) return rc;
+    return launch_bp_all(e, e->vol[TOMO_VOL_RECON], e->sino[TOMO_SINO_R], nullptr, 1.f, -(lambda / e->lipschitz), 1);
+}
+
+int tomo_poisson_residual(tomo_engine *e, int vol, int sino_b, int sino_out)
+{
     NEED(e);
-    float *x = e->vol[TOMO_VOL_RECON], *r; int rc;
-    if ((rc = get_sino(e, &e->sino_r, &r))) return rc;
+    float *x, *b, *r; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = sino_slot(e, sino_b, &b)) || (rc = sino_slot(e, sino_out, &r))) return rc;
     if ((rc = reduce_begin(e))) return rc;
-    if ((rc = launch_fp<FP_POISSON>(e, x, 0, (int)e->nrows, e->sino_b, r, e->fp_all_lpr))) return rc;
-    if ((rc = reduce_end(e, TOMO_S_COST))) return rc;
-    return launch_bp_all(e, x, r, nullptr, 1.f, -(lambda / e->lipschitz), 1);
+    if ((rc = launch_fp<FP_POISSON>(e, x, 0, (int)e->nrows, b, r, e->fp_all_lpr))) return rc;
+    return reduce_end(e, TOMO_S_COST);
+}
+
+int tomo_scale_volume(tomo_engine *e, int vol, float factor)
+{
+    NEED(e);
+    float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
+    int64_t n4 = e->vol_elems() / 4;
+    hipLaunchKernelGGL(k_scale, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, factor, n4);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_sino_diff_norm_sq(tomo_engine *e, int a, int b, int slot)
+{
+    NEED(e);
+    if (slot < 0 || slot >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
+    float *pa, *pb; int rc;
+    if ((rc = sino_slot(e, a, &pa)) || (rc = sino_slot(e, b, &pb))) return rc;
+    if ((rc = reduce_begin(e))) return rc;
+    int64_t n4 = e->sino_elems() / 4;
+    hipLaunchKernelGGL(k_sqdiff, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const f4 *)pa, (const f4 *)pb, e->d_part, n4);
+    LAUNCHCHK();
+    return reduce_end(e, slot);
+}
+
+// per-projection maximum over (slices, rays): multimodal::rescale_projections (multimodal.cpp:323-327)
+int tomo_sino_proj_max(tomo_engine *e, int sino, float *out_host)
+{
+    NEED(e);
+    float *g; int rc; if ((rc = sino_slot(e, sino, &g))) return rc;
+    if (!out_host) return fail(TOMO_ERR_ARG, "null output");
+    if ((rc = ensure_stage(e, e->np * sizeof(float)))) return rc;
+    hipLaunchKernelGGL(k_proj_max, dim3(e->np), dim3(256), 0, e->stream, g, e->stage, e->n, e->nx, e->sx);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(out_host, e->stage, e->np * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+int tomo_sino_proj_scale(tomo_engine *e, int sino, const float *div_host, const float *mul_host)
+{
+    NEED(e);
+    float *g; int rc; if ((rc = sino_slot(e, sino, &g))) return rc;
+    if (!div_host || !mul_host) return fail(TOMO_ERR_ARG, "null factors");
+    if ((rc = ensure_stage(e, 2 * e->np * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpyAsync(e->stage, div_host, e->np * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->stage + e->np, mul_host, e->np * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_proj_scale, dim3(e->np), dim3(256), 0, e->stream, g, e->stage, e->n, e->sx);
+    LAUNCHCHK();
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+int tomo_get_stream(tomo_engine *e, void **out) { if (!e || !out) return fail(TOMO_ERR_ARG, "null"); *out = (void *)e->stream; return TOMO_OK; }
+
+// ---- multimodal (ChemicalTomo) element-wise steps: two engines of equal slab size on one device/stream ----
+static int mm_check(tomo_engine *a, tomo_engine *b, int nel)
+{
+    if (!a || !b) return fail(TOMO_ERR_ARG, "null engine");
+    if (a->nx != b->nx || a->n != b->n || a->sx != b->sx || a->device != b->device) return fail(TOMO_ERR_ARG, "engines differ in slab shape or device");
+    if (a->stream != b->stream) return fail(TOMO_ERR_STATE, "engines must share one stream (tomo_set_stream)");
+    if (nel < 1 || nel > MM_MAX_EL) return fail(TOMO_ERR_ARG, "element count out of range");
+    return TOMO_OK;
+}
+
+// model = Sigma * x^gamma = sum_e w_e x_e^gamma      multimodal.cpp:425-427 (fuse), :459-460
+int tomo_mm_model(tomo_engine *ce, const int32_t *xvols, int nel, const float *w, float gamma, tomo_engine *he, int model_vol)
+{
+    int rc = mm_check(ce, he, nel); if (rc) return rc;
+    HIPCHK(hipSetDevice(ce->device));
+    MMArgs a{};
+    a.nel = nel; a.gamma = gamma;
+    for (int i = 0; i < nel; ++i) { float *p; if ((rc = get_vol(ce, xvols[i], &p))) return rc; a.x[i] = p; a.w[i] = w[i]; }
+    float *m; if ((rc = get_vol(he, model_vol, &m))) return rc;
+    int64_t n4 = ce->vol_elems() / 4;
+    hipLaunchKernelGGL(k_mm_model, dim3(grid_1d(n4)), dim3(256), 0, ce->stream, a, (f4 *)m, n4);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+// x_e <- max(0, x_e - (lamC_over_L * uC_e - lamH * gamma x_e^(gamma-1) w_e (upd - model)))   multimodal.cpp:435-438,471
+int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, int nel, const float *w, float gamma,
+                   float lamC_over_L, float lamH, tomo_engine *he, int upd_vol, int model_vol)
+{
+    int rc = mm_check(ce, he, nel); if (rc) return rc;
+    HIPCHK(hipSetDevice(ce->device));
+    MMArgs a{};
+    a.nel = nel; a.gamma = gamma;
+    for (int i = 0; i < nel; ++i) {
+        float *p, *u;
+        if ((rc = get_vol(ce, xvols[i], &p)) || (rc = get_vol(ce, uvols[i], &u))) return rc;
+        a.x[i] = p; a.u[i] = u; a.w[i] = w[i];
+    }
+    float *upd = nullptr, *m = nullptr;
+    if (lamH != 0.f) { if ((rc = get_vol(he, upd_vol, &upd)) || (rc = get_vol(he, model_vol, &m))) return rc; }
+    int64_t n4 = ce->vol_elems() / 4;
+    hipLaunchKernelGGL(k_mm_update, dim3(grid_1d(n4)), dim3(256), 0, ce->stream, a, (const f4 *)upd, (const f4 *)m, lamC_over_L, lamH, n4);
+    LAUNCHCHK();
+    return TOMO_OK;
 }
 
 int tomo_positivity(tomo_engine *e, int vol)
@@ -727,9 +842,9 @@ int tomo_data_distance_sq(tomo_engine *e, int vol)
 {
     NEED(e);
     float *x, *g; int rc;
-    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino_g, &g))) return rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
-    if ((rc = launch_fp<FP_DD>(e, x, 0, (int)e->nrows, e->sino_b, g, e->fp_all_lpr))) return rc;
+    if ((rc = launch_fp<FP_DD>(e, x, 0, (int)e->nrows, e->sino[TOMO_SINO_B], g, e->fp_all_lpr))) return rc;
     return reduce_end(e, TOMO_S_DD);
 }
 
@@ -868,10 +983,14 @@ int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp)
     return TOMO_OK;
 }
 
-int tomo_fgp_begin(tomo_engine *e)
+int tomo_fgp_begin(tomo_engine *e) { return tomo_fgp_begin_vol(e, TOMO_VOL_RECON); }
+
+int tomo_fgp_begin_vol(tomo_engine *e, int vol)
 {
     NEED(e);
     float *d, *p; int rc;
+    if ((rc = get_vol(e, vol, &d))) return rc;
+    e->fgp_target = vol;
     if ((rc = get_scratch(e, &e->tvg, &d))) return rc;
     HIPCHK(hipMemsetAsync(d, 0, e->vol_elems() * sizeof(float), e->stream));
     for (int i = 0; i < 3; ++i) {
@@ -886,7 +1005,7 @@ int tomo_fgp_obj(tomo_engine *e, float lambda)
     NEED(e);
     if (!e->tvg || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_begin has not been called");
     ProfScope ps(e, TOMO_K_FGP_OBJ);
-    hipLaunchKernelGGL(k_fgp_obj, dim3(tv_grid(e)), dim3(256), 0, e->stream, e->vol[TOMO_VOL_RECON], e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->halo_lo, e->is_first, lambda, e->n, e->nx, e->sx);
+    hipLaunchKernelGGL(k_fgp_obj, dim3(tv_grid(e)), dim3(256), 0, e->stream, e->vol[e->fgp_target], e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->halo_lo, e->is_first, lambda, e->n, e->nx, e->sx);
     LAUNCHCHK();
     return TOMO_OK;
 }
@@ -907,7 +1026,7 @@ int tomo_fgp_end(tomo_engine *e, int iters)
     NEED(e);
     if (!e->tvg) return fail(TOMO_ERR_STATE, "tomo_fgp_begin has not been called");
     (void)iters;  // D is the zero-filled buffer when no iteration ran, exactly like d_update (tv_fgp.cu:223,272)
-    HIPCHK(hipMemcpyAsync(e->vol[TOMO_VOL_RECON], e->tvg, e->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->vol[e->fgp_target], e->tvg, e->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     return TOMO_OK;
 }
 
@@ -931,11 +1050,13 @@ int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps)
     return TOMO_OK;
 }
 
-int tomo_tv_fgp(tomo_engine *e, int iters, float lambda)
+int tomo_tv_fgp(tomo_engine *e, int iters, float lambda) { return tomo_tv_fgp_vol(e, TOMO_VOL_RECON, iters, lambda); }
+
+int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
 {
     int rc;
-    if ((rc = tomo_tv(e, TOMO_VOL_RECON, 1e-6f))) return rc;    // tv_fgp.cu:170-189,231-238
-    if ((rc = tomo_fgp_begin(e))) return rc;
+    if ((rc = tomo_tv(e, vol, 1e-6f))) return rc;    // tv_fgp.cu:170-189,231-238
+    if ((rc = tomo_fgp_begin_vol(e, vol))) return rc;
     int f = e->is_first, l = e->is_last;
     e->is_first = e->is_last = 1;
     for (int i = 0; i < iters; ++i) {
@@ -952,7 +1073,6 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value < 0 || value > 2 ? 2 : value; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value ? 1 : 0; return TOMO_OK; }
-    if (std::strcmp(name, "fp_variant") == 0) { e->fp_variant = value; return TOMO_OK; }
     if (std::strcmp(name, "sart_unroll") == 0) { e->sart_unroll = value == 4 ? 4 : 8; return TOMO_OK; }
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
