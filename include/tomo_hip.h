@@ -102,6 +102,11 @@ int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter);
  * (sequential)  tomoengine.cpp:151-179 */
 int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *order);
 int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order); /* multimodal.cpp:377-396 */
+/* tomoengine::CGLS(nIter): CGLS restarted from the current volume, per slice, then positivity  tomoengine.cpp:207-229 */
+int tomo_cgls(tomo_engine *e, int vol, int niter);
+/* tomoengine::FBP(apply_positivity): recon = scale * A^T (taps * b), taps[0..Nray-1] = symmetric real-space filter
+ * (built by the host for the named filter, pytvlib.py:33-36)  tomoengine.cpp:317-347 */
+int tomo_fbp(tomo_engine *e, const float *taps_host, float scale, int apply_positivity);
 /* ctvlib::ART(beta): row-action Kaczmarz sweep + positivity  ctvlib.cpp:137-155 */
 int tomo_art(tomo_engine *e, float beta);
 /* tomoengine::poisson_ML(lambda): cost accumulates in TOMO_S_COST  tomoengine.cpp:231-246, 293-315 */

@@ -71,6 +71,8 @@ SIGNATURES = {
     "tomo_tv_fgp": [_p, _i, _f],
     "tomo_set_option": [_p, ctypes.c_char_p, _i],
     "tomo_set_sinogram": [_p, _i, _p],
+    "tomo_cgls": [_p, _i, _i],
+    "tomo_fbp": [_p, _p, _f, _i],
     "tomo_sirt_data": [_p, _i, _i, _i],
     "tomo_sart_data": [_p, _i, _i, _f, _i, _p],
     "tomo_poisson_residual": [_p, _i, _i, _i],

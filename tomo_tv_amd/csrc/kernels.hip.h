@@ -799,6 +799,69 @@ __global__ __launch_bounds__(256) void k_mm_update(MMArgs a, const f4 *__restric
     }
 }
 
+// ---- per-slice scalars (CGLS: every slice is its own least-squares problem with its own alpha, beta) -------
+// sums[s] += sum_m v[m][s]^2 over the rows m of this workgroup; lanes = slices, so the loads are coalesced
+__global__ __launch_bounds__(256) void k_slice_sumsq(const float *__restrict__ v, double *__restrict__ sums, int64_t m,
+                                                      int sx, int rows_per_block)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= sx) return;
+    int64_t m0 = (int64_t)blockIdx.y * rows_per_block, m1 = min(m, m0 + rows_per_block);
+    double acc = 0.0;
+    for (int64_t r = m0; r < m1; ++r) { float a = v[r * sx + s]; acc += (double)(a * a); }
+    atomicAdd(&sums[s], acc);
+}
+
+// coef[s] = num[s] / den[s] (0 when den == 0)
+__global__ void k_slice_ratio(const double *__restrict__ num, const double *__restrict__ den, float *__restrict__ coef, int sx)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < sx) coef[s] = den[s] > 0.0 ? (float)(num[s] / den[s]) : 0.f;
+}
+
+// y[m][s] = ay * y[m][s] + sign * coef[s] * x[m][s]      (ay = 1: y += c x ; used with p = z + beta p as y=p, ay->coef)
+__global__ __launch_bounds__(256) void k_slice_axpy(float *__restrict__ y, const float *__restrict__ x,
+                                                     const float *__restrict__ coef, float sign, int64_t n, int sx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int s = (int)(i % sx);
+        y[i] = y[i] + sign * coef[s] * x[i];
+    }
+}
+
+// p[m][s] = z[m][s] + coef[s] * p[m][s]
+__global__ __launch_bounds__(256) void k_slice_xpay(float *__restrict__ p, const float *__restrict__ z,
+                                                     const float *__restrict__ coef, int64_t n, int sx)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int s = (int)(i % sx);
+        p[i] = z[i] + coef[s] * p[i];
+    }
+}
+
+// filtered sinogram for WBP: out[i*N + j][s] = sum_k h[|j - k|] in[i*N + k][s]; one wave = one output ray x 64*VEC slices
+template <int VEC>
+__global__ __launch_bounds__(256) void k_filter_rows(const float *__restrict__ in, float *__restrict__ out,
+                                                      const float *__restrict__ h, int n, int nrows, int sx, int nchunk)
+{
+    typedef typename VecOf<VEC>::T V;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    int chunk = (int)(gw / nrows);
+    if (chunk >= nchunk) return;
+    int row = (int)(gw - (int64_t)chunk * nrows);
+    int i = row / n, j = row - i * n;
+    int off = chunk * (64 * VEC) + lane * VEC;
+    const float *base = in + (size_t)i * n * sx + off;
+    V acc = vzero<VEC>();
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) {
+        int d = j - k;
+        acc += h[d < 0 ? -d : d] * *reinterpret_cast<const V *>(base + (size_t)k * sx);
+    }
+    *reinterpret_cast<V *>(out + (size_t)row * sx + off) = acc;
+}
+
 // ---- 3-D TV stencils ---------------------------------------------------------------------------------
 // Index map to the reference's (i, j, k): i = slice s (periodic over the GLOBAL slice count, neighbours
 // of the slab's end slices come from halo planes), j = y, k = z (periodic over N).

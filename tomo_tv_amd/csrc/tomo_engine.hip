@@ -62,7 +62,10 @@ struct tomo_engine {
     float *vol[TOMO_VOL_SLOTS] = {};
     float *sino[TOMO_SINO_SLOTS] = {};
     int fgp_target = TOMO_VOL_RECON;
-    float *cur_b = nullptr;                      // data sinogram of the SART call in progress
+    float *cur_b = nullptr;
+    float *cg_p = nullptr, *cg_z = nullptr, *cg_w = nullptr, *fbp_h = nullptr;   // CGLS direction / A^T r / A p; WBP kernel
+    double *cg_sums = nullptr;                    // 2*sx per-slice sums
+    float *cg_coef = nullptr;                     // sx per-slice coefficients                      // data sinogram of the SART call in progress
     float *tvg = nullptr;                         // TV gradient tensor; doubles as FGP "D"
     float *fgp_p[3] = {nullptr, nullptr, nullptr};
     float *stage = nullptr;
@@ -432,7 +435,7 @@ int tomo_destroy(tomo_engine *e)
     if (!e) return TOMO_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -705,6 +708,79 @@ int tomo_poisson_residual(tomo_engine *e, int vol, int sino_b, int sino_out)
     if ((rc = reduce_begin(e))) return rc;
     if ((rc = launch_fp<FP_POISSON>(e, x, 0, (int)e->nrows, b, r, e->fp_all_lpr))) return rc;
     return reduce_end(e, TOMO_S_COST);
+}
+
+// ---- CGLS (TomoGPU.cgls; ASTRA CCudaCglsAlgorithm in the reference: tomoengine.cpp:207-229) -------------------------
+// Standard CGLS on min ||A x - b||, restarted from the current volume at every call exactly like the reference
+// (algo_cgls->initialize per call), independently per slice (alpha, beta are per-slice scalars), positivity at the end.
+static int slice_sumsq(tomo_engine *e, const float *v, int64_t m, double *sums)
+{
+    HIPCHK(hipMemsetAsync(sums, 0, e->sx * sizeof(double), e->stream));
+    int rpb = (int)std::max<int64_t>(64, (m + 1023) / 1024);
+    dim3 grid((unsigned)((e->sx + 255) / 256), (unsigned)((m + rpb - 1) / rpb));
+    hipLaunchKernelGGL(k_slice_sumsq, grid, dim3(256), 0, e->stream, v, sums, m, e->sx, rpb);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+int tomo_cgls(tomo_engine *e, int vol, int niter)
+{
+    NEED(e);
+    float *x, *r, *b, *w; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, TOMO_SINO_B, &b))) return rc;
+    if ((rc = get_scratch(e, &e->cg_p, &w)) || (rc = get_scratch(e, &e->cg_z, &w))) return rc;
+    if ((rc = get_sino(e, &e->cg_w, &w))) return rc;
+    if (!e->cg_sums) { if ((rc = dev_alloc((void **)&e->cg_sums, 2 * e->sx * sizeof(double), true, e->stream))) return rc; }
+    if (!e->cg_coef) { if ((rc = dev_alloc((void **)&e->cg_coef, e->sx * sizeof(float), true, e->stream))) return rc; }
+    double *gam = e->cg_sums, *tmp = e->cg_sums + e->sx;
+    const int64_t nv = (int64_t)e->vol_elems(), ns = (int64_t)e->sino_elems();
+    auto ratio = [&](const double *num, const double *den) {
+        hipLaunchKernelGGL(k_slice_ratio, dim3((e->sx + 255) / 256), dim3(256), 0, e->stream, num, den, e->cg_coef, e->sx);
+    };
+    // r = b - A x ; z = A^T r ; p = z ; gamma = |z|^2
+    if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, b, r, e->fp_all_lpr))) return rc;
+    if ((rc = launch_bp_all(e, e->cg_z, r, nullptr, 0.f, 1.f, 0))) return rc;
+    HIPCHK(hipMemcpyAsync(e->cg_p, e->cg_z, nv * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    if ((rc = slice_sumsq(e, e->cg_z, e->npix, gam))) return rc;
+    for (int it = 0; it < niter; ++it) {
+        // w = A p ; alpha = gamma / |w|^2 ; x += alpha p ; r -= alpha w
+        if ((rc = launch_fp<FP_STORE>(e, e->cg_p, 0, (int)e->nrows, nullptr, e->cg_w, e->fp_all_lpr))) return rc;
+        if ((rc = slice_sumsq(e, e->cg_w, e->nrows, tmp))) return rc;
+        ratio(gam, tmp);
+        hipLaunchKernelGGL(k_slice_axpy, dim3(grid_1d(nv / 4)), dim3(256), 0, e->stream, x, e->cg_p, e->cg_coef, 1.f, nv, e->sx);
+        hipLaunchKernelGGL(k_slice_axpy, dim3(grid_1d(ns / 4)), dim3(256), 0, e->stream, r, e->cg_w, e->cg_coef, -1.f, ns, e->sx);
+        // z = A^T r ; beta = |z|^2 / gamma ; gamma = |z|^2 ; p = z + beta p
+        if ((rc = launch_bp_all(e, e->cg_z, r, nullptr, 0.f, 1.f, 0))) return rc;
+        if ((rc = slice_sumsq(e, e->cg_z, e->npix, tmp))) return rc;
+        ratio(tmp, gam);
+        HIPCHK(hipMemcpyAsync(gam, tmp, e->sx * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        hipLaunchKernelGGL(k_slice_xpay, dim3(grid_1d(nv / 4)), dim3(256), 0, e->stream, e->cg_p, e->cg_z, e->cg_coef, nv, e->sx);
+        LAUNCHCHK();
+    }
+    return tomo_positivity(e, vol);
+}
+
+// ---- WBP / FBP (TomoGPU.wbp; ASTRA CCudaFilteredBackProjectionAlgorithm: tomoengine.cpp:317-347) ----------------------
+// recon = scale * A^T (h * b): h = real-space filter taps h[0..N-1] (symmetric), built by the host for the named filter.
+int tomo_fbp(tomo_engine *e, const float *taps_host, float scale, int apply_positivity)
+{
+    NEED(e);
+    if (!taps_host) return fail(TOMO_ERR_ARG, "null filter");
+    float *x, *b, *g; int rc;
+    if ((rc = get_vol(e, TOMO_VOL_RECON, &x)) || (rc = sino_slot(e, TOMO_SINO_B, &b)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &g))) return rc;
+    if (!e->fbp_h) { if ((rc = dev_alloc((void **)&e->fbp_h, e->n * sizeof(float), false, e->stream))) return rc; }
+    HIPCHK(hipMemcpyAsync(e->fbp_h, taps_host, e->n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int nchunk = e->sxc / (64 * e->vec);
+    int64_t waves = e->nrows * nchunk;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (e->vec) {
+    case 4: hipLaunchKernelGGL((k_filter_rows<4>), grid, block, 0, e->stream, b, g, e->fbp_h, e->n, (int)e->nrows, e->sx, nchunk); break;
+    case 2: hipLaunchKernelGGL((k_filter_rows<2>), grid, block, 0, e->stream, b, g, e->fbp_h, e->n, (int)e->nrows, e->sx, nchunk); break;
+    default: hipLaunchKernelGGL((k_filter_rows<1>), grid, block, 0, e->stream, b, g, e->fbp_h, e->n, (int)e->nrows, e->sx, nchunk); break;
+    }
+    LAUNCHCHK();
+    return launch_bp_all(e, x, g, nullptr, 0.f, scale, apply_positivity ? 1 : 0);
 }
 
 int tomo_scale_volume(tomo_engine *e, int vol, float factor)

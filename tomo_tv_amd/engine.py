@@ -397,10 +397,24 @@ class tomoengine(_EngineBase):
         pass
 
     def initialize_CGLS(self):
-        raise NotImplementedError("CGLS is outside this round's hot-path scope (SURVEY.md section 8f rank 1)")
+        pass
+
+    def CGLS(self, nIter=1):
+        """nIter CGLS steps restarted from the current recon, then positivity (tomoengine.cpp:214-229).
+        ASTRA's CGLS is not in the reference tree: this is the textbook CGLS on the parallelRay matrix."""
+        self.be.c("cgls", VOL_RECON, int(nIter))
 
     def initialize_FBP(self, filter_name="ram-lak"):
-        raise NotImplementedError("FBP/WBP is outside this round's hot-path scope (SURVEY.md section 8f rank 2)")
+        from .pytvlib import wbp_filters
+        if filter_name not in wbp_filters():
+            raise ValueError(f"unknown filter {filter_name!r}")
+        self.fbpFilter = filter_name
+
+    def FBP(self, apply_positivity=True):
+        """Weighted (filtered) back-projection: recon = pi/Nproj * A^T (h * b)   (tomoengine.cpp:330-347).
+        ASTRA's filter construction is not in the reference tree; taps come from ``fbp_filter_taps``."""
+        taps = fbp_filter_taps(self.Ny, getattr(self, "fbpFilter", "ram-lak"))
+        self.be.c("fbp", _ptr(taps), float(np.pi / self.Nproj), int(bool(apply_positivity)))
 
     def initialize_poisson_ML(self):
         """tomoengine.cpp:231-246: L = max(A^T A 1); normalise the tilt series by its maximum if > 1."""
@@ -495,6 +509,39 @@ class ctvlib(_EngineBase):
 
     def tv_gd(self, ng, dPOCS):  # void in the reference (ctvlib.cpp:406); the TV value is returned as a courtesy
         return super().tv_gd(ng, dPOCS)
+
+
+def fbp_filter_taps(n, name="ram-lak"):
+    """Real-space taps h[0..n-1] of the symmetric FBP filter |f| * W(f) (names: tomofusion/pytvlib.py:33-36).
+
+    The band-limited ramp is the Kak-Slaney kernel (h[0] = 1/4, h[odd k] = -1/(pi k)^2, h[even] = 0); a window is
+    applied in the frequency domain of a 4n-point periodic extension, f = frequency / Nyquist in [0, 1]."""
+    L = 4 * int(2 ** np.ceil(np.log2(max(n, 2))))
+    k = np.arange(L)
+    k = np.minimum(k, L - k).astype(np.float64)
+    h = np.zeros(L)
+    h[0] = 0.25
+    odd = (k % 2) == 1
+    h[odd] = -1.0 / (np.pi * k[odd]) ** 2
+    H = np.fft.rfft(h).real
+    f = np.arange(H.size) / (H.size - 1.0)
+    c = lambda a: sum(ai * np.cos(i * np.pi * f) for i, ai in enumerate(a))  # noqa: E731
+    windows = {
+        "ram-lak": lambda: np.ones_like(f),
+        "shepp-logan": lambda: np.sinc(f / 2),
+        "cosine": lambda: np.cos(np.pi * f / 2),
+        "hamming": lambda: c([0.54, 0.46]),
+        "lanczos": lambda: np.sinc(f),
+        "triangular": lambda: 1 - f,
+        "gaussian": lambda: np.exp(-0.5 * (f / 0.4) ** 2),
+        "blackman": lambda: c([0.42, 0.5, 0.08]),
+        "nuttall": lambda: c([0.355768, 0.487396, 0.144232, 0.012604]),
+        "blackman-harris": lambda: c([0.35875, 0.48829, 0.14128, 0.01168]),
+        "kaiser": lambda: np.i0(8.6 * np.sqrt(np.clip(1 - f * f, 0, 1))) / np.i0(8.6),
+        "parzen": lambda: np.where(f <= 0.5, 1 - 6 * f ** 2 * (1 - f), 2 * (1 - f) ** 3),
+    }
+    taps = np.fft.irfft(H * windows[name](), L)[:n]
+    return np.ascontiguousarray(taps, dtype=np.float32)
 
 
 def system_matrix(Nside, angles_deg):

@@ -74,6 +74,16 @@ class TomoGPU:
         pytvlib.initialize_algorithm(self.tomo, "SIRT")
         return self._run_iterative("SIRT", Niter, show_convergence)
 
+    def cgls(self, Niter=100, show_convergence=True):
+        pytvlib.initialize_algorithm(self.tomo, "CGLS")
+        return self._run_iterative("CGLS", Niter, show_convergence)
+
+    def wbp(self, filter="ram-lak"):
+        if filter not in pytvlib.wbp_filters():
+            filter = "ram-lak"
+        pytvlib.initialize_algorithm(self.tomo, "FBP", filter)
+        pytvlib.run(self.tomo, "FBP")
+
     def kl_divergence(self, Niter=100, lambda_param=0.1):
         self.tomo.restart_recon()
         pytvlib.initialize_algorithm(self.tomo, "kl-divergence")
