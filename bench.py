@@ -139,7 +139,7 @@ def main():
     for _ in range(args.warmup):
         asd_pocs_step(t, st)
     sync()
-    kernels = {"k_sart_fused": K_SART_FUSED, "k_bp_angle": K_BP_ANGLE, "k_fp_angle": 1}   # k_sart_fused = k_sart_seg<FUSED=true>
+    kernels = {"k_sart_seg<4,8,true>": K_SART_FUSED, "k_bp_angle<4,4>": K_BP_ANGLE, "k_sart_seg<4,8,false>": 1}   # names as rocprofv3 prints them
     for kid in kernels.values():
         _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
     t0 = time.perf_counter()
@@ -162,12 +162,13 @@ def main():
     if rank == 0:
         vox_total = nloc * world * n * n
         # Algorithmic bytes per launch (SURVEY.md section 8d, V = voxels of this GPU's slab, fp32):
-        #   k_bp_angle   single-angle voxel update: slab in + slab out + that angle's residual rows = 8V + 4 Nx N
-        #   k_sart_fused BP(a_k)+FP(a_k+1): slab in + slab out + residual rows in + b rows in + residual rows out
-        #                = 8V + 12 Nx N
+        #   k_bp_angle          single-angle voxel update: slab in + slab out + that angle's residual rows = 8V + 4 Nx N
+        #   k_sart_seg<..true>  BP(a_k)+FP(a_k+1): slab in + slab out + residual rows in + b rows in + residual rows
+        #                       out = 8V + 12 Nx N
+        #   k_sart_seg<..false> plain FP of one angle: slab in + b rows in + residual rows out = 4V + 8 Nx N
         V = float(nloc) * n * n
-        alg_bytes = {"k_bp_angle": 8.0 * V + 4.0 * nloc * n, "k_sart_fused": 8.0 * V + 12.0 * nloc * n,
-                     "k_fp_angle": 4.0 * V + 8.0 * nloc * n}
+        alg_bytes = {"k_bp_angle<4,4>": 8.0 * V + 4.0 * nloc * n, "k_sart_seg<4,8,true>": 8.0 * V + 12.0 * nloc * n,
+                     "k_sart_seg<4,8,false>": 4.0 * V + 8.0 * nloc * n}
         roofs = {}
         for name, (cnt, tot) in prof.items():
             avg_ms = tot / cnt if cnt else 0.0
@@ -178,7 +179,8 @@ def main():
         # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), null if absent
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            match = {"k_sart_fused": "k_sart_seg<4, 8, true>", "k_bp_angle": "k_bp_angle<4, 4>", "k_fp_angle": "k_sart_seg<4, 8, false>"}
+            match = {"k_sart_seg<4,8,true>": "k_sart_seg<4, 8, true>", "k_bp_angle<4,4>": "k_bp_angle<4, 4>",
+                     "k_sart_seg<4,8,false>": "k_sart_seg<4, 8, false>"}
             if (nloc, n, nproj) == (512, 512, 90):
                 for name, key in match.items():
                     hit = [v for k, v in pmc.items() if key in k]
@@ -207,8 +209,8 @@ def main():
                        "slices_per_gpu": nloc, "nray": n, "nproj": nproj, "sharding": f"tilt-axis slabs x{world}"},
             "final_dd": dd, "final_tv": tv,
             "roofline": dominant,
-            "roofline_bp_angle": roofs["k_bp_angle"],
-            "roofline_fp_angle": roofs["k_fp_angle"],
+            "roofline_bp_angle": roofs["k_bp_angle<4,4>"],
+            "roofline_fp_angle": roofs["k_sart_seg<4,8,false>"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, nproj)

@@ -1131,4 +1131,116 @@ __global__ __launch_bounds__(256) void k_fgp_grad(const float *__restrict__ D, f
     }
 }
 
+// ---- fused FGP iteration (single slab): D = max(0, A - lambda div P) is NOT written, only P_new ---------------
+// The reference runs Obj, nonneg, Grad, Proj as four full-volume kernels per iteration (tv_fgp.cu:244-268,
+// ~80 B/voxel); the two-kernel form above moves 48 B/voxel.  Here one kernel per iteration reads A and P (16 B),
+// rebuilds D for the pixel rows y and y+1 in LDS and writes P_new (12 B): 28 B/voxel.  P is ping-ponged because a
+// neighbouring workgroup still needs the old values of this workgroup's border voxels.  Boundaries are the
+// reference's: lower neighbours of the first slice/row/column and upper differences at the last are zero.
+__global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, const float *__restrict__ P1i,
+                                                    const float *__restrict__ P2i, const float *__restrict__ P3i,
+                                                    float *__restrict__ P1o, float *__restrict__ P2o,
+                                                    float *__restrict__ P3o, float lambda, float multip, int n, int nx,
+                                                    int sx, int yseg)
+{
+    __shared__ float pl[3][2][TVL_TZ + 2][TVL_PITCH];     // P1,P2,P3 planes (parity ring); row zi = column z0-1+zi
+    __shared__ float al[TVL_TZ + 2][TVL_PITCH];           // A plane being turned into D
+    __shared__ float dl[2][TVL_TZ + 1][TVL_PITCH];        // D planes: row zi' = column z0+zi', element si' = slice s0+si'
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nzb = (n + TVL_TZ - 1) / TVL_TZ;
+    const int bz = blockIdx.x % nzb, bs = blockIdx.x / nzb;
+    const int y0 = blockIdx.y * yseg, y1 = min(y0 + yseg, n);
+    const int z0 = bz * TVL_TZ, s0 = bs * 64;
+    auto ld = [&](const float *__restrict__ f, int y, int zi, int si) -> float {
+        int z = z0 - 1 + zi, s = s0 - 1 + si;
+        if (y < 0 || y >= n || z < 0 || z >= n || s < 0 || s >= nx) return 0.f;
+        return f[(size_t)(y * n + z) * sx + s];
+    };
+    // a pixel row (A and the three P fields, with halo) travels global -> registers -> LDS; the fetch of row
+    // y+2 is issued a full iteration before it is needed
+    float rg[4][3], rh[4];
+    auto fetch = [&](int y) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int r = wave + 4 * t;
+            bool ok = r < TVL_TZ + 2;
+            rg[0][t] = ok ? ld(P1i, y, r, lane + 1) : 0.f;
+            rg[1][t] = ok ? ld(P2i, y, r, lane + 1) : 0.f;
+            rg[2][t] = ok ? ld(P3i, y, r, lane + 1) : 0.f;
+            rg[3][t] = ok ? ld(A, y, r, lane + 1) : 0.f;
+        }
+        if (wave == 3 && lane < 2 * (TVL_TZ + 2)) {
+            int r = lane >> 1, si = (lane & 1) ? 65 : 0;
+            rh[0] = ld(P1i, y, r, si); rh[1] = ld(P2i, y, r, si); rh[2] = ld(P3i, y, r, si); rh[3] = ld(A, y, r, si);
+        }
+    };
+    auto stash = [&](int par) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int r = wave + 4 * t;
+            if (r < TVL_TZ + 2) {
+                pl[0][par][r][lane + 1] = rg[0][t]; pl[1][par][r][lane + 1] = rg[1][t];
+                pl[2][par][r][lane + 1] = rg[2][t]; al[r][lane + 1] = rg[3][t];
+            }
+        }
+        if (wave == 3 && lane < 2 * (TVL_TZ + 2)) {
+            int r = lane >> 1, si = (lane & 1) ? 65 : 0;
+            pl[0][par][r][si] = rh[0]; pl[1][par][r][si] = rh[1]; pl[2][par][r][si] = rh[2]; al[r][si] = rh[3];
+        }
+    };
+    // D of the row staged in slot `par` (its -y neighbour row of P2 is in slot par^1)
+    auto compute_d = [&](int y, int par) {
+        for (int e = threadIdx.x; e < (TVL_TZ + 1) * 65; e += 256) {
+            int zq = e / 65, sq = e - zq * 65;
+            int zi = zq + 1, si = sq + 1;
+            float v1 = pl[0][par][zi][si - 1];                       // P1(s-1): zero-loaded below slice 0
+            float v2 = y > 0 ? pl[1][par ^ 1][zi][si] : 0.f;         // P2(y-1)
+            float v3 = pl[2][par][zi - 1][si];                       // P3(z-1): zero-loaded left of column 0
+            float d = al[zi][si] - lambda * (pl[0][par][zi][si] + pl[1][par][zi][si] + pl[2][par][zi][si] - v1 - v2 - v3);
+            dl[par][zq][sq] = fmaxf(d, 0.f);
+        }
+    };
+    fetch(y0 - 1); stash((y0 + 1) & 1);        // only P2(y0-1) is used
+    __syncthreads();
+    fetch(y0); stash(y0 & 1);
+    fetch(y0 + 1);
+    __syncthreads();
+    compute_d(y0, y0 & 1);
+    __syncthreads();
+    for (int y = y0; y < y1; ++y) {
+        int par = y & 1, nxt = par ^ 1;
+        float keep[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                                // old P of this thread's outputs
+            int zi = 1 + wave * 2 + q, si = lane + 1;
+            keep[q][0] = pl[0][par][zi][si]; keep[q][1] = pl[1][par][zi][si]; keep[q][2] = pl[2][par][zi][si];
+        }
+        stash(nxt);                                                  // row y+1 replaces row y-1 (and A of row y)
+        if (y + 1 < y1) fetch(y + 2);
+        __syncthreads();
+        compute_d(y + 1, nxt);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int zq = wave * 2 + q, sq = lane;
+            int z = z0 + zq, s = s0 + sq;
+            if (z < n && s < nx) {
+                float dc = dl[par][zq][sq];
+                float v1 = s + 1 < nx ? dc - dl[par][zq][sq + 1] : 0.f;
+                float v2 = y + 1 < n ? dc - dl[nxt][zq][sq] : 0.f;
+                float v3 = z + 1 < n ? dc - dl[par][zq + 1][sq] : 0.f;
+                float a = keep[q][0] + multip * v1, b = keep[q][1] + multip * v2, c = keep[q][2] + multip * v3;
+                float denom = a * a + b * b + c * c;
+                if (denom > 1.0f) {
+                    float sq_ = 1.0f / sqrtf(denom);
+                    a *= sq_; b *= sq_; c *= sq_;
+                }
+                size_t o = (size_t)(y * n + z) * sx + s;
+                P1o[o] = a; P2o[o] = b; P3o[o] = c;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace tomo

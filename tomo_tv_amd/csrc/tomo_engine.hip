@@ -68,6 +68,8 @@ struct tomo_engine {
     float *cg_coef = nullptr;                     // sx per-slice coefficients                      // data sinogram of the SART call in progress
     float *tvg = nullptr;                         // TV gradient tensor; doubles as FGP "D"
     float *fgp_p[3] = {nullptr, nullptr, nullptr};
+    float *fgp_q[3] = {nullptr, nullptr, nullptr};   // ping-pong partners for the fused FGP iteration
+    int fgp_fused = 1;
     float *stage = nullptr;
     size_t stage_bytes = 0;
     // scalars
@@ -435,7 +437,7 @@ int tomo_destroy(tomo_engine *e)
     if (!e) return TOMO_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -1135,8 +1137,28 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
     if ((rc = tomo_fgp_begin_vol(e, vol))) return rc;
     int f = e->is_first, l = e->is_last;
     e->is_first = e->is_last = 1;
-    for (int i = 0; i < iters; ++i) {
-        if ((rc = tomo_fgp_obj(e, lambda)) || (rc = tomo_fgp_grad(e, lambda))) break;
+    if (e->fgp_fused && iters > 1) {
+        // iterations 0..iters-2: one fused kernel each (D stays on chip); the last iteration only needs D (tv_fgp.cu:272)
+        float *q;
+        for (int i = 0; i < 3 && !rc; ++i) rc = get_scratch(e, &e->fgp_q[i], &q);
+        int yseg = 32;
+        int nzb = (e->n + TVL_TZ - 1) / TVL_TZ;
+        dim3 grid((unsigned)(nzb * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+        float multip = 1.0f / (26.0f * lambda);
+        for (int i = 0; i + 1 < iters && !rc; ++i) {
+            {
+                ProfScope ps(e, TOMO_K_FGP_GRAD);
+                hipLaunchKernelGGL(k_fgp_fused, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                                   e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg);
+            }
+            if (hipGetLastError() != hipSuccess) rc = fail(TOMO_ERR_HIP, "k_fgp_fused launch failed");
+            for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
+        }
+        if (!rc) rc = tomo_fgp_obj(e, lambda);
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            if ((rc = tomo_fgp_obj(e, lambda)) || (rc = tomo_fgp_grad(e, lambda))) break;
+        }
     }
     e->is_first = f; e->is_last = l;
     if (rc) return rc;
@@ -1146,6 +1168,7 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
 int tomo_set_option(tomo_engine *e, const char *name, int value)
 {
     if (!e || !name) return fail(TOMO_ERR_ARG, "null argument");
+    if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value < 0 || value > 2 ? 2 : value; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value ? 1 : 0; return TOMO_OK; }
