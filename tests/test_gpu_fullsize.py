@@ -1,0 +1,89 @@
+"""Size-independent properties at the BASELINE.json shapes (the oracle is far too slow there).
+
+config 2: 256^3, 60 tilts (SART)      config 3: 512^3, 90 tilts (FISTA / the SART+TV headline)
+Properties: adjointness <Ax, y> = <x, A^T y>; linearity of the projector; fused SART == FP+BP SART; a volume
+reconstructed as two half-slabs by two engines == one engine (what tilt-axis sharding relies on); the volume the
+engine holds is what was uploaded; non-negativity and monotone data distance of SART.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from tomo_tv_amd._lib import SINO_B, SINO_G, VOL_ORIGINAL, VOL_RECON, VOL_TEMP
+from tomo_tv_amd.engine import tomoengine
+from tomo_tv_amd.phantom import ellipsoids, tilt_angles
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[(256, 256, 60), (512, 512, 90)], ids=["config2_256x60", "config3_512x90"])
+def big(request, gpu):
+    nx, n, p = request.param
+    ang = np.deg2rad(tilt_angles(p))
+    x = ellipsoids(nx, n)
+    t = tomoengine(nx, n, ang)
+    t.set_volume(x, VOL_ORIGINAL)
+    t.create_projections()
+    return t, x, (nx, n, p), ang
+
+
+def test_roundtrip_and_adjointness(big):
+    t, x, (nx, n, p), ang = big
+    assert np.array_equal(t.get_volume(VOL_ORIGINAL), x)
+    b = t.get_projections()
+    assert b.shape == (nx, n * p) and np.isfinite(b).all() and b.min() >= 0
+    rng = np.random.default_rng(0)
+    y = rng.random(b.shape, dtype=np.float32)
+    t.be.c("set_sinogram", SINO_G, y.ctypes.data)
+    t.be.c("back_projection", SINO_G, VOL_TEMP)
+    aty = t.get_volume(VOL_TEMP)
+    lhs = float(np.vdot(b.astype(np.float64), y.astype(np.float64)))
+    rhs = float(np.vdot(x.astype(np.float64), aty.astype(np.float64)))
+    assert abs(lhs - rhs) <= 2e-6 * abs(lhs), (lhs, rhs)
+
+
+def test_projector_linearity(big):
+    t, x, (nx, n, p), ang = big
+    b = t.get_projections()
+    z = np.roll(x, 7, axis=1) * np.float32(0.5)
+    t.set_volume(z, VOL_RECON)
+    t.forward_projection()
+    bz = t.get_model_projections()
+    t.set_volume((2 * x + z).astype(np.float32), VOL_RECON)
+    t.forward_projection()
+    assert rel_l2(t.get_model_projections(), 2 * b.astype(np.float64) + bz) < 1e-6
+
+
+def test_sart_fused_equals_unfused_and_converges(big):
+    t, x, (nx, n, p), ang = big
+    vols = []
+    for fused in (2, 0):
+        t.set_option("sart_fused", fused)
+        t.restart_recon()
+        t.SART(0.5, 1)
+        vols.append(t.get_volume())
+    t.set_option("sart_fused", 2)
+    assert rel_l2(vols[0], vols[1]) < 2e-6
+    assert vols[0].min() >= 0
+    dd0 = t.data_distance()
+    t.SART(0.5, 1)
+    dd1 = t.data_distance()
+    assert dd1 < dd0 < np.linalg.norm(t.get_projections())
+
+
+def test_two_half_slabs_equal_one_slab(big):
+    """Every slice shares one system matrix, so slab sharding must not change a single voxel."""
+    t, x, (nx, n, p), ang = big
+    b = t.get_projections()
+    t.restart_recon()
+    t.SART(0.7, 1)
+    whole = t.get_volume()
+    half = nx // 2
+    parts = []
+    for s0 in (0, half):
+        e = tomoengine(half, n, ang)
+        e.set_tilt_series(b[s0:s0 + half])
+        e.SART(0.7, 1)
+        parts.append(e.get_volume())
+        del e
+    assert rel_l2(np.concatenate(parts), whole) < 2e-6

@@ -966,7 +966,7 @@ __global__ __launch_bounds__(256) void k_tv_grad(const float *__restrict__ x, Ha
 //    correctly-rounded reciprocal R = 1/D is shared through LDS, and the gradient is
 //    g = (3c - x_ip - x_jp - x_kp) R(p) + (c - x_im) R(p-i) + (c - x_jm) R(p-j) + (c - x_km) R(p-k).
 //    (v * (1/D) instead of v / D: at most one ulp per term away from the reference's expression.)
-constexpr int TVL_TZ = 8;          // z-columns per workgroup (2 per wave)
+constexpr int TVL_TZ = 8;          // z-columns per workgroup of the FGP kernel (2 per wave)
 constexpr int TVL_PITCH = 66;      // 64 slices + halo each side
 
 __device__ __forceinline__ float tv_ld(const float *__restrict__ x, const Halo &h, int pix, int s, int nx, int sx)
@@ -976,43 +976,49 @@ __device__ __forceinline__ float tv_ld(const float *__restrict__ x, const Halo &
     return x[(size_t)pix * sx + s];
 }
 
+template <int TZ>
 __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x, Halo h, float *__restrict__ g,
                                                       double *__restrict__ part, float eps, int n, int nx, int sx,
                                                       int yseg)
 {
-    __shared__ float ring[4][TVL_TZ + 2][TVL_PITCH];      // x planes; row zi = column z0-1+zi, element si = slice s0-1+si
-    __shared__ float rinv[2][TVL_TZ + 1][TVL_PITCH];      // R planes; rows zi = 0..TZ, elements si = 0..64
+    __shared__ float ring[4][TZ + 2][TVL_PITCH];      // x planes; row zi = column z0-1+zi, element si = slice s0-1+si
+    __shared__ float rinv[2][TZ + 1][TVL_PITCH];      // R planes; rows zi = 0..TZ, elements si = 0..64
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nzb = (n + TVL_TZ - 1) / TVL_TZ;
+    const int nzb = (n + TZ - 1) / TZ;
     int bz = blockIdx.x % nzb;
     int bs = blockIdx.x / nzb;                 // slice chunk
     int y0 = blockIdx.y * yseg;
     int y1 = min(y0 + yseg, n);
-    int z0 = bz * TVL_TZ, s0 = bs * 64;
+    int z0 = bz * TZ, s0 = bs * 64;
     auto zcol = [&](int zi) { int z = z0 - 1 + zi; return z < 0 ? z + n : (z >= n ? z - n : z); };
     auto yrow = [&](int y) { return y < 0 ? y + n : (y >= n ? y - n : y); };
-    float v0, v1, v2, vh;
-    auto fetch = [&](int y) {                  // rows (wave, wave+4, wave+8) x column lane+1, + halo columns
+    constexpr int NR = (TZ + 2 + 3) / 4;       // plane rows per wave
+    float v[NR], vh;
+    auto fetch = [&](int y) {                  // rows (wave, wave+4, ...) x column lane+1, + halo columns
         int yy = yrow(y);
         int s = s0 + lane;
-        v0 = tv_ld(x, h, yy * n + zcol(wave), s, nx, sx);
-        v1 = tv_ld(x, h, yy * n + zcol(wave + 4), s, nx, sx);
-        v2 = (wave + 8 < TVL_TZ + 2) ? tv_ld(x, h, yy * n + zcol(wave + 8), s, nx, sx) : 0.f;
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            int r = wave + 4 * t;
+            v[t] = r < TZ + 2 ? tv_ld(x, h, yy * n + zcol(r), s, nx, sx) : 0.f;
+        }
         vh = 0.f;
-        if (wave == 3 && lane < 2 * (TVL_TZ + 2)) {
+        if (wave == 3 && lane < 2 * (TZ + 2)) {
             int zi = lane >> 1, side = lane & 1;
             vh = tv_ld(x, h, yy * n + zcol(zi), side ? s0 + 64 : s0 - 1, nx, sx);
         }
     };
     auto stash = [&](int slot) {
-        ring[slot][wave][lane + 1] = v0;
-        ring[slot][wave + 4][lane + 1] = v1;
-        if (wave + 8 < TVL_TZ + 2) ring[slot][wave + 8][lane + 1] = v2;
-        if (wave == 3 && lane < 2 * (TVL_TZ + 2)) ring[slot][lane >> 1][(lane & 1) ? 65 : 0] = vh;
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            int r = wave + 4 * t;
+            if (r < TZ + 2) ring[slot][r][lane + 1] = v[t];
+        }
+        if (wave == 3 && lane < 2 * (TZ + 2)) ring[slot][lane >> 1][(lane & 1) ? 65 : 0] = vh;
     };
     // R of the plane in slot a, whose +y neighbour plane is in slot b
     auto compute_r = [&](int a, int b, int rslot) {
-        for (int e = threadIdx.x; e < (TVL_TZ + 1) * 65; e += 256) {
+        for (int e = threadIdx.x; e < (TZ + 1) * 65; e += 256) {
             int zi = e / 65, si = e - zi * 65;
             float c = ring[a][zi][si];
             float d1 = c - ring[a][zi][si + 1];
@@ -1039,8 +1045,8 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
         compute_r(m1, m2, rc);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            int zi = 1 + wave * 2 + q;
+        for (int q = 0; q < TZ / 4; ++q) {
+            int zi = 1 + wave * (TZ / 4) + q;
             int z = z0 + zi - 1;
             if (z < n && s < nx) {
                 float c = ring[m1][zi][si];

@@ -51,7 +51,7 @@ struct tomo_engine {
     uint2 *d_went = nullptr;
     float lipschitz = 0.f;
     int sart_fused = 2, sart_unroll = 8;     // sart_fused: 0 FP+BP per angle, 1 fused per-ray, 2 fused segmented
-    int tv_lds = 1, fp_all_lpr = 16;           // all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
+    int tv_lds = 8, fp_all_lpr = 16;           // all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
     SegItemD *d_seg_exec = nullptr;
     std::vector<uint32_t> h_seg_exec_ptr;
     uint32_t *d_row_first = nullptr, *d_row_nseg = nullptr;
@@ -1036,9 +1036,13 @@ int tomo_tv_grad(tomo_engine *e, float eps)
         ProfScope ps(e, TOMO_K_TV_GRAD);
         if (e->tv_lds) {
             int yseg = 32;
-            int nzb = (e->n + TVL_TZ - 1) / TVL_TZ;
-            dim3 grid((unsigned)(nzb * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
-            hipLaunchKernelGGL(k_tv_grad_lds, grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg);
+            if (e->tv_lds == 16) {
+                dim3 grid((unsigned)(((e->n + 15) / 16) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+                hipLaunchKernelGGL((k_tv_grad_lds<16>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg);
+            } else {
+                dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+                hipLaunchKernelGGL((k_tv_grad_lds<8>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg);
+            }
         } else {
             hipLaunchKernelGGL(k_tv_grad, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx);
         }
@@ -1171,7 +1175,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value < 0 || value > 2 ? 2 : value; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
-    if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 0 direct, 8 / 16 = z-columns per workgroup
     if (std::strcmp(name, "sart_unroll") == 0) { e->sart_unroll = value == 4 ? 4 : 8; return TOMO_OK; }
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
