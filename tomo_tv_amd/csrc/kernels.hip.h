@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_fp_rows_g(const float *__restrict__ x, 
 {
     typedef VecOf<4>::T V;
     constexpr int R = 64 / LPR;                       // rays per wave
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPR, gl = lane - grp * LPR;
     const int ngw = (nrows + R - 1) / R;              // ray groups per chunk
@@ -247,18 +247,21 @@ __global__ __launch_bounds__(256) void k_fp_rows_g(const float *__restrict__ x, 
     int off = chunk * (LPR * 4) + gl * 4;
     const float *xp = x + off;
     V acc = vzero<4>();
-    for (uint32_t k = kb; __any(k < ke); k += U) {
-        uint2 e[U];
-        V xv[U];
+    // software pipeline: the entry (pixel, weight) loads of trip t+1 are issued before the row loads of trip t are
+    // consumed, so a trip costs one memory round trip instead of two dependent ones
+    uint2 e[U], en[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t kk = min(k + u, ke > kb ? ke - 1 : kb);
-            e[u] = (k + u < ke) ? rent[kk] : make_uint2(0u, 0u);
-        }
+    for (int u = 0; u < U; ++u) e[u] = (kb + u < ke) ? rent[kb + u] : make_uint2(0u, 0u);
+    for (uint32_t k = kb; __any(k < ke); k += U) {
+        V xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const V *>(xp + (size_t)e[u].x * sx);
 #pragma unroll
+        for (int u = 0; u < U; ++u) en[u] = (k + U + u < ke) ? rent[k + U + u] : make_uint2(0u, 0u);
+#pragma unroll
         for (int u = 0; u < U; ++u) acc += __uint_as_float(e[u].y) * xv[u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = en[u];
     }
     double local = 0.0;
     if (valid) {
@@ -293,70 +296,6 @@ __global__ __launch_bounds__(256) void k_fp_rows_g(const float *__restrict__ x, 
         local = wave_sum(local);
         if (lane == 0) atomicAdd(&part[blockIdx.x & (NPART - 1)], local);
     }
-}
-
-// Experimental variant: one wave per ray (no split, no LDS), 4 rays per workgroup.  RESID_NORM epilogue only.
-template <int VEC, int UNR>
-__global__ __launch_bounds__(256) void k_fp_rows_w1(const float *__restrict__ x, const uint32_t *__restrict__ rptr,
-                                                     const uint2 *__restrict__ rent, const float *__restrict__ b,
-                                                     const float *__restrict__ rowsum, float *__restrict__ out,
-                                                     int row0, int nrows, int sx)
-{
-    typedef typename VecOf<VEC>::T V;
-    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    int chunk, rowidx;
-    ray_block_map(blockIdx.x * 4 + wave, gridDim.x * 4, nrows, chunk, rowidx);
-    int row = row0 + rowidx;
-    uint32_t kb = rptr[row], ke = rptr[row + 1];
-    int off = chunk * (64 * VEC) + lane * VEC;
-    const float *xp = x + off;
-    V acc = vzero<VEC>();
-#pragma unroll UNR
-    for (uint32_t k = kb; k < ke; ++k) {
-        uint2 e = rent[k];
-        float w = __uint_as_float(e.y);
-        V xv = *reinterpret_cast<const V *>(xp + (size_t)e.x * sx);
-        acc += w * xv;
-    }
-    size_t o = (size_t)row * sx + off;
-    V bv = *reinterpret_cast<const V *>(b + o);
-    float rs = rowsum[row];
-    V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
-    *reinterpret_cast<V *>(out + o) = r;
-}
-
-// Experimental variant: one wave per ray covering TWO float4 chunks (2 KB contiguous per pixel), 4 rays per workgroup.
-template <int UNR>
-__global__ __launch_bounds__(256) void k_fp_rows_w1x2(const float *__restrict__ x, const uint32_t *__restrict__ rptr,
-                                                       const uint2 *__restrict__ rent, const float *__restrict__ b,
-                                                       const float *__restrict__ rowsum, float *__restrict__ out,
-                                                       int row0, int nrows, int sx)
-{
-    typedef VecOf<4>::T V;
-    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    int chunk, rowidx;
-    ray_block_map(blockIdx.x * 4 + wave, gridDim.x * 4, nrows, chunk, rowidx);
-    int row = row0 + rowidx;
-    uint32_t kb = rptr[row], ke = rptr[row + 1];
-    int off = chunk * 512 + lane * 4;
-    const float *xp = x + off;
-    V acc0 = vzero<4>(), acc1 = vzero<4>();
-#pragma unroll UNR
-    for (uint32_t k = kb; k < ke; ++k) {
-        uint2 e = rent[k];
-        float w = __uint_as_float(e.y);
-        V x0 = *reinterpret_cast<const V *>(xp + (size_t)e.x * sx);
-        V x1 = *reinterpret_cast<const V *>(xp + (size_t)e.x * sx + 256);
-        acc0 += w * x0;
-        acc1 += w * x1;
-    }
-    size_t o = (size_t)row * sx + off;
-    float rs = rowsum[row];
-    V b0 = *reinterpret_cast<const V *>(b + o), b1 = *reinterpret_cast<const V *>(b + o + 256);
-    *reinterpret_cast<V *>(out + o) = rs > 0.f ? (b0 - acc0) / rs : vzero<4>();
-    *reinterpret_cast<V *>(out + o + 256) = rs > 0.f ? (b1 - acc1) / rs : vzero<4>();
 }
 
 // ---- voxel-driven back-projector, one angle (the SART update) ---------------------------------------

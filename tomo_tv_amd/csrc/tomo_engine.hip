@@ -51,7 +51,8 @@ struct tomo_engine {
     uint2 *d_went = nullptr;
     float lipschitz = 0.f;
     int sart_fused = 2, sart_unroll = 8;     // sart_fused: 0 FP+BP per angle, 1 fused per-ray, 2 fused segmented
-    int tv_lds = 8, fp_all_lpr = 16;           // all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
+    int tv_lds = 8, fp_all_lpr = 16;
+    // fp_all_lpr: all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
     SegItemD *d_seg_exec = nullptr;
     std::vector<uint32_t> h_seg_exec_ptr;
     uint32_t *d_row_first = nullptr, *d_row_nseg = nullptr;
