@@ -33,10 +33,16 @@ def asd_pocs_step(t, st):
         dp = st["dPOCS"] / 0.2
     else:
         dp = t.matrix_2norm()
-    dd = t.data_distance() / st["norm"]
     t.copy_recon()
-    tv = t.tv_gd(10, st["dPOCS"])
-    dg = t.matrix_2norm()
+    if hasattr(t, "data_distance_begin"):      # engine: residual of the SART result on the second stream, under the TV steps
+        t.data_distance_begin()
+        tv = t.tv_gd(10, st["dPOCS"])
+        dg = t.matrix_2norm()
+        dd = t.data_distance_end() / st["norm"]
+    else:                                      # oracle (cpu_baseline): same work, sequentially
+        dd = t.data_distance() / st["norm"]
+        tv = t.tv_gd(10, st["dPOCS"])
+        dg = t.matrix_2norm()
     if dg > dp * 0.95 and dd > 0.025:
         st["dPOCS"] *= 0.95
     st["i"] += 1

@@ -120,6 +120,10 @@ int tomo_fista_momentum(tomo_engine *e, float beta);                    /* tomoe
 
 /* ---- scalar reductions: partial sums of this slab land in the device scalar buffer ------------------ */
 int tomo_data_distance_sq(tomo_engine *e, int vol);                     /* tomoengine.cpp:410-413 -> TOMO_S_DD (also fills G) */
+/* the same evaluation on a second stream, for a volume the main sequence no longer writes (e.g. the TEMP copy);
+ * tomo_async_wait (also implied by tomo_read_scalars) orders the main stream behind it */
+int tomo_data_distance_sq_async(tomo_engine *e, int vol);
+int tomo_async_wait(tomo_engine *e);
 int tomo_diff_norm_sq(tomo_engine *e, int a, int b, int slot);          /* :407 matrix_2norm, :433 rmse */
 int tomo_sino_diff_norm_sq(tomo_engine *e, int a, int b, int slot);     /* multimodal.cpp:489 (g - bh).norm() */
 int tomo_sino_proj_max(tomo_engine *e, int sino, float *out_host);      /* multimodal.cpp:323-327: max per projection */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "tomo_fista_momentum": [_p, _f],
     "tomo_data_distance_sq": [_p, _i],
     "tomo_diff_norm_sq": [_p, _i, _i, _i],
+    "tomo_data_distance_sq_async": [_p, _i],
+    "tomo_async_wait": [_p],
     "tomo_l1_norm": [_p, _i],
     "tomo_read_scalars": [_p, _p, _i],
     "tomo_bind_scalar_buffer": [_p, _p],

@@ -288,6 +288,15 @@ class _EngineBase:
         self.be.c("data_distance_sq", VOL_RECON)
         return float(np.sqrt(self._scalar(S_DD)))
 
+    def data_distance_begin(self, vol=VOL_TEMP):
+        """Start ||A vol - b|| on the engine's second stream; ``vol`` must not be written until ``data_distance_end``.
+        (ASD-POCS: the residual of the SART result, held in the TEMP copy, overlaps the TV descent on recon.)"""
+        self.be.c("data_distance_sq_async", vol)
+
+    def data_distance_end(self):
+        self.be.c("async_wait")
+        return float(np.sqrt(self._scalar(S_DD)))
+
     # ---- TV ----------------------------------------------------------------------------------------------------
     def _tv_of(self, vol, eps):
         if self.comm is None:

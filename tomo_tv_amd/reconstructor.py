@@ -137,10 +137,13 @@ class TomoGPU:
                 dp = dPOCS / alpha
             else:
                 dp = t.matrix_2norm()
-            self.dd_vec[i] = t.data_distance() / norm
+            # the residual of the SART result is independent of the TV descent: evaluate it on the snapshot (TEMP)
+            # on the engine's second stream while the TV steps run
             t.copy_recon()
+            t.data_distance_begin()
             self.tv_vec[i] = t.tv_gd(nTViter, dPOCS)
             dg = t.matrix_2norm()
+            self.dd_vec[i] = t.data_distance_end() / norm
             if dg > dp * r_max and self.dd_vec[i] > eps:
                 dPOCS *= alpha_reduce
         return self.dd_vec, self.tv_vec
