@@ -74,7 +74,10 @@ struct tomo_engine {
     float *stage = nullptr;
     size_t stage_bytes = 0;
     // scalars
-    double *d_scal = nullptr, *d_scal_own = nullptr, *d_part = nullptr;
+    double *d_scal = nullptr, *d_scal_own = nullptr, *d_part = nullptr, *d_part_aux = nullptr;
+    hipStream_t aux = nullptr;                    // second stream for work that is independent of the main sequence
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool async_pending = false;
     // halos
     float *halo_lo = nullptr, *halo_hi = nullptr, *halo_lo_own = nullptr, *halo_hi_own = nullptr;
     int is_first = 1, is_last = 1;
@@ -438,7 +441,8 @@ int tomo_destroy(tomo_engine *e)
     if (!e) return TOMO_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
+    void *ptrs[] = {e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -927,6 +931,44 @@ int tomo_data_distance_sq(tomo_engine *e, int vol)
     return reduce_end(e, TOMO_S_DD);
 }
 
+// The data distance of a volume that the main sequence no longer modifies (e.g. the TEMP copy) can be evaluated on
+// a second stream while the main stream goes on (ASD-POCS: the residual of the SART result next to the TV descent).
+int tomo_data_distance_sq_async(tomo_engine *e, int vol)
+{
+    NEED(e);
+    if (e->async_pending) return fail(TOMO_ERR_STATE, "an asynchronous evaluation is already in flight");
+    if (!e->aux) {
+        HIPCHK(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        int rc = dev_alloc((void **)&e->d_part_aux, NPART * sizeof(double), true, e->stream);
+        if (rc) return rc;
+    }
+    float *tmp; int rc;
+    if ((rc = get_vol(e, vol, &tmp)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &tmp))) return rc;   // allocate on the main stream
+    HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+    hipStream_t main_stream = e->stream;
+    double *main_part = e->d_part;
+    e->stream = e->aux; e->d_part = e->d_part_aux;
+    rc = tomo_data_distance_sq(e, vol);
+    e->stream = main_stream; e->d_part = main_part;
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev_join, e->aux));
+    e->async_pending = true;
+    return TOMO_OK;
+}
+
+int tomo_async_wait(tomo_engine *e)
+{
+    NEED(e);
+    if (e->async_pending) {
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        e->async_pending = false;
+    }
+    return TOMO_OK;
+}
+
 int tomo_diff_norm_sq(tomo_engine *e, int a, int b, int slot)
 {
     NEED(e);
@@ -955,6 +997,7 @@ int tomo_read_scalars(tomo_engine *e, double *out, int count)
 {
     NEED(e);
     if (!out || count < 0 || count > TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar count");
+    { int rc = tomo_async_wait(e); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(out, e->d_scal, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return TOMO_OK;
