@@ -170,8 +170,12 @@ int tomo_mm_model(tomo_engine *ce, const int32_t *xvols, int nel, const float *w
 int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, int nel, const float *w, float gamma,
                    float lamC_over_L, float lamH, tomo_engine *he, int upd_vol, int model_vol); /* :435-438, :471-476 */
 
-/* Engine options.  "sart_fused" (default 1): run a SART sweep as FP(a0), [BP(a_k)+FP(a_k+1)] fused steps, BP(a_last)
- * instead of separate FP/BP launches per angle (same arithmetic per voxel; 8 instead of 12 bytes per voxel-angle). */
+/* Engine options (A/B switches for measurement; defaults are the fast paths):
+ *   "sart_fused" (1): run a SART sweep as FP(a0), [BP(a_k)+FP(a_k+1)] fused steps, BP(a_last) instead of separate
+ *                     FP/BP launches per angle (same arithmetic per voxel; 8 instead of 12 bytes per voxel-angle)
+ *   "tv_lds" (8):     TV gradient as LDS march with that many z-columns per workgroup (0 = direct-global stencil)
+ *   "fgp_fused" (1):  one fused kernel per FGP iteration (single slab)
+ *   "fp_all_lpr" (16): all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks (0 = wide form) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------

@@ -98,7 +98,7 @@ def test_fused_sart_equals_separate_fp_bp(gpu, Nx, P, niter, order):
     ang = np.deg2rad(np.linspace(-70, 70, P)) if P > 1 else np.deg2rad([17.0])
     x = ellipsoids(Nx, N, seed=3)
     vols = []
-    for fused in (2, 1, 0):
+    for fused in (1, 0):
         dev = tomoengine(Nx, N, ang)
         dev.set_option("sart_fused", fused)
         dev.set_volume(x, VOL_ORIGINAL)
@@ -108,7 +108,7 @@ def test_fused_sart_equals_separate_fp_bp(gpu, Nx, P, niter, order):
         dev.SART(0.3, 1)                      # a second call starts from the swapped buffer
         vols.append(dev.get_volume())
         dd = dev.data_distance()
-    assert rel_l2(vols[0], vols[2]) < 2e-6 and rel_l2(vols[1], vols[2]) < 2e-6
+    assert rel_l2(vols[0], vols[1]) < 2e-6
     ref = oracle.ctvlib(Nx, N, P)
     ref.load_A(oracle.parallel_ray(N, np.rad2deg(ang)))
     ref.original_volume = x.copy()

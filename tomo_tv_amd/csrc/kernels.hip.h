@@ -350,84 +350,15 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
 // owns the pixel stores it.  The walk lists make the rays of one angle visit every pixel with exactly one
 // owner, so x_new is fully written; reads come from x_old only (ping-pong), so the 1-2 rays that share a pixel
 // never see a half-updated volume.  Per angle the slab is read once and written once: 8 B/voxel instead of the
-// 12 B/voxel of a separate FP + BP pair.  Epilogue = normalised residual of "next" (as FP_RESID_NORM).
-template <int VEC, int U>
-__global__ __launch_bounds__(256) void k_sart_fused(const float *__restrict__ x_old, float *__restrict__ x_new,
-                                                     const uint32_t *__restrict__ wptr, const uint2 *__restrict__ went,
-                                                     const CellD *__restrict__ cell_prev,
-                                                     const float *__restrict__ r_prev, float beta,
-                                                     const float *__restrict__ b, const float *__restrict__ rowsum,
-                                                     float *__restrict__ r_out, int row0, int nrows, int sx)
-{
-    typedef typename VecOf<VEC>::T V;
-    int chunk, rowidx;
-    ray_block_map(blockIdx.x, gridDim.x, nrows, chunk, rowidx);
-    int row = row0 + rowidx;
-    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    uint32_t beg = wptr[row], end = wptr[row + 1];
-    uint32_t seg = (end - beg + 3u) >> 2;
-    uint32_t kb = min(beg + wave * seg, end), ke = min(kb + seg, end);
-    int off = chunk * (64 * VEC) + lane * VEC;
-    const float *xp = x_old + off;
-    const float *rp = r_prev + off;
-    float *xo = x_new + off;
-    V acc = vzero<VEC>();
-    // U visits per trip, in four phases so that all table fetches and then all 3U row loads are in flight
-    // together (a visit-at-a-time loop serialises four dependent memory round trips per pixel).
-    for (uint32_t k = kb; k < ke; k += U) {
-        uint2 e[U];
-        CellD c[U];
-        V xv[U], a0[U], a1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) e[u] = went[min(k + u, ke - 1)];
-#pragma unroll
-        for (int u = 0; u < U; ++u) c[u] = cell_prev[e[u].x & 0x7fffffffu];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            size_t po = (size_t)(e[u].x & 0x7fffffffu) * sx;
-            xv[u] = *reinterpret_cast<const V *>(xp + po);
-            a0[u] = *reinterpret_cast<const V *>(rp + (size_t)c[u].r0 * sx);
-            a1[u] = *reinterpret_cast<const V *>(rp + (size_t)c[u].r1 * sx);
-        }
-        // pin the loads here: without this the optimiser sinks each visit's loads behind the previous visit's
-        // conditional store and the trip degenerates into U serial round trips
-#pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(xv[u]), "+v"(a0[u]), "+v"(a1[u]));
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bool live = k + u < ke;                       // the tail repeats the last visit with no effect
-            float cs = c[u].w0 + c[u].w1;
-            V num = c[u].w0 * a0[u];
-            num += c[u].w1 * a1[u];
-            V upd = num / (cs > 0.f ? cs : 1.0f);         // cs == 0 means w0 == w1 == 0, so num == 0
-            V nv = xv[u] + beta * upd;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
-            float w = live ? __uint_as_float(e[u].y) : 0.f;
-            acc += w * nv;
-            if (live && (e[u].x & 0x80000000u)) *reinterpret_cast<V *>(xo + (size_t)(e[u].x & 0x7fffffffu) * sx) = nv;
-        }
-    }
-    __shared__ V red[3][64];
-    if (wave > 0) red[wave - 1][lane] = acc;
-    __syncthreads();
-    if (wave == 0) {
-        acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
-        size_t o = (size_t)row * sx + off;
-        V bv = *reinterpret_cast<const V *>(b + o);
-        float rs = rowsum[row];
-        V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
-        *reinterpret_cast<V *>(r_out + o) = r;
-    }
-}
-
-// ---- segmented form of the fused step: equal-sized work items --------------------------------------------
-// A launch of one workgroup per (ray, chunk) finishes when its longest ray does, and with ~4 workgroups per CU
-// there is no second round to even things out (measured: 242 us against 187 us at the streaming rate).  Here a
-// ray's walk list is cut into segments of <= seg_len visits (host: build_segments) and ONE WAVE runs one
+// 12 B/voxel of a separate FP + BP pair.
+//
+// Work decomposition: one workgroup per (ray, chunk) finishes when its longest ray does, and with ~4 workgroups
+// per CU there is no second round to even things out (measured: 242 us against 187 us at the streaming rate).
+// So a ray's walk list is cut into segments of <= seg_len visits (host: build_segments) and ONE WAVE runs one
 // segment: many short equal items, dealt to the XCDs in groups of neighbouring rays.  Each item leaves its
 // partial line integral in partial[id][s]; k_resid_finish adds a ray's segments in order and forms the residual.
+// A visit-at-a-time loop serialises four dependent memory round trips per pixel; the loop runs U visits per trip
+// in phases (entries, cells, 3U row loads, then arithmetic and the owner stores).
 // FUSED = false is the plain per-angle forward projection (no pending voxel update, no volume write).
 struct SegItemD { uint32_t id, kbeg, kend, pad; };
 

@@ -50,7 +50,7 @@ struct tomo_engine {
     uint32_t *d_wptr = nullptr;                   // walk lists of the fused SART step
     uint2 *d_went = nullptr;
     float lipschitz = 0.f;
-    int sart_fused = 2, sart_unroll = 8;     // sart_fused: 0 FP+BP per angle, 1 fused per-ray, 2 fused segmented
+    int sart_fused = 1;                      // 1: SART sweep as a chain of fused BP+FP steps; 0: separate FP and BP per angle
     int tv_lds = 8, fp_all_lpr = 16;
     // fp_all_lpr: all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
     SegItemD *d_seg_exec = nullptr;
@@ -215,29 +215,6 @@ static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_a
     }
     LAUNCHCHK();
     return TOMO_OK;
-}
-
-template <int U>
-static int launch_sart_fused_u(tomo_engine *e, const float *x_old, float *x_new, int prev, int next, float *r, float beta)
-{
-    int nchunk = e->sxc / (64 * e->vec);
-    dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
-    const CellD *cell = e->d_cell + (size_t)prev * e->npix;
-    const float *rp = r + (size_t)prev * e->n * e->sx;
-    switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_sart_fused<4, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->cur_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
-    case 2: hipLaunchKernelGGL((k_sart_fused<2, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->cur_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
-    default: hipLaunchKernelGGL((k_sart_fused<1, U>), grid, block, 0, e->stream, x_old, x_new, e->d_wptr, e->d_went, cell, rp, beta, e->cur_b, e->d_rowsum, r, next * e->n, e->n, e->sx); break;
-    }
-    LAUNCHCHK();
-    return TOMO_OK;
-}
-
-static int launch_sart_fused(tomo_engine *e, const float *x_old, float *x_new, int prev, int next, float *r, float beta)
-{
-    ProfScope ps(e, TOMO_K_SART_FUSED);
-    return e->sart_unroll == 4 ? launch_sart_fused_u<4>(e, x_old, x_new, prev, next, r, beta)
-                               : launch_sart_fused_u<8>(e, x_old, x_new, prev, next, r, beta);
 }
 
 // segmented per-angle step: FUSED -> BP(prev) + FP(next); else plain FP(next).  Leaves the residual rows of `next` in r.
@@ -666,13 +643,7 @@ int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, c
     float *alt;
     if ((rc = get_scratch(e, &e->sart_alt, &alt))) return rc;
     float *cur = x;
-    const bool seg = e->sart_fused == 2;
-    if (seg) {
-        if ((rc = launch_sart_seg<false>(e, cur, nullptr, 0, angle_at(0), r, beta))) return rc;
-    } else {
-        ProfScope ps(e, TOMO_K_FP_ANGLE);
-        if ((rc = launch_fp<FP_RESID_NORM>(e, cur, angle_at(0) * e->n, e->n, e->cur_b, r))) return rc;
-    }
+    if ((rc = launch_sart_seg<false>(e, cur, nullptr, 0, angle_at(0), r, beta))) return rc;
     for (int64_t k = 1; k < steps; ++k) {
         int prev = angle_at(k - 1), next = angle_at(k);
         if (prev == next) {   // single-angle geometry: the residual rows read and written would be the same
@@ -680,9 +651,7 @@ int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, c
             if ((rc = launch_fp<FP_RESID_NORM>(e, cur, next * e->n, e->n, e->cur_b, r))) return rc;
             continue;
         }
-        if (seg) rc = launch_sart_seg<true>(e, cur, alt, prev, next, r, beta);
-        else rc = launch_sart_fused(e, cur, alt, prev, next, r, beta);
-        if (rc) return rc;
+        if ((rc = launch_sart_seg<true>(e, cur, alt, prev, next, r, beta))) return rc;
         std::swap(cur, alt);
     }
     int last = angle_at(steps - 1);
@@ -1217,10 +1186,9 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
 {
     if (!e || !name) return fail(TOMO_ERR_ARG, "null argument");
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
-    if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value < 0 || value > 2 ? 2 : value; return TOMO_OK; }
+    if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 0 direct, 8 / 16 = z-columns per workgroup
-    if (std::strcmp(name, "sart_unroll") == 0) { e->sart_unroll = value == 4 ? 4 : 8; return TOMO_OK; }
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
 
