@@ -109,6 +109,9 @@ int tomo_cgls(tomo_engine *e, int vol, int niter);
 int tomo_fbp(tomo_engine *e, const float *taps_host, float scale, int apply_positivity);
 /* ctvlib::ART(beta): row-action Kaczmarz sweep + positivity  ctvlib.cpp:137-155 */
 int tomo_art(tomo_engine *e, float beta);
+/* ctvlib::randART(beta) with the rows visited in the given permutation (the reference's loop, ctvlib.cpp:158-179,
+ * rewrites its own counter and draws from an unseedable device: quirk Q9)  */
+int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host);
 /* tomoengine::poisson_ML(lambda): cost accumulates in TOMO_S_COST  tomoengine.cpp:231-246, 293-315 */
 int tomo_poisson_ml(tomo_engine *e, float lambda);
 /* out = (A x - b)/(A x + 0.1), cost sum(Ax - b log(Ax + 0.1)) -> TOMO_S_COST   multimodal.cpp:284-292, 466-473 */

@@ -58,7 +58,7 @@ def lib():
         L.orc_row_inner.restype = None
         L.orc_row_inner.argtypes = [i64, P, P, P]
         L.orc_art.restype = None
-        L.orc_art.argtypes = [i32, i64, i64, P, P, P, P, P, P, f32]
+        L.orc_art.argtypes = [i32, i64, i64, P, P, P, P, P, P, f32, P]
         L.orc_sqdiff.restype = f64
         L.orc_sqdiff.argtypes = [i64, P, P]
         L.orc_sart.restype = None
@@ -221,9 +221,10 @@ class ctvlib:
     def SIRT(self, beta, niter=1):
         lib().orc_sirt(self.Nslice_, self.Nrow, self.Ncol, *self._a(), _p(self.b), _p(self.recon), beta, niter)
 
-    def ART(self, beta):
+    def ART(self, beta, order=None):
+        o = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
         lib().orc_art(self.Nslice_, self.Nrow, self.Ncol, *self._a(), _p(self.innerProduct), _p(self.b),
-                      _p(self.recon), beta)
+                      _p(self.recon), beta, None if o is None else _p(o))
 
     def SART(self, beta, niter=1, order=None, target="recon"):
         vol = getattr(self, target)

@@ -314,13 +314,14 @@ void orc_row_inner(int64_t nrow, const int64_t *ptr, const float *val, float *in
 /* ART(beta): ctvlib.cpp:137-155.  Rows in natural order; clamp after the full sweep.
  * A row with zero inner product (empty ray) would divide by zero in the reference; it is skipped. */
 void orc_art(int nslice, int64_t nrow, int64_t ncol, const int64_t *ptr, const int32_t *idx,
-             const float *val, const float *inner, const float *b, float *vol, float beta)
+             const float *val, const float *inner, const float *b, float *vol, float beta, const int32_t *order)
 {
 #pragma omp parallel for
     for (int s = 0; s < nslice; s++) {
         float *x = vol + (size_t)s * ncol;
         const float *bs = b + (size_t)s * nrow;
-        for (int64_t j = 0; j < nrow; j++) {
+        for (int64_t q = 0; q < nrow; q++) {
+            int64_t j = order ? order[q] : q;          /* randART as a permutation sweep (ctvlib.cpp:158-179, quirk Q9) */
             if (!(inner[j] > 0.0f)) continue;
             float dot = 0.0f;
             for (int64_t k = ptr[j]; k < ptr[j + 1]; k++) dot += val[k] * x[idx[k]];

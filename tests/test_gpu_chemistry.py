@@ -39,18 +39,6 @@ def make_case(N=32, Nx=6, Ph=9, Pc=7, Nel=2, gamma=1.6, seed=0):
     return dev, ref, gt
 
 
-def test_summation_weights_equal_reference_matrix():
-    """Weights vs the imported reference create_weighted_summation_matrix (tests/golden/sigma_*.npz)."""
-    for fn, zs, method in [("sigma_m3_nz2.npz", [31, 8], 3), ("sigma_m1_nz2.npz", [31, 8], 1), ("sigma_m3_nz3.npz", [22, 38, 8], 3)]:
-        g = np.load(os.path.join(GOLDEN, fn))
-        w = create_weighted_summation_weights(zs, 1.6, method)
-        npix, nel = int(g["shape"][0]), len(zs)
-        indptr, indices, data = g["indptr"], g["indices"], g["data"]
-        for p in (0, npix // 2, npix - 1):
-            cols, vals = indices[indptr[p]:indptr[p + 1]], data[indptr[p]:indptr[p + 1]]
-            assert np.array_equal(cols, p + npix * np.arange(nel)) and np.array_equal(vals, w)
-
-
 @pytest.mark.parametrize("gamma", [1.0, 1.6])
 def test_poisson_ml_then_data_fusion(gpu, gamma):
     dev, ref, gt = make_case(gamma=gamma)

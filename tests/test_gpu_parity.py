@@ -148,6 +148,19 @@ def test_art_sweep(gpu, golden, N, P, Nx):
     assert rel_l2(dev.get_volume(), g["art_1"]) < TOL
 
 
+def test_randart_permutation_sweep(gpu, golden):
+    N, P, Nx = 32, 9, 4
+    dev, ref, g = make_pair(golden, N, P, Nx)
+    dev.set_tilt_series(g["b"])
+    ref.set_tilt_series(g["b"])
+    ref.row_inner_product()
+    for seed in (5, 6):
+        order = dev.randART(0.5, seed=seed)
+        assert np.array_equal(np.sort(order), np.arange(N * P))
+        ref.ART(0.5, order=order)
+        assert rel_l2(dev.get_volume(), ref.recon) < TOL
+
+
 @pytest.mark.parametrize("N,P,Nx", SHAPES)
 @pytest.mark.parametrize("eps", [1e-8, 1e-6])
 def test_tv_value_and_gradient_descent(gpu, golden, N, P, Nx, eps):

@@ -46,6 +46,7 @@ SIGNATURES = {
     "tomo_sirt": [_p, _i, _i],
     "tomo_sart": [_p, _i, _f, _i, _p],
     "tomo_art": [_p, _f],
+    "tomo_art_order": [_p, _f, _p],
     "tomo_poisson_ml": [_p, _f],
     "tomo_positivity": [_p, _i],
     "tomo_soft_threshold": [_p, _i, _f],

@@ -514,11 +514,13 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
 // One wave per 64 slices walks every row in order: a = (b_j - A_j x)/|A_j|^2 ; x += A_j^T a beta.
 __global__ __launch_bounds__(64) void k_art(float *__restrict__ x, const uint32_t *__restrict__ rptr,
                                              const uint2 *__restrict__ rent, const float *__restrict__ b,
-                                             const float *__restrict__ inner, float beta, int nrows, int sx)
+                                             const float *__restrict__ inner, float beta, int nrows, int sx,
+                                             const int32_t *__restrict__ order)
 {
     int off = blockIdx.x * 64 + threadIdx.x;
     float *xp = x + off;
-    for (int row = 0; row < nrows; ++row) {
+    for (int q = 0; q < nrows; ++q) {
+        int row = order ? order[q] : q;                // randART: a permutation of the rows (ctvlib.cpp:158-179)
         float ip = inner[row];
         if (!(ip > 0.f)) continue;
         uint32_t beg = rptr[row], end = rptr[row + 1];

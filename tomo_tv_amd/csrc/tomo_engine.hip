@@ -660,13 +660,28 @@ int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, c
     return TOMO_OK;
 }
 
-int tomo_art(tomo_engine *e, float beta)
+int tomo_art(tomo_engine *e, float beta) { return tomo_art_order(e, beta, nullptr); }
+
+int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
 {
     NEED(e);
     float *x = e->vol[TOMO_VOL_RECON];
-    hipLaunchKernelGGL(k_art, dim3(e->sx / 64), dim3(64), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino[TOMO_SINO_B], e->d_rowinner, beta, (int)e->nrows, e->sx);
+    int32_t *d_order = nullptr;
+    if (order_host) {
+        std::vector<char> seen(e->nrows, 0);
+        for (int64_t q = 0; q < e->nrows; ++q) {
+            if (order_host[q] < 0 || order_host[q] >= e->nrows || seen[order_host[q]]) return fail(TOMO_ERR_ARG, "row order is not a permutation");
+            seen[order_host[q]] = 1;
+        }
+        int rc = ensure_stage(e, e->nrows * sizeof(int32_t)); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(e->stage, order_host, e->nrows * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        d_order = (int32_t *)e->stage;
+    }
+    hipLaunchKernelGGL(k_art, dim3(e->sxc / 64), dim3(64), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino[TOMO_SINO_B], e->d_rowinner, beta, (int)e->nrows, e->sx, d_order);
     LAUNCHCHK();
-    return tomo_positivity(e, TOMO_VOL_RECON);
+    int rc = tomo_positivity(e, TOMO_VOL_RECON);
+    if (!rc && order_host) HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffer holds the order until the sweep is done
+    return rc;
 }
 
 int tomo_poisson_ml(tomo_engine *e, float lambda)

@@ -512,6 +512,14 @@ class ctvlib(_EngineBase):
     def ART(self, beta):
         self.be.c("art", float(beta))
 
+    def randART(self, beta, seed=None):
+        """Kaczmarz sweep over a seeded random permutation of the rows (the reference's randART, ctvlib.cpp:158-179,
+        walks a random sequence with an unseedable generator: quirk Q9).  Returns the permutation used."""
+        rng = np.random.default_rng(seed) if seed is not None else self._order_rng
+        order = np.ascontiguousarray(rng.permutation(self.Nrow), dtype=np.int32)
+        self.be.c("art_order", float(beta), _ptr(order))
+        return order
+
     def data_distance(self):
         """||A recon - b||_2 / (Nslice*Nrow)  (ctvlib.cpp:272-276)."""
         return self._data_distance_raw() / (self.Nslice_ * self.Nrow)

@@ -74,8 +74,10 @@ def run_ctvlib(tomo, alg, beta=1):
         tomo.SIRT(beta)
     elif alg == "ART":
         tomo.ART(beta)
+    elif alg == "randART":
+        tomo.randART(beta)
     else:
-        raise NotImplementedError(f"{alg}: only the Landweber SIRT and ART branches are on the hot path")
+        raise NotImplementedError(f"{alg}: the Cimmino branch multiplies by the row norms instead of dividing (quirk Q10) and is not built")
 
 
 def create_projections(tomo, original_volume):
