@@ -84,6 +84,9 @@ int tomo_set_slice(tomo_engine *e, int vol, int s, const float *img);   /* :104-
 int tomo_get_slice(tomo_engine *e, int vol, int s, float *img);         /* :452 getRecon */
 int tomo_restart_recon(tomo_engine *e);                                 /* :462-468 restart_recon */
 int tomo_copy_volume(tomo_engine *e, int dst, int src);                 /* :404 copy_recon = (TEMP <- RECON) */
+/* volume of another engine with the same slab shape (rebuilding the tilt geometry keeps the reconstruction:
+ * tomoengine::update_projection_angles, tomoengine.cpp:128-149) */
+int tomo_copy_volume_from(tomo_engine *dst, int dst_vol, tomo_engine *src, int src_vol);
 
 /* ---- projector -------------------------------------------------------------------------------------- */
 int tomo_forward_projection(tomo_engine *e, int vol, int sino);         /* :416-427 forwardProjection; :109-126 create_projections */

@@ -539,3 +539,34 @@ def test_wbp_reconstructs_full_angular_range(gpu, name):
     inner = x > 0
     corr = np.corrcoef(rec.ravel(), x.ravel())[0, 1]
     assert corr > 0.9 and 0.7 < rec[inner].mean() / x[inner].mean() < 1.3, (corr, rec[inner].mean() / x[inner].mean())
+
+
+def test_update_projection_angles_and_poisson_noise(gpu):
+    """Dynamic tilt append keeps the reconstruction (tomoengine.cpp:128-149); seeded Poisson noise keeps the total."""
+    N, Nx = 32, 5
+    x = ellipsoids(Nx, N, seed=9)
+    a1, a2 = np.linspace(-60, 0, 5), np.linspace(-60, 60, 9)
+    dev = tomoengine(Nx, N, np.deg2rad(a1))
+    dev.set_volume(x, VOL_ORIGINAL)
+    dev.create_projections()
+    dev.SART(0.5, 2)
+    before = dev.get_volume()
+    dev.update_projection_angles(np.deg2rad(a2))
+    assert np.array_equal(dev.get_volume(), before) and np.array_equal(dev.get_volume(VOL_ORIGINAL), x)
+    dev.create_projections()
+    ref = oracle.ctvlib(Nx, N, 9)
+    ref.load_A(oracle.parallel_ray(N, a2))
+    ref.original_volume = x.copy()
+    ref.create_projections()
+    assert rel_l2(dev.get_projections(), ref.b) < TOL
+    dev.SART(0.5, 1)
+    ref.recon[:] = before
+    ref.SART(0.5, 1)
+    assert rel_l2(dev.get_volume(), ref.recon) < TOL
+    b0 = dev.get_projections()
+    dev.poisson_noise(50, seed=1)
+    b1 = dev.get_projections()
+    assert abs(b1.sum(dtype=np.float64) / b0.sum(dtype=np.float64) - 1) < 0.02 and not np.array_equal(b0, b1)
+    dev.set_tilt_series(b0)
+    dev.poisson_noise(50, seed=1)
+    assert np.array_equal(dev.get_projections(), b1)            # reproducible

@@ -38,6 +38,7 @@ SIGNATURES = {
     "tomo_get_slice": [_p, _i, _i, _p],
     "tomo_restart_recon": [_p],
     "tomo_copy_volume": [_p, _i, _i],
+    "tomo_copy_volume_from": [_p, _i, _p, _i],
     "tomo_forward_projection": [_p, _i, _i],
     "tomo_back_projection": [_p, _i, _i],
     "tomo_lipschitz": [_p, ctypes.POINTER(_f)],

@@ -825,6 +825,21 @@ int tomo_sino_proj_scale(tomo_engine *e, int sino, const float *div_host, const 
     return TOMO_OK;
 }
 
+// copy a volume between two engines of the same slab shape on one device (used when the tilt geometry is rebuilt:
+// tomoengine::update_projection_angles, tomoengine.cpp:128-149, keeps the reconstruction)
+int tomo_copy_volume_from(tomo_engine *dst, int dst_vol, tomo_engine *src, int src_vol)
+{
+    if (!dst || !src) return fail(TOMO_ERR_ARG, "null engine");
+    if (dst->nx != src->nx || dst->n != src->n || dst->sx != src->sx || dst->device != src->device) return fail(TOMO_ERR_ARG, "engines differ in slab shape or device");
+    HIPCHK(hipSetDevice(dst->device));
+    float *d, *s; int rc;
+    if ((rc = get_vol(dst, dst_vol, &d)) || (rc = get_vol(src, src_vol, &s))) return rc;
+    HIPCHK(hipStreamSynchronize(src->stream));
+    HIPCHK(hipMemcpyAsync(d, s, dst->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    return TOMO_OK;
+}
+
 int tomo_get_stream(tomo_engine *e, void **out) { if (!e || !out) return fail(TOMO_ERR_ARG, "null"); *out = (void *)e->stream; return TOMO_OK; }
 
 // ---- multimodal (ChemicalTomo) element-wise steps: two engines of equal slab size on one device/stream ----

@@ -454,6 +454,33 @@ class tomoengine(_EngineBase):
         self.be.c("poisson_ml", float(lam))
         return self._scalar(S_COST)
 
+    def poisson_noise(self, Nc, seed=4321):
+        """Poisson noise on the tilt series at a mean of ``Nc`` counts per sample, total intensity preserved
+        (tomoengine.cpp:471-484; the reference draws from an unseeded std::default_random_engine, quirk Q13: here a
+        seeded numpy generator on the host -- a simulation edge, not part of the hot path)."""
+        b = self.get_projections().astype(np.float64)
+        total = b.sum()
+        if total <= 0:
+            return
+        scaled = b / total * Nc * b.size
+        noisy = np.random.default_rng(seed).poisson(scaled).astype(np.float64)
+        self.set_tilt_series(noisy / (Nc * b.size) * total)
+
+    def update_projection_angles(self, pyAngles):
+        """New tilt geometry, reconstruction kept (tomoengine.cpp:128-149): tables are rebuilt in a fresh engine and
+        the volumes that exist are moved over on the device.  The tilt series must be set again (its shape changed)."""
+        ang = np.ascontiguousarray(pyAngles, dtype=np.float64).ravel()
+        old = self.be
+        self.Nproj = ang.size
+        self.Nrow = self.Ny * self.Nproj
+        self.be = self._backend_cls(self.nloc, self.Ny, self.Nproj, angles_rad=ang, device=self.gpuID)
+        if self.comm is not None:
+            self.be.enable_torch()
+            self.be.c("set_slab_edges", int(self.comm.rank == 0), int(self.comm.rank == self.comm.world - 1))
+        for v in (VOL_RECON, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD):
+            check(self.be.L.tomo_copy_volume_from(self.be.h, v, old.h, v))
+        old.close()
+
     def data_distance(self):
         """||A recon - b||_2, un-normalised (tomoengine.cpp:410-413)."""
         return self._data_distance_raw()
