@@ -1079,6 +1079,7 @@ int tomo_tv_grad(tomo_engine *e, float eps)
         ProfScope ps(e, TOMO_K_TV_GRAD);
         if (e->tv_lds) {
             int yseg = 32;
+            if (const char *ys = std::getenv("TOMO_TV_YSEG")) yseg = std::max(1, std::atoi(ys));
             if (e->tv_lds == 16) {
                 dim3 grid((unsigned)(((e->n + 15) / 16) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
                 hipLaunchKernelGGL((k_tv_grad_lds<16>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg);
