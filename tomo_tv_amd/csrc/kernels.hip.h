@@ -511,29 +511,48 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
 }
 
 // ---- ART (Kaczmarz), row-sequential by definition (ctvlib.cpp:137-155) -------------------------------
-// One wave per 64 slices walks every row in order: a = (b_j - A_j x)/|A_j|^2 ; x += A_j^T a beta.
-__global__ __launch_bounds__(64) void k_art(float *__restrict__ x, const uint32_t *__restrict__ rptr,
-                                             const uint2 *__restrict__ rent, const float *__restrict__ b,
-                                             const float *__restrict__ inner, float beta, int nrows, int sx,
-                                             const int32_t *__restrict__ order)
+// a = (b_j - A_j x)/|A_j|^2 ; x += A_j^T a beta, one row after the other: row j+1 shares pixels with row j, so
+// rows cannot run side by side.  The parallelism that exists is across slices (lanes) and inside a row: one
+// 1024-thread workgroup owns 64 slices, its 16 waves split the row's entries for the dot product (LDS reduce)
+// and again for the update.  Two barriers per row; the grid is only Nslice/64 workgroups, so ART uses a small
+// part of the chip -- it is the reference CPU path's default algorithm, kept for completeness.
+constexpr int ART_WAVES = 16;
+
+__global__ __launch_bounds__(1024) void k_art(float *__restrict__ x, const uint32_t *__restrict__ rptr,
+                                               const uint2 *__restrict__ rent, const float *__restrict__ b,
+                                               const float *__restrict__ inner, float beta, int nrows, int sx,
+                                               const int32_t *__restrict__ order)
 {
-    int off = blockIdx.x * 64 + threadIdx.x;
+    __shared__ float red[ART_WAVES][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int off = blockIdx.x * 64 + lane;
     float *xp = x + off;
     for (int q = 0; q < nrows; ++q) {
         int row = order ? order[q] : q;                // randART: a permutation of the rows (ctvlib.cpp:158-179)
         float ip = inner[row];
-        if (!(ip > 0.f)) continue;
+        if (!(ip > 0.f)) continue;                     // uniform: an empty ray would divide by zero in the reference
         uint32_t beg = rptr[row], end = rptr[row + 1];
+        uint32_t seg = (end - beg + ART_WAVES - 1) / ART_WAVES;
+        uint32_t kb = min(beg + wave * seg, end), ke = min(kb + seg, end);
         float dot = 0.f;
-        for (uint32_t k = beg; k < end; ++k) {
+#pragma unroll 4
+        for (uint32_t k = kb; k < ke; ++k) {
             uint2 e = rent[k];
             dot += __uint_as_float(e.y) * xp[(size_t)e.x * sx];
         }
-        float a = (b[(size_t)row * sx + off] - dot) / ip;
-        for (uint32_t k = beg; k < end; ++k) {
+        red[wave][lane] = dot;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < ART_WAVES; ++w) tot += red[w][lane];
+        float a = (b[(size_t)row * sx + off] - tot) / ip;
+#pragma unroll 4
+        for (uint32_t k = kb; k < ke; ++k) {
             uint2 e = rent[k];
             xp[(size_t)e.x * sx] += __uint_as_float(e.y) * a * beta;
         }
+        __syncthreads();                               // the next row reads what this one wrote
     }
 }
 

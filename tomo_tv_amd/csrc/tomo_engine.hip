@@ -677,7 +677,7 @@ int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
         HIPCHK(hipMemcpyAsync(e->stage, order_host, e->nrows * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
         d_order = (int32_t *)e->stage;
     }
-    hipLaunchKernelGGL(k_art, dim3(e->sxc / 64), dim3(64), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino[TOMO_SINO_B], e->d_rowinner, beta, (int)e->nrows, e->sx, d_order);
+    hipLaunchKernelGGL(k_art, dim3(e->sxc / 64), dim3(64 * ART_WAVES), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino[TOMO_SINO_B], e->d_rowinner, beta, (int)e->nrows, e->sx, d_order);
     LAUNCHCHK();
     int rc = tomo_positivity(e, TOMO_VOL_RECON);
     if (!rc && order_host) HIPCHK(hipStreamSynchronize(e->stream));   // the staging buffer holds the order until the sweep is done

@@ -9,7 +9,7 @@ from tomo_tv_amd._lib import VOL_ORIGINAL, VOL_RECON, VOL_YK
 from tomo_tv_amd import pytvlib
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--alg", default="fista", choices=["fista", "sirt", "sart", "kl"])
+ap.add_argument("--alg", default="fista", choices=["fista", "sirt", "sart", "kl", "art", "cgls"])
 ap.add_argument("--n", type=int, default=512)
 ap.add_argument("--nslice", type=int, default=512)
 ap.add_argument("--nproj", type=int, default=90)
@@ -37,6 +37,10 @@ def step(k, st):
         t.SIRT(1); return t.data_distance()
     if a.alg == "sart":
         t.SART(1.0, 1); return t.data_distance()
+    if a.alg == "art":
+        t.be.c("art", 0.5); return t.data_distance()
+    if a.alg == "cgls":
+        t.CGLS(1); return t.data_distance()
     return t.poisson_ML(0.1)
 st = {"t0": 1.0}
 step(0, st); t.synchronize()
