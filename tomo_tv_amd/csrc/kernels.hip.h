@@ -447,7 +447,14 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
     int off = chunk * (64 * VEC) + lane * VEC;
     uint32_t first = row_first[row], ns = row_nseg[row];
     V acc = vzero<VEC>();
-    for (uint32_t s = 0; s < ns; ++s) acc += *reinterpret_cast<const V *>(partial + (size_t)(first + s) * sx + off);
+    const float *pp = partial + (size_t)first * sx + off;
+    for (uint32_t s = 0; s < ns; s += 8) {            // 8 independent loads per trip, summed in segment order
+        V t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (s + u < ns) ? *reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx) : vzero<VEC>();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
     size_t o = (size_t)row * sx + off;
     V bv = *reinterpret_cast<const V *>(b + o);
     float rs = rowsum[row];
