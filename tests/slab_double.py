@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 import oracle
-from tomo_tv_amd._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COUNT, S_DD, S_GNORM, S_TV, SINO_B, SINO_G, VOL_ORIGINAL,
+from tomo_tv_amd._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COST, S_COUNT, S_DD, S_GNORM, S_TV, SINO_B, SINO_G, VOL_ORIGINAL,
                               VOL_RECON, VOL_TEMP)
 
 
@@ -30,6 +30,8 @@ class OracleSlabBackend:
         self.t = oracle.ctvlib(nslice, nray, nproj)
         self.t.load_A(A)
         self.vol = {VOL_RECON: self.t.recon}
+        self.sino = {}
+        self.fgp_target = VOL_RECON
         self.scal = torch.zeros(S_COUNT, dtype=torch.float64)
         npix = nray * nray
         self.halo_lo, self.halo_hi = torch.zeros(npix), torch.zeros(npix)
@@ -155,6 +157,7 @@ class OracleSlabBackend:
             np.maximum(self.t.recon, 0, out=self.t.recon)
 
     def c_fgp_begin(self):
+        self.fgp_target = VOL_RECON
         z = lambda: np.zeros_like(self.t.recon)  # noqa: E731
         self.fields = {FIELD_FGP_D: z(), FIELD_FGP_P1: z(), "P2": z(), "P3": z()}
 
@@ -167,7 +170,7 @@ class OracleSlabBackend:
         v2[:, 1:, :] = P2[:, :-1, :]
         v3 = np.zeros_like(P3)
         v3[:, :, 1:] = P3[:, :, :-1]
-        d = self.t.recon - np.float32(lam) * (P1 + P2 + P3 - v1 - v2 - v3)
+        d = self._v(self.fgp_target) - np.float32(lam) * (P1 + P2 + P3 - v1 - v2 - v3)
         self.fields[FIELD_FGP_D] = np.maximum(d, 0).astype(np.float32)
 
     def c_fgp_grad(self, lam):
@@ -190,4 +193,87 @@ class OracleSlabBackend:
         self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"] = a * sq, b * sq, c * sq
 
     def c_fgp_end(self, iters):
-        self.t.recon[:] = self.fields[FIELD_FGP_D]
+        self._v(self.fgp_target)[:] = self.fields[FIELD_FGP_D]
+
+    # ---- generic slots + multimodal primitives (tests/test_distributed_gloo.py::test_sharded_multimodal) -----
+    def _s(self, sid):
+        if sid == SINO_B:
+            return self.t.b
+        if sid == SINO_G:
+            return self.t.g
+        if sid not in self.sino:
+            self.sino[sid] = np.zeros_like(self.t.b)
+        return self.sino[sid]
+
+    def c_set_sinogram(self, sid, ptr):
+        self._s(sid)[:] = _arr(ptr, self.t.b.shape)
+
+    def c_get_sinogram(self, sid, ptr):
+        _arr(ptr, self.t.b.shape)[:] = self._s(sid)
+
+    def c_forward_projection(self, vid, sid):
+        v = np.ascontiguousarray(self._v(vid))
+        out = np.empty_like(self.t.b)
+        oracle.lib().orc_forward(self.nslice, self.t.Nrow, self.t.Ncol, *self.t._a(), oracle._p(v), oracle._p(out))
+        self._s(sid)[:] = out
+
+    def c_back_projection(self, sid, vid):
+        self._v(vid)[:] = self.t.back_projection(self._s(sid))
+
+    def c_sirt_data(self, vid, sid, niter):
+        keep_b, keep_r = self.t.b, self.t.recon
+        self.t.b, self.t.recon = np.ascontiguousarray(self._s(sid)), np.ascontiguousarray(self._v(vid).copy())
+        self.t.SIRT_norm(niter)
+        self._v(vid)[:] = self.t.recon
+        self.t.b, self.t.recon = keep_b, keep_r
+
+    def c_poisson_residual(self, vid, sid_b, sid_out):
+        self.c_forward_projection(vid, 9999)
+        ax, b = self.sino[9999], self._s(sid_b)
+        eps = np.float32(0.1)
+        self._s(sid_out)[:] = (ax - b) / (ax + eps)
+        self.scal[S_COST] = float((ax - b * np.log(ax + eps, dtype=np.float32)).astype(np.float64).sum())
+
+    def c_scale_volume(self, vid, f):
+        self._v(vid)[:] = self._v(vid) * np.float32(f)
+
+    def c_sino_diff_norm_sq(self, a, b, slot):
+        d = self._s(a).astype(np.float64) - self._s(b)
+        self.scal[slot] = float((d ** 2).sum())
+
+    def c_sino_proj_max(self, sid, ptr):
+        g = self._s(sid).reshape(self.nslice, self.nproj, self.nray)
+        _arr(ptr, (self.nproj,))[:] = g.max(axis=(0, 2))
+
+    def c_sino_proj_scale(self, sid, pdiv, pmul):
+        g = self._s(sid).reshape(self.nslice, self.nproj, self.nray)
+        g[:] = (g / _arr(pdiv, (self.nproj,))[None, :, None]) * _arr(pmul, (self.nproj,))[None, :, None]
+
+    def c_fgp_begin_vol(self, vid):
+        self.fgp_target = vid
+        z = lambda: np.zeros_like(self.t.recon)  # noqa: E731
+        self.fields = {FIELD_FGP_D: z(), FIELD_FGP_P1: z(), "P2": z(), "P3": z()}
+
+    def share_stream_with(self, other):
+        pass
+
+    def lipschitz(self):
+        return self.t.lipschits()
+
+    def mm_model(self, xvols, w, gamma, he, model_vol):
+        acc = np.zeros_like(self.t.recon)
+        for e, v in enumerate(xvols):
+            x = self._v(int(v))
+            acc = acc + np.float32(w[e]) * (x if gamma == 1 else np.power(x, np.float32(gamma), dtype=np.float32))
+        he._v(model_vol)[:] = acc
+
+    def mm_update(self, xvols, uvols, w, gamma, lamC_over_L, lamH, he, upd_vol, model_vol):
+        F = np.float32
+        d = (he._v(upd_vol) - he._v(model_vol)) if lamH != 0 else 0
+        for e, (v, u) in enumerate(zip(xvols, uvols)):
+            x, uc = self._v(int(v)), self._v(int(u))
+            uh = F(w[e]) * d
+            if gamma != 1:
+                uh = (F(gamma) * np.power(x, F(gamma) - F(1), dtype=F)) * uh
+            x[:] = np.maximum(x - (F(lamC_over_L) * uc - F(lamH) * uh), 0)
+

@@ -100,6 +100,79 @@ def test_sharded_equals_single_process(tmp_path, world, Nx):
     assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
 
 
+def _mm_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.multimodal import multimodal as ref_multimodal
+        from slab_double import OracleSlabBackend
+        from tomo_tv_amd import chemistry, engine
+        from tomo_tv_amd.distributed import SlabComm
+        from tomo_tv_amd.phantom import ellipsoids
+
+        class ShardedEngine(engine.tomoengine):
+            _backend_cls = OracleSlabBackend
+
+        class ShardedMM(chemistry.multimodal):
+            _engine_cls = ShardedEngine
+
+        N, Nx, Nel = 16, 7, 2
+        ha, ca = np.linspace(-70, 70, 5), np.linspace(-60, 66, 4)
+        gt = np.stack([ellipsoids(Nx, N, seed=40 + e, k=6) * (0.5 + 0.4 * e) for e in range(Nel)])
+        w = chemistry.create_weighted_summation_weights([31, 8], 1.6, 3)
+        ref = ref_multimodal(Nx, N, Nel, ha, ca)
+        ref.w, ref.gamma = w.copy(), np.float32(1.6)
+        for e in range(Nel):
+            ref.bChem[e] = ref._fp(ref.C, gt[e])
+        ref.recon = gt.copy()
+        ref.bh = ref._fp(ref.H, ref.model())
+        ref.bh /= ref.bh.max()
+        ref.bChem /= ref.bChem.max()
+        ref.recon = np.zeros_like(gt)
+
+        dev = ShardedMM(Nx, N, Nel, np.deg2rad(ha), np.deg2rad(ca), comm=SlabComm())
+        dev.set_gamma(1.6)
+        dev.set_weights(w)
+        dev.set_haadf_tilt_series(ref.bh)
+        dev.set_chem_tilt_series(np.concatenate([ref.bChem[e] for e in range(Nel)], axis=1))
+        dev.set_measureChem(True)
+        dev.set_measureHaadf(True)
+        got, want = [], []
+        for _ in range(3):
+            got.append(dev.poisson_ml(0.05)); want.append(ref.poisson_ml(0.05))
+        dev.rescale_tomograms(10); ref.rescale_tomograms(10)
+        dev.rescale_projections(); ref.rescale_projections()
+        bh = dev.get_haadf_projections()
+        for _ in range(2):
+            h, c = dev.sirt_data_fusion(10, 0.05, 2)
+            hr, cr = ref.data_fusion(10, 0.05, 2)
+            got += [h, c]; want += [hr, cr]
+            got.append(dev.tv_fgp_4D(2, 1e-3)); want.append(ref.tv_fgp_4D(2, 1e-3))
+        got.append(dev.data_distance()); want.append(ref.data_distance())
+        vol = dev.get_volume()
+        if rank == 0:
+            np.savez(out_path, got=np.array(got), want=np.array(want), vol=vol, ref=ref.recon, bh=bh, ref_bh=ref.bh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_multimodal_equals_single_process(tmp_path):
+    """ChemicalTomo's engine sharded over 2 ranks: costs, per-projection max rescale (all-reduce max), 4-D FGP with halo
+    exchange and the fused update equal the single-process restatement of multimodal.cpp."""
+    out = str(tmp_path / "mm.npz")
+    mp.spawn(_mm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    assert np.allclose(r["got"], r["want"], rtol=2e-5), (r["got"], r["want"])
+    assert np.allclose(r["bh"], r["ref_bh"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(r["vol"], r["ref"], rtol=0, atol=5e-6)
+
+
 def test_slab_partition_covers_and_balances():
     from tomo_tv_amd.distributed import slab_partition
     for n in (1, 7, 8, 64, 1000, 1024):

@@ -53,16 +53,15 @@ class multimodal:
     """``multimodal(Nslice, Nray, Nelements, haadfAngles_rad, chemAngles_rad)`` -- multimodal.cpp:48-108."""
 
     eps = 1e-1  # multimodal.hpp:67
+    _engine_cls = tomoengine
 
     def __init__(self, Nslice, Nray, Nelements, haadfAngles, chemAngles, device=None, comm=None):
         self.Nslice_, self.Ny, self.Nz, self.Nel = int(Nslice), int(Nray), int(Nray), int(Nelements)
         if not 1 <= self.Nel <= 8:
             raise ValueError("1..8 elements supported")
-        self.he = tomoengine(Nslice, Nray, haadfAngles, device=device, comm=comm)
-        self.ce = tomoengine(Nslice, Nray, chemAngles, device=device, comm=comm)
-        st = ctypes.c_void_p()
-        check(self.ce.be.L.tomo_get_stream(self.ce.be.h, ctypes.byref(st)))
-        self.he.be.c("set_stream", st)
+        self.he = self._engine_cls(Nslice, Nray, haadfAngles, device=device, comm=comm)
+        self.ce = self._engine_cls(Nslice, Nray, chemAngles, device=device, comm=comm)
+        self.ce.be.share_stream_with(self.he.be)
         self.comm = comm
         self.NprojHaadf, self.NprojChem = self.he.Nproj, self.ce.Nproj
         self.NrowHaadf, self.NrowChem = self.he.Nrow, self.ce.Nrow
@@ -191,8 +190,7 @@ class multimodal:
 
     # ---- helpers -------------------------------------------------------------------------------------------
     def _mm_model(self):
-        check(self.ce.be.L.tomo_mm_model(self.ce.be.h, _ptr(self._x), self.Nel, _ptr(self.w), self.gamma_,
-                                         self.he.be.h, self.MODEL))
+        self.ce.be.mm_model(self._x, self.w, self.gamma_, self.he.be, self.MODEL)
 
     def _chem_gradient(self, measure):
         """u_e = BP_C((A x_e - b_e)/(A x_e + eps)); returns the Poisson cost when asked (multimodal.cpp:284-292)."""
@@ -214,8 +212,8 @@ class multimodal:
     def poisson_ml(self, lambdaCHEM):
         """multimodal.cpp:277-304."""
         cost = self._chem_gradient(self.measureChem_)
-        check(self.ce.be.L.tomo_mm_update(self.ce.be.h, _ptr(self._x), _ptr(self._u), self.Nel, _ptr(self.w), self.gamma_,
-                                          float(lambdaCHEM) / self.L_Aps, 0.0, self.he.be.h, self.UPD, self.MODEL))
+        self.ce.be.mm_update(self._x, self._u, self.w, self.gamma_, float(lambdaCHEM) / self.L_Aps, 0.0, self.he.be,
+                             self.UPD, self.MODEL)
         return cost
 
     def data_fusion(self, lambdaHAADF, lambdaCHEM, nIter=1, method="SIRT"):
@@ -229,9 +227,8 @@ class multimodal:
         else:
             he.be.c("sart_data", self.UPD, SINO_B, 1.0, int(nIter), None)
         costCHEM = self._chem_gradient(self.measureChem_)
-        check(self.ce.be.L.tomo_mm_update(self.ce.be.h, _ptr(self._x), _ptr(self._u), self.Nel, _ptr(self.w), self.gamma_,
-                                          float(lambdaCHEM) / self.L_Aps, float(lambdaHAADF), he.be.h, self.UPD,
-                                          self.MODEL))
+        self.ce.be.mm_update(self._x, self._u, self.w, self.gamma_, float(lambdaCHEM) / self.L_Aps, float(lambdaHAADF),
+                             he.be, self.UPD, self.MODEL)
         costHAADF = 0.0
         if self.measureHaadf_:
             he.be.c("sino_diff_norm_sq", SINO_G, SINO_B, S_DD)

@@ -103,6 +103,24 @@ class _SlabBackend:
         self.c("get_slice", vol, s, _ptr(img))
         return torch.from_numpy(img).to(self._halo_lo.device)
 
+    def lipschitz(self):
+        L = ctypes.c_float(0)
+        check(self.L.tomo_lipschitz(self.h, ctypes.byref(L)))
+        return float(L.value)
+
+    # ---- multimodal (ChemicalTomo) element-wise steps across two engines (include/tomo_hip.h: tomo_mm_*) ----
+    def share_stream_with(self, other):
+        st = ctypes.c_void_p()
+        check(self.L.tomo_get_stream(self.h, ctypes.byref(st)))
+        other.c("set_stream", st)
+
+    def mm_model(self, xvols, w, gamma, he, model_vol):
+        check(self.L.tomo_mm_model(self.h, _ptr(xvols), len(xvols), _ptr(w), float(gamma), he.h, int(model_vol)))
+
+    def mm_update(self, xvols, uvols, w, gamma, lamC_over_L, lamH, he, upd_vol, model_vol):
+        check(self.L.tomo_mm_update(self.h, _ptr(xvols), _ptr(uvols), len(xvols), _ptr(w), float(gamma),
+                                    float(lamC_over_L), float(lamH), he.h, int(upd_vol), int(model_vol)))
+
 
 class _EngineBase:
     """Shared implementation; ``comm`` is None for one slab = whole volume."""
@@ -357,9 +375,7 @@ class _EngineBase:
         self.L_A = self.get_lipschitz()
 
     def get_lipschitz(self):
-        L = ctypes.c_float(0)
-        check(self.be.L.tomo_lipschitz(self.be.h, ctypes.byref(L)))
-        return float(L.value)
+        return self.be.lipschitz()
 
     def remove_momentum(self):
         self.momentum = False
