@@ -874,10 +874,12 @@ __device__ __forceinline__ float tv_ld(const float *__restrict__ x, const Halo &
     return x[(size_t)pix * sx + s];
 }
 
-template <int TZ>
+// WITH_TV: D(p) is exactly the TV integrand (ctvlib.cpp:336-367), so the first gradient pass of a tv_gd call also
+// returns the TV value "before descent" (tv_gd.cu:177-183) without a separate pass over the volume.
+template <int TZ, bool WITH_TV>
 __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x, Halo h, float *__restrict__ g,
                                                       double *__restrict__ part, float eps, int n, int nx, int sx,
-                                                      int yseg)
+                                                      int yseg, double *__restrict__ part_tv)
 {
     __shared__ float ring[4][TZ + 2][TVL_PITCH];      // x planes; row zi = column z0-1+zi, element si = slice s0-1+si
     __shared__ float rinv[2][TZ + 1][TVL_PITCH];      // R planes; rows zi = 0..TZ, elements si = 0..64
@@ -915,7 +917,8 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
         if (wave == 3 && lane < 2 * (TZ + 2)) ring[slot][lane >> 1][(lane & 1) ? 65 : 0] = vh;
     };
     // R of the plane in slot a, whose +y neighbour plane is in slot b
-    auto compute_r = [&](int a, int b, int rslot) {
+    double tvacc = 0.0;
+    auto compute_r = [&](int a, int b, int rslot, bool own_plane) {
         for (int e = threadIdx.x; e < (TZ + 1) * 65; e += 256) {
             int zi = e / 65, si = e - zi * 65;
             float c = ring[a][zi][si];
@@ -924,13 +927,14 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
             float d3 = c - ring[a][zi + 1][si];
             float D = sqrtf(eps + d1 * d1 + d2 * d2 + d3 * d3);
             rinv[rslot][zi][si] = 1.0f / D;
+            if (WITH_TV && own_plane && zi >= 1 && si >= 1 && z0 + zi - 1 < n && s0 + si - 1 < nx) tvacc += (double)D;
         }
     };
     fetch(y0 - 1); stash(0);
     fetch(y0);     stash(1);
     fetch(y0 + 1); stash(2);
     __syncthreads();
-    compute_r(0, 1, 0);                        // R(y0-1)
+    compute_r(0, 1, 0, false);                 // R(y0-1)
     double acc = 0.0;
     const int si = lane + 1;
     const int s = s0 + lane;
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
         int rc = (t + 1) & 1, rp = t & 1;                                      // R(y), R(y-1)
         bool more = y + 1 < y1;
         if (more) fetch(y + 2);                // in flight while this row is computed
-        compute_r(m1, m2, rc);
+        compute_r(m1, m2, rc, true);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < TZ / 4; ++q) {
@@ -961,6 +965,10 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
         __syncthreads();
     }
     block_accumulate(acc, part);
+    if (WITH_TV) {
+        __syncthreads();
+        block_accumulate(tvacc, part_tv);
+    }
 }
 
 // x -= dPOCS * g / ||g||   (ctvlib.cpp:452-458); gnorm2 = global sum g^2 on the device; optional clamp (:461)

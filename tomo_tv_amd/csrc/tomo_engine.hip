@@ -74,7 +74,7 @@ struct tomo_engine {
     float *stage = nullptr;
     size_t stage_bytes = 0;
     // scalars
-    double *d_scal = nullptr, *d_scal_own = nullptr, *d_part = nullptr, *d_part_aux = nullptr;
+    double *d_scal = nullptr, *d_scal_own = nullptr, *d_part = nullptr, *d_part_aux = nullptr, *d_part_tv = nullptr;
     hipStream_t aux = nullptr;                    // second stream for work that is independent of the main sequence
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool async_pending = false;
@@ -419,7 +419,7 @@ int tomo_destroy(tomo_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
-    void *ptrs[] = {e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -1068,32 +1068,43 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
     return reduce_end(e, TOMO_S_TV);
 }
 
-int tomo_tv_grad(tomo_engine *e, float eps)
+static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
 {
     NEED(e);
     float *x = e->vol[TOMO_VOL_RECON], *g; int rc;
     if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     Halo h{e->halo_lo, e->halo_hi};
+    if (with_tv && e->tv_lds != 8) with_tv = false;
+    if (with_tv) {
+        if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
+        HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
+    }
     {
         ProfScope ps(e, TOMO_K_TV_GRAD);
         if (e->tv_lds) {
             int yseg = 32;
-            if (const char *ys = std::getenv("TOMO_TV_YSEG")) yseg = std::max(1, std::atoi(ys));
             if (e->tv_lds == 16) {
                 dim3 grid((unsigned)(((e->n + 15) / 16) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
-                hipLaunchKernelGGL((k_tv_grad_lds<16>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg);
+                hipLaunchKernelGGL((k_tv_grad_lds<16, false>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr);
             } else {
                 dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
-                hipLaunchKernelGGL((k_tv_grad_lds<8>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg);
+                if (with_tv) hipLaunchKernelGGL((k_tv_grad_lds<8, true>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+                else hipLaunchKernelGGL((k_tv_grad_lds<8, false>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr);
             }
         } else {
             hipLaunchKernelGGL(k_tv_grad, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx);
         }
     }
     LAUNCHCHK();
+    if (with_tv) {
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part_tv, e->d_scal + TOMO_S_TV);
+        LAUNCHCHK();
+    }
     return reduce_end(e, TOMO_S_GNORM);
 }
+
+int tomo_tv_grad(tomo_engine *e, float eps) { return tv_grad_impl(e, eps, false); }
 
 int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp)
 {
@@ -1166,10 +1177,13 @@ int tomo_tv(tomo_engine *e, int vol, float eps)
 int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps)
 {
     int rc;
-    if ((rc = tomo_tv(e, TOMO_VOL_RECON, eps))) return rc;
+    // the TV value before descent comes out of the first gradient pass (its denominators are the TV integrand)
+    const bool fold_tv = ng > 0 && e && e->tv_lds == 8;
+    if (fold_tv) { if ((rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc; }
+    else if ((rc = tomo_tv(e, TOMO_VOL_RECON, eps))) return rc;
     for (int g = 0; g < ng; ++g) {
         if (g > 0 && (rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc;
-        if ((rc = tomo_tv_grad(e, eps))) return rc;
+        if ((rc = tv_grad_impl(e, eps, fold_tv && g == 0))) return rc;
         if ((rc = tomo_tv_update(e, dPOCS, g == ng - 1))) return rc;
     }
     if (ng <= 0) return tomo_positivity(e, TOMO_VOL_RECON);
