@@ -309,26 +309,19 @@ void build_segments(int N, int P, int seg_len, Tables &t)
             next_id += ns;
             maxseg_all = std::max(maxseg_all, ns);
         }
-        static const int order_mode = std::getenv("TOMO_SEG_ORDER") ? std::atoi(std::getenv("TOMO_SEG_ORDER")) : 0;
-        auto emit = [&](int g, uint32_t sidx) {
+        // group-major: the s-th segments of neighbouring rays run side by side, one ray group after another
+        // (a segment-major order over the whole angle measured the same)
+        for (int g = 0; g < ngroups; ++g) {
             auto &L = lists[g & 7];
             int j0 = g * G, j1 = std::min(N, j0 + G);
-            for (int j = j0; j < j1; ++j) {
-                size_t r = (size_t)i * N + j;
-                if (sidx >= t.row_nseg[r]) continue;
-                uint32_t kb = t.walk_ptr[r] + sidx * seg_len;
-                uint32_t ke = std::min(t.walk_ptr[r + 1], kb + (uint32_t)seg_len);
-                L.push_back({t.row_first[r] + sidx, kb, ke, 0});
-            }
-        };
-        if (order_mode == 1) {
-            // segment-major over the whole angle: the chip sweeps the image top to bottom
             for (uint32_t sidx = 0; sidx < maxseg_all; ++sidx)
-                for (int g = 0; g < ngroups; ++g) emit(g, sidx);
-        } else {
-            // group-major: the s-th segments of neighbouring rays run side by side, one ray group after another
-            for (int g = 0; g < ngroups; ++g)
-                for (uint32_t sidx = 0; sidx < maxseg_all; ++sidx) emit(g, sidx);
+                for (int j = j0; j < j1; ++j) {
+                    size_t r = (size_t)i * N + j;
+                    if (sidx >= t.row_nseg[r]) continue;
+                    uint32_t kb = t.walk_ptr[r] + sidx * seg_len;
+                    uint32_t ke = std::min(t.walk_ptr[r + 1], kb + (uint32_t)seg_len);
+                    L.push_back({t.row_first[r] + sidx, kb, ke, 0});
+                }
         }
         size_t Lmax = 0;
         for (auto &L : lists) Lmax = std::max(Lmax, L.size());
