@@ -74,3 +74,29 @@ def test_system_matrix_digest_config1():
         A = system_matrix(N, np.linspace(-70, 70, P))
         assert A.shape[1] == dig[key]["nnz"]
         assert hashlib.sha256(np.ascontiguousarray(A).tobytes()).hexdigest() == dig[key]["sha256"]
+
+
+def test_engine_creation_without_gpu_fails_loudly():
+    """No CPU fallback anywhere: on a box without a HIP device the engine refuses to exist."""
+    from tomo_tv_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from tomo_tv_amd.engine import tomoengine
+    with pytest.raises(_lib.TomoError, match="hip"):
+        tomoengine(4, 16, np.deg2rad([0.0, 30.0]))
+    from tomo_tv_amd.reconstructor import TomoGPU
+    with pytest.raises(_lib.TomoError):
+        TomoGPU(np.array([0.0, 30.0]), np.zeros((4, 16, 2), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import tomo_tv_amd.engine, tomo_tv_amd.reconstructor, tomo_tv_amd.chemistry, "
+            "tomo_tv_amd.pytvlib; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tomo_tv_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "tomo_oracle" not in src, f

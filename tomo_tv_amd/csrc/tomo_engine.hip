@@ -270,14 +270,14 @@ static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *
 }
 
 // ---- creation ----------------------------------------------------------------------------------------------
-static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out)
+static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
 {
     Tables t;
     std::string err;
     sort_rows(m);
-    if (!build_tables(m, e->n, e->np, t, err)) { delete e; return fail(TOMO_ERR_GEOMETRY, err); }
+    if (!build_tables(m, e->n, e->np, t, err)) return fail(TOMO_ERR_GEOMETRY, err);
     e->nnz = m.ptr[m.nrow];
-    if (e->nnz >= (int64_t)0xFFFFFFFFu) { delete e; return fail(TOMO_ERR_ARG, "matrix too large for 32-bit entry offsets"); }
+    if (e->nnz >= (int64_t)0xFFFFFFFFu) return fail(TOMO_ERR_ARG, "matrix too large for 32-bit entry offsets");
     e->lipschitz = t.lipschitz;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -334,6 +334,20 @@ static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out)
     HIPCHK(hipStreamSynchronize(e->stream));
     *out = e;
     return TOMO_OK;
+}
+
+extern "C" int tomo_destroy(tomo_engine *e);
+
+// a half-built engine is torn down again (device buffers, stream) and the first error is the one reported
+static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out)
+{
+    int rc = finish_create_impl(e, m, out);
+    if (rc) {
+        std::string first = g_err;
+        tomo_destroy(e);
+        g_err = first;
+    }
+    return rc;
 }
 
 static tomo_engine *new_engine(int nslice, int nray, int nproj, int device)
