@@ -347,14 +347,14 @@ class _EngineBase:
             self.be.c("positivity", VOL_RECON)
         return tv0
 
-    def tv_fgp(self, ng, lam):
-        """FGP-TV prox on recon (tv_fgp.cu:192-281); returns TV of the input."""
+    def tv_fgp(self, ng, lam, vol=VOL_RECON):
+        """FGP-TV prox on recon (tv_fgp.cu:192-281), or on another volume slot; returns TV of the input."""
         ng, lam = int(ng), float(lam)
         if self.comm is None:
-            self.be.c("tv_fgp", ng, lam)
+            self.be.c("tv_fgp_vol", vol, ng, lam)
             return self._scalar(S_TV)
-        tv0 = self._tv_of(VOL_RECON, 1e-6)
-        self.be.c("fgp_begin")
+        tv0 = self._tv_of(vol, 1e-6)
+        self.be.c("fgp_begin_vol", vol)
         for _ in range(ng):
             self._exchange(FIELD_FGP_P1)
             self.be.c("fgp_obj", lam)

@@ -103,13 +103,12 @@ class TomoGPU:
         for k in range(Niter):
             pytvlib.run(t, "fista")                       # gradient step on yk (or recon without momentum)
             if momentum:
-                t.be.c("copy_volume", VOL_RECON, VOL_YK)  # prox acts on the stepped point ...
-            t.tv_fgp(nTViter, lambda_param)
-            if momentum:
-                t.be.c("copy_volume", VOL_YK, VOL_RECON)  # ... and its result is what momentum extrapolates
+                t.tv_fgp(nTViter, lambda_param, vol=VOL_YK)   # the prox acts on the stepped point, in place ...
                 tk = 0.5 * (1 + np.sqrt(1 + 4 * t0 ** 2))
-                t.fista_momentum((t0 - 1) / tk)
+                t.fista_momentum((t0 - 1) / tk)               # ... and its result is what momentum extrapolates
                 t0 = tk
+            else:
+                t.tv_fgp(nTViter, lambda_param)
             if show_convergence:
                 self.cost[k] = 0.5 * t.data_distance() ** 2 + lambda_param * t.tv()
         return self.cost

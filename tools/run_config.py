@@ -26,9 +26,7 @@ elif a.alg == "kl":
 def step(k, st):
     if a.alg == "fista":
         pytvlib.run(t, "fista")
-        t.be.c("copy_volume", VOL_RECON, VOL_YK)
-        t.tv_fgp(10, 0.1)
-        t.be.c("copy_volume", VOL_YK, VOL_RECON)
+        t.tv_fgp(10, 0.1, vol=VOL_YK)
         tk = 0.5 * (1 + np.sqrt(1 + 4 * st["t0"] ** 2))
         t.fista_momentum((st["t0"] - 1) / tk)
         st["t0"] = tk
