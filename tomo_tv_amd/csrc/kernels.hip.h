@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void k_tv_grad(const float *__restrict__ x, Ha
 //  * every volume element is fetched once per workgroup column, the next row's loads fly during compute;
 //  * the four denominators of ctvlib.cpp:431-447 are one field, D(p) = sqrt(eps + sum_d (x_p - x_{p+d})^2),
 //    taken at p, p-i, p-j, p-k (same term order as the reference), so D is evaluated ONCE per voxel, its
-//    correctly-rounded reciprocal R = 1/D is shared through LDS, and the gradient is
+//    reciprocal R = 1/D (<= 1 ulp) is shared through LDS, and the gradient is
 //    g = (3c - x_ip - x_jp - x_kp) R(p) + (c - x_im) R(p-i) + (c - x_jm) R(p-j) + (c - x_km) R(p-k).
 //    (v * (1/D) instead of v / D: at most one ulp per term away from the reference's expression.)
 constexpr int TVL_TZ = 8;          // z-columns per workgroup of the FGP kernel (2 per wave)
@@ -925,8 +925,15 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
             float d1 = c - ring[a][zi][si + 1];
             float d2 = c - ring[b][zi][si];
             float d3 = c - ring[a][zi + 1][si];
-            float D = sqrtf(eps + d1 * d1 + d2 * d2 + d3 * d3);
-            rinv[rslot][zi][si] = 1.0f / D;
+            // R = 1/sqrt(q) from the hardware estimate plus one Newton step (<= 1 ulp); the IEEE sqrt followed by an
+            // IEEE division costs 10 % of the whole pass.  D = q R is the TV integrand.
+            // (explicit fma/mul intrinsics: the sequence must round identically in every instantiation of this kernel)
+            float q_ = __fmaf_rn(d3, d3, __fmaf_rn(d2, d2, __fmaf_rn(d1, d1, eps)));
+            float y_ = __frsqrt_rn(q_);
+            float e_ = __fmaf_rn(-__fmul_rn(q_, y_), __fmul_rn(0.5f, y_), 0.5f);   // 0.5 - 0.5 q y^2
+            float rr_ = __fmaf_rn(y_, e_, y_);                                      // y (1.5 - 0.5 q y^2)
+            float D = __fmul_rn(q_, rr_);
+            rinv[rslot][zi][si] = rr_;
             if (WITH_TV && own_plane && zi >= 1 && si >= 1 && z0 + zi - 1 < n && s0 + si - 1 < nx) tvacc += (double)D;
         }
     };
