@@ -298,6 +298,161 @@ __global__ __launch_bounds__(256) void k_fp_rows_g(const float *__restrict__ x, 
     }
 }
 
+// ---- forward projector, tile-stationary form: all angles from one LDS-resident image tile -----------------------
+// The ray-driven forms re-read every pixel once per angle through L1/L2 (nnz x 256 B per 64-slice chunk: 61 GB at
+// 512^3 x 90).  Here a workgroup stages a FT_TY x FT_TZ pixel tile x 64 slices (128 KiB) in LDS once and computes, for
+// every angle, the partial sums of the rays crossing the tile ("tile segments", host table sysmat.cpp:build_tiles);
+// k_fp_tile_reduce then adds a row's segments in ascending tile order (fixed order: bit-reproducible, no float
+// atomics) and applies the epilogue.  HBM traffic: the volume once + the partials written and read once
+// (~(1.3 (TY+TZ)/2 + 1)/(TY*TZ) of the volume per angle).
+// A lane group of 16 lanes x float4 (64 slices) owns one entry stream.  Entries arrive by coalesced vector loads,
+// 8 per group and batch (lanes 8-15 hold a second copy); inside a batch lane l takes the entries in the rotated
+// order l, l+1, ... (DPP row_ror), so no broadcast is needed: every lane still adds all 8, each to its own slices.
+// ds_read_b128 of 256-B pixel images is conflict-free at 256 B/clk whatever the pixels (MI355X_MICROARCH.md, LDS).
+constexpr int FT_TY = 16, FT_TZ = 32, FT_PIX = FT_TY * FT_TZ, FT_THREADS = 1024, FT_SLOTS = FT_THREADS / 16, FT_BATCH = 8;
+constexpr int FT_LDS_BYTES = (FT_PIX + 1) * 256;         // + one zero pixel for the padding entries
+
+template <int J> __device__ __forceinline__ uint32_t row_ror(uint32_t v)
+{
+    if (J == 0) return v;
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x120 + J, 0xf, 0xf, true);
+}
+
+__global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict__ x, const uint32_t *__restrict__ slot_ptr,
+                                                         const uint32_t *__restrict__ slot_seg0, const uint2 *__restrict__ tent,
+                                                         float *__restrict__ part, int n, int sx, int tiles_z, int ntiles,
+                                                         int chunk0, int ncp)
+{
+    typedef VecOf<4>::T V;
+    extern __shared__ V ft_tile[];                      // [FT_PIX + 1][16]
+    // all chunks of a tile run back to back on one XCD (workgroups b and b+8 share an XCD): they read the same table
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int tile = (l / ncp) * 8 + xcd, c = l % ncp;
+    if (tile >= ntiles) return;
+    const int ty = tile / tiles_z, tz = tile - ty * tiles_z;
+    const int t = threadIdx.x, gl = t & 15;
+    {
+        V v[FT_PIX / 64];
+#pragma unroll
+        for (int k = 0; k < FT_PIX / 64; ++k) {
+            int lp = (t >> 4) + 64 * k;
+            int y = ty * FT_TY + lp / FT_TZ, z = tz * FT_TZ + lp % FT_TZ;
+            v[k] = (y < n && z < n) ? *reinterpret_cast<const V *>(x + ((size_t)y * n + z) * sx + (size_t)(chunk0 + c) * 64 + gl * 4)
+                                    : vzero<4>();
+        }
+#pragma unroll
+        for (int k = 0; k < FT_PIX / 64; ++k) ft_tile[((t >> 4) + 64 * k) * 16 + gl] = v[k];
+        if (t < 16) ft_tile[FT_PIX * 16 + t] = vzero<4>();
+    }
+    __syncthreads();
+    const size_t slot = (size_t)tile * FT_SLOTS + (t >> 4);
+    const uint32_t b0 = slot_ptr[slot], b1 = slot_ptr[slot + 1];
+    uint32_t seg = slot_seg0[slot];
+    const uint2 *ep = tent + (size_t)b0 * FT_BATCH + (gl & 7);
+    const uint32_t nb = b1 - b0;
+    // FT_PF batches in flight, each in its own registers and reloaded in place once consumed (no rotation: a trip
+    // then waits only for the oldest load).  The table is padded by FT_PF batches, so the reload needs no bounds test;
+    // what lies past the stream's end is replaced by the zero entry.
+    const uint32_t zoff = (uint32_t)FT_PIX * 256u;
+    const char *base = reinterpret_cast<const char *>(ft_tile) + gl * 16;
+    V acc = vzero<4>();
+    uint2 e0 = ep[0], e1 = ep[FT_BATCH], e2 = ep[2 * FT_BATCH], e3 = ep[3 * FT_BATCH];
+    uint2 e4 = ep[4 * FT_BATCH], e5 = ep[5 * FT_BATCH], e6 = ep[6 * FT_BATCH], e7 = ep[7 * FT_BATCH];
+#define FT_LOAD(J) xv[J] = *reinterpret_cast<const V *>(base + row_ror<J>(off));
+#define FT_FMA(J) acc += __uint_as_float(row_ror<J>(wb)) * xv[J];
+#define FT_STEP(E, I)                                                                                     \
+    {                                                                                                     \
+        const bool in = b + (I) < nb;                      /* past the stream's end: the zero entry */   \
+        const uint32_t off = in ? (E.x & 0x7FFFFFFFu) : zoff, wb = in ? E.y : 0u;                         \
+        const bool last = in && (E.x >> 31) != 0;                                                         \
+        V xv[FT_BATCH];                                                                                   \
+        FT_LOAD(0) FT_LOAD(1) FT_LOAD(2) FT_LOAD(3) FT_LOAD(4) FT_LOAD(5) FT_LOAD(6) FT_LOAD(7)           \
+        E = ep[(size_t)(b + (I) + FT_PF) * FT_BATCH];                                                     \
+        FT_FMA(0) FT_FMA(1) FT_FMA(2) FT_FMA(3) FT_FMA(4) FT_FMA(5) FT_FMA(6) FT_FMA(7)                   \
+        if (last) {                                                                                       \
+            *reinterpret_cast<V *>(part + ((size_t)seg * ncp + c) * 64 + gl * 4) = acc;                   \
+            acc = vzero<4>();                                                                             \
+            ++seg;                                                                                        \
+        }                                                                                                 \
+    }
+    constexpr int FT_PF = 8;
+    for (uint32_t b = 0; __any(b < nb); b += FT_PF) {
+        FT_STEP(e0, 0) FT_STEP(e1, 1) FT_STEP(e2, 2) FT_STEP(e3, 3) FT_STEP(e4, 4) FT_STEP(e5, 5) FT_STEP(e6, 6) FT_STEP(e7, 7)
+    }
+#undef FT_STEP
+#undef FT_FMA
+#undef FT_LOAD
+}
+
+// row sums of the tile partials + epilogue.  LPR lanes x float4 cover LPR/16 chunks of one row; part = [seg][ncp][64]
+template <int LPR, int MODE>
+__global__ __launch_bounds__(256) void k_fp_tile_reduce(const float *__restrict__ part, const uint32_t *__restrict__ rsptr,
+                                                         const uint32_t *__restrict__ rsidx, const float *__restrict__ b,
+                                                         const float *__restrict__ rowsum, float *__restrict__ out,
+                                                         double *__restrict__ dpart, int nrows, int sx, int chunk0, int ncp)
+{
+    typedef VecOf<4>::T V;
+    constexpr int R = 64 / LPR, U = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPR, gl = lane - grp * LPR;
+    const int spans = ncp * 16 / LPR;                    // lane-group spans per row in this pass
+    int64_t item = ((int64_t)blockIdx.x * 4 + wave) * R + grp;
+    int row = (int)(item / spans), span = (int)(item - (int64_t)row * spans);
+    bool valid = row < nrows;
+    if (!__any(valid)) return;
+    if (!valid) row = 0;
+    uint32_t kb = rsptr[row], ke = valid ? rsptr[row + 1] : kb;
+    const float *pp = part + (size_t)span * (LPR * 4) + gl * 4;
+    V acc = vzero<4>();
+    uint32_t sidx[U], sn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sidx[u] = (kb + u < ke) ? rsidx[kb + u] : 0xFFFFFFFFu;
+    for (uint32_t k = kb; __any(k < ke); k += U) {
+        V pv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pv[u] = (sidx[u] != 0xFFFFFFFFu) ? *reinterpret_cast<const V *>(pp + (size_t)sidx[u] * ncp * 64) : vzero<4>();
+#pragma unroll
+        for (int u = 0; u < U; ++u) sn[u] = (k + U + u < ke) ? rsidx[k + U + u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += pv[u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sidx[u] = sn[u];
+    }
+    double local = 0.0;
+    if (valid) {
+        size_t o = (size_t)row * sx + (size_t)chunk0 * 64 + (size_t)span * (LPR * 4) + gl * 4;
+        if (MODE == FP_STORE) {
+            *reinterpret_cast<V *>(out + o) = acc;
+        } else {
+            V bv = *reinterpret_cast<const V *>(b + o);
+            V r;
+            if (MODE == FP_RESID) {
+                r = bv - acc;
+            } else if (MODE == FP_RESID_NORM) {
+                float rs = rowsum[row];
+                r = rs > 0.f ? (bv - acc) / rs : vzero<4>();
+            } else if (MODE == FP_DD) {
+                r = acc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { float d = acc[i] - bv[i]; local += (double)(d * d); }
+            } else {
+                const float eps = 1e-1f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a = acc[i], bb = bv[i];
+                    r[i] = (a - bb) / (a + eps);
+                    local += (double)(a - bb * logf(a + eps));
+                }
+            }
+            *reinterpret_cast<V *>(out + o) = r;
+        }
+    }
+    if (MODE == FP_DD || MODE == FP_POISSON) {
+        local = wave_sum(local);
+        if (lane == 0) atomicAdd(&dpart[blockIdx.x & (NPART - 1)], local);
+    }
+}
+
 // ---- voxel-driven back-projector, one angle (the SART update) ---------------------------------------
 // x[p][s] = max(0, x[p][s] + beta * (w0 r[j0][s] + w1 r[j1][s]) / (w0 + w1))
 // cell[p] = {j0, w0, j1, w1}: the (at most two) rays of this angle through pixel p.  r = this angle's

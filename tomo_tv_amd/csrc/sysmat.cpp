@@ -334,4 +334,149 @@ void build_segments(int N, int P, int seg_len, Tables &t)
     }
 }
 
+// Tile tables (see sysmat.h).  Per row the entries are stably regrouped by tile (ascending pixel inside a tile, the
+// order the row-driven kernels use).  The segments of a tile go longest first to the stream with the least work so
+// far, so the 64 lane groups of a workgroup finish together.
+void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t)
+{
+    constexpr int NS = Tables::TILE_SLOTS, NB = Tables::TILE_BATCH;
+    const int64_t nrows = (int64_t)N * P;
+    const int64_t nnz = m.ptr[nrows];
+    t.tile_ty = TY; t.tile_tz = TZ;
+    t.tiles_y = (N + TY - 1) / TY; t.tiles_z = (N + TZ - 1) / TZ;
+    const uint32_t ntiles = (uint32_t)t.tiles_y * t.tiles_z;
+    // pass 1 (threads over rows): entries regrouped by tile in a CSR-aligned temp, segments listed per row
+    std::vector<uint32_t> tmp_lpix(nnz ? nnz : 1);
+    std::vector<float> tmp_w(nnz ? nnz : 1);
+    struct RowSeg { uint32_t tile, cnt; };
+    std::vector<std::vector<RowSeg>> rsegs(nrows);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, nrows / 256));
+    auto work = [&](int th) {
+        std::vector<std::pair<uint32_t, uint32_t>> key;   // (tile, position in row)
+        for (int64_t r = nrows * th / nth; r < nrows * (th + 1) / nth; ++r) {
+            int64_t b = m.ptr[r], e = m.ptr[r + 1];
+            int n = (int)(e - b);
+            key.resize(n);
+            for (int k = 0; k < n; ++k) {
+                uint32_t p = m.col[b + k];
+                uint32_t y = p / (uint32_t)N, z = p - y * (uint32_t)N;
+                key[k] = {(y / TY) * (uint32_t)t.tiles_z + z / TZ, (uint32_t)k};
+            }
+            std::sort(key.begin(), key.end());
+            auto &rs = rsegs[r];
+            for (int k = 0; k < n; ++k) {
+                uint32_t p = m.col[b + key[k].second];
+                uint32_t y = p / (uint32_t)N, z = p - y * (uint32_t)N;
+                tmp_lpix[b + k] = (y % TY) * (uint32_t)TZ + z % TZ;
+                tmp_w[b + k] = m.val[b + key[k].second];
+                if (rs.empty() || rs.back().tile != key[k].first) rs.push_back({key[k].first, 0u});
+                rs.back().cnt++;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> thr;
+        for (int th = 1; th < nth; ++th) thr.emplace_back(work, th);
+        work(0);
+        for (auto &x : thr) x.join();
+    }
+    // pass 2: bucket the segments by tile
+    struct Ref { uint32_t cnt, row, src; };               // src = offset of the segment's entries in the temp
+    std::vector<uint32_t> tptr(ntiles + 1, 0);
+    size_t nseg = 0;
+    for (int64_t r = 0; r < nrows; ++r) { for (auto &s : rsegs[r]) tptr[s.tile + 1]++; nseg += rsegs[r].size(); }
+    for (uint32_t k = 0; k < ntiles; ++k) tptr[k + 1] += tptr[k];
+    std::vector<Ref> refs(nseg ? nseg : 1);
+    {
+        std::vector<uint32_t> fill(tptr.begin(), tptr.end() - 1);
+        for (int64_t r = 0; r < nrows; ++r) {
+            uint32_t src = (uint32_t)m.ptr[r];
+            for (auto &s : rsegs[r]) { refs[fill[s.tile]++] = {s.cnt, (uint32_t)r, src}; src += s.cnt; }
+        }
+    }
+    t.tile_nseg = (uint32_t)nseg;
+    t.rseg_ptr.assign(nrows + 1, 0);
+    for (int64_t r = 0; r < nrows; ++r) t.rseg_ptr[r + 1] = t.rseg_ptr[r] + (uint32_t)rsegs[r].size();
+    t.rseg_idx.assign(nseg ? nseg : 1, 0);
+    t.tile_slot_ptr.assign((size_t)ntiles * NS + 1, 0);
+    t.tile_slot_seg0.assign((size_t)ntiles * NS, 0);
+    // pass 3 (threads over tiles): deal segments to streams; sizes first, then the streams themselves
+    std::vector<std::vector<uint32_t>> deal(ntiles);      // per tile: refs index per stream, concatenated; sizes in cnts
+    std::vector<uint32_t> nbatch_of(ntiles * (size_t)NS, 0), nseg_of(ntiles * (size_t)NS, 0);
+    int nth2 = (int)std::min<uint32_t>(std::max(1u, std::min(hw, 32u)), std::max(1u, ntiles / 8));
+    auto deal_work = [&](int th) {
+        std::vector<uint32_t> order;
+        for (uint32_t k = ntiles * (uint64_t)th / nth2; k < ntiles * (uint64_t)(th + 1) / nth2; ++k) {
+            uint32_t b = tptr[k], e = tptr[k + 1];
+            order.resize(e - b);
+            for (uint32_t i = 0; i < e - b; ++i) order[i] = b + i;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                return refs[x].cnt != refs[y].cnt ? refs[x].cnt > refs[y].cnt : refs[x].row < refs[y].row; });
+            uint32_t load[NS] = {0};
+            std::vector<uint32_t> lists[NS];
+            for (uint32_t idx : order) {
+                int best = 0;
+                for (int q = 1; q < NS; ++q) if (load[q] < load[best]) best = q;
+                load[best] += (refs[idx].cnt + NB - 1) / NB;
+                lists[best].push_back(idx);
+            }
+            auto &d = deal[k];
+            d.reserve(e - b);
+            for (int q = 0; q < NS; ++q) {
+                nbatch_of[(size_t)k * NS + q] = load[q];
+                nseg_of[(size_t)k * NS + q] = (uint32_t)lists[q].size();
+                d.insert(d.end(), lists[q].begin(), lists[q].end());
+            }
+        }
+    };
+    {
+        std::vector<std::thread> thr;
+        for (int th = 1; th < nth2; ++th) thr.emplace_back(deal_work, th);
+        deal_work(0);
+        for (auto &x : thr) x.join();
+    }
+    uint32_t segid = 0;
+    for (size_t q = 0; q < (size_t)ntiles * NS; ++q) {
+        t.tile_slot_ptr[q + 1] = t.tile_slot_ptr[q] + nbatch_of[q];
+        t.tile_slot_seg0[q] = segid;
+        segid += nseg_of[q];
+    }
+    const size_t nent = ((size_t)t.tile_slot_ptr.back() + 16) * NB;   // + 16 batches: the kernel prefetches past a stream's end
+    t.tile_off.assign(nent, 0u);
+    t.tile_w.assign(nent, 0.f);
+    auto emit_work = [&](int th) {
+        for (uint32_t k = ntiles * (uint64_t)th / nth2; k < ntiles * (uint64_t)(th + 1) / nth2; ++k) {
+            const auto &d = deal[k];
+            size_t di = 0;
+            for (int q = 0; q < NS; ++q) {
+                size_t slot = (size_t)k * NS + q;
+                size_t o = (size_t)t.tile_slot_ptr[slot] * NB;
+                uint32_t id = t.tile_slot_seg0[slot];
+                for (uint32_t i = 0; i < nseg_of[slot]; ++i, ++id) {
+                    const Ref &f = refs[d[di++]];
+                    uint32_t nb = (f.cnt + NB - 1) / NB;
+                    for (uint32_t j = 0; j < nb * NB; ++j) {
+                        uint32_t flag = (j >= (nb - 1) * NB) ? 0x80000000u : 0u;
+                        if (j < f.cnt) { t.tile_off[o] = (tmp_lpix[f.src + j] * (uint32_t)pixel_bytes) | flag; t.tile_w[o] = tmp_w[f.src + j]; }
+                        else { t.tile_off[o] = ((uint32_t)(TY * TZ) * (uint32_t)pixel_bytes) | flag; t.tile_w[o] = 0.f; }   // the image's spare zero pixel
+                        ++o;
+                    }
+                    // a row meets a tile once, so (row, tile) finds the slot in the row's ascending-tile list
+                    const auto &rs = rsegs[f.row];
+                    size_t lo = 0, hi = rs.size();
+                    while (lo + 1 < hi) { size_t mid = (lo + hi) / 2; if (rs[mid].tile <= k) lo = mid; else hi = mid; }
+                    t.rseg_idx[t.rseg_ptr[f.row] + lo] = id;
+                }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> thr;
+        for (int th = 1; th < nth2; ++th) thr.emplace_back(emit_work, th);
+        emit_work(0);
+        for (auto &x : thr) x.join();
+    }
+}
+
 }  // namespace tomo

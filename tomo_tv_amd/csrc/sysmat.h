@@ -37,6 +37,21 @@ struct Tables {
     std::vector<uint32_t> row_first;             // [P*N] first partial-sum id of the row (within its angle)
     std::vector<uint32_t> row_nseg;              // [P*N]
     uint32_t max_items_per_angle = 0;
+    // Tile-stationary all-angle projector: the matrix re-sorted by (image tile, row).  A "tile segment" is the part of
+    // one ray inside one tile; its partial ray sum is computed from the tile held in LDS, the row's segments are then
+    // summed in ascending tile order.  A tile's segments are dealt to TILE_SLOTS entry streams of equal length (one
+    // per 16-lane group of the workgroup); a stream is a run of batches of TILE_BATCH entries, every segment padded
+    // to whole batches with zero weights.  Entry = {byte offset of the pixel in the LDS tile image | last-batch-of-
+    // segment flag << 31, weight}.  Partial-sum ids count segments in stream order.
+    static constexpr int TILE_SLOTS = 64, TILE_BATCH = 8;
+    int tile_ty = 0, tile_tz = 0, tiles_y = 0, tiles_z = 0;
+    uint32_t tile_nseg = 0;
+    std::vector<uint32_t> tile_slot_ptr;         // [ntiles*TILE_SLOTS + 1] first batch of a stream
+    std::vector<uint32_t> tile_slot_seg0;        // [ntiles*TILE_SLOTS]     partial-sum id of its first segment
+    std::vector<uint32_t> tile_off;              // [nbatch*TILE_BATCH]
+    std::vector<float> tile_w;                   // [nbatch*TILE_BATCH]
+    std::vector<uint32_t> rseg_ptr;              // [P*N + 1] segments of a row ...
+    std::vector<uint32_t> rseg_idx;              // [nseg]    ... as partial-sum ids, ascending tile
 };
 
 void build_parallel_ray(int N, int P, const double *angles_rad, Coo &out);
@@ -46,5 +61,6 @@ void sort_rows(Coo &m);
 bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err);
 void build_walk(const Coo &m, int N, int P, Tables &t);
 void build_segments(int N, int P, int seg_len, Tables &t);
+void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t);
 
 }  // namespace tomo

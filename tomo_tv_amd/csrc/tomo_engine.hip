@@ -59,6 +59,14 @@ struct tomo_engine {
     float *seg_partial = nullptr;
     uint32_t max_items = 0;
     float *sart_alt = nullptr;                    // ping-pong partner of the volume being swept
+    // tile-stationary all-angle FP (k_fp_tile): tables, partial-sum scratch (one per stream that can run it)
+    int fp_tile = 1, ft_tiles_z = 0, ft_ntiles = 0;
+    uint32_t ft_nseg = 0;
+    uint32_t *d_ft_slot_ptr = nullptr, *d_ft_slot_seg0 = nullptr, *d_ft_rsptr = nullptr, *d_ft_rsidx = nullptr;
+    uint2 *d_ft_tent = nullptr;
+    float *ft_part = nullptr, *ft_part_aux = nullptr;
+    int ft_ncp = 0;                               // slice chunks per pass (bounds the scratch)
+    size_t ft_scratch_cap = (size_t)4 << 30;
     // fields
     float *vol[TOMO_VOL_SLOTS] = {};
     float *sino[TOMO_SINO_SLOTS] = {};
@@ -198,6 +206,52 @@ static int launch_fp(tomo_engine *e, const float *x, int row0, int nrows, const 
     return TOMO_OK;
 }
 
+// all-angle FP: tile-stationary form (k_fp_tile + k_fp_tile_reduce) unless switched off, else the ray-driven form
+template <int MODE>
+static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *out)
+{
+    if (!e->fp_tile) return launch_fp<MODE>(e, x, 0, (int)e->nrows, b, out, e->fp_all_lpr);
+    const int nchunk = e->sxc / 64;
+    if (!e->ft_ncp) {
+        size_t per_chunk = (size_t)std::max<uint32_t>(1, e->ft_nseg) * 64 * sizeof(float);
+        int ncp = (int)std::min<size_t>(nchunk, std::max<size_t>(1, e->ft_scratch_cap / per_chunk));
+        if (ncp >= 4) ncp &= ~3; else if (ncp >= 2) ncp &= ~1;
+        e->ft_ncp = ncp;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_fp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FT_LDS_BYTES));
+            attr_set = true;
+        }
+    }
+    float **slot = (e->aux && e->stream == e->aux) ? &e->ft_part_aux : &e->ft_part;
+    if (!*slot) {
+        int rc = dev_alloc((void **)slot, (size_t)std::max<uint32_t>(1, e->ft_nseg) * e->ft_ncp * 64 * sizeof(float), false, e->stream);
+        if (rc) return rc;
+    }
+    float *part = *slot;
+    for (int c0 = 0; c0 < nchunk; c0 += e->ft_ncp) {
+        int ncp = std::min(e->ft_ncp, nchunk - c0);
+        {
+            ProfScope ps(e, TOMO_K_FP_TILE);
+            dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * ncp)), block(FT_THREADS);
+            hipLaunchKernelGGL(k_fp_tile, grid, block, FT_LDS_BYTES, e->stream, x, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, part,
+                               e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, c0, ncp);
+            LAUNCHCHK();
+        }
+        int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
+        int64_t items = (int64_t)e->nrows * (ncp * 16 / lpr);
+        int64_t waves = (items + 64 / lpr - 1) / (64 / lpr);
+        dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        switch (lpr) {
+        case 64: hipLaunchKernelGGL((k_fp_tile_reduce<64, MODE>), grid, block, 0, e->stream, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+        case 32: hipLaunchKernelGGL((k_fp_tile_reduce<32, MODE>), grid, block, 0, e->stream, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+        default: hipLaunchKernelGGL((k_fp_tile_reduce<16, MODE>), grid, block, 0, e->stream, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+        }
+        LAUNCHCHK();
+    }
+    return TOMO_OK;
+}
+
 constexpr int BP_PPW = 4;
 
 static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_angle, float beta)
@@ -320,6 +374,24 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_row_first, t.row_first.data(), t.row_first.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_row_nseg, t.row_nseg.data(), t.row_nseg.size() * 4, hipMemcpyHostToDevice));
     }
+    {
+        build_tiles(m, e->n, e->np, FT_TY, FT_TZ, 256, t);
+        static_assert(Tables::TILE_SLOTS == FT_SLOTS && Tables::TILE_BATCH == FT_BATCH, "tile stream shape");
+        e->ft_tiles_z = t.tiles_z; e->ft_ntiles = t.tiles_y * t.tiles_z;
+        e->ft_nseg = t.tile_nseg;
+        std::vector<uint2> tent(t.tile_off.size());
+        for (size_t k = 0; k < tent.size(); ++k) { uint32_t bits; std::memcpy(&bits, &t.tile_w[k], 4); tent[k] = make_uint2(t.tile_off[k], bits); }
+        if ((rc = dev_alloc((void **)&e->d_ft_slot_ptr, t.tile_slot_ptr.size() * 4, false, e->stream))) return rc;
+        if ((rc = dev_alloc((void **)&e->d_ft_slot_seg0, std::max<size_t>(1, t.tile_slot_seg0.size()) * 4, false, e->stream))) return rc;
+        if ((rc = dev_alloc((void **)&e->d_ft_tent, tent.size() * sizeof(uint2), false, e->stream))) return rc;
+        if ((rc = dev_alloc((void **)&e->d_ft_rsptr, t.rseg_ptr.size() * 4, false, e->stream))) return rc;
+        if ((rc = dev_alloc((void **)&e->d_ft_rsidx, t.rseg_idx.size() * 4, false, e->stream))) return rc;
+        HIPCHK(hipMemcpy(e->d_ft_slot_ptr, t.tile_slot_ptr.data(), t.tile_slot_ptr.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_ft_slot_seg0, t.tile_slot_seg0.data(), t.tile_slot_seg0.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_ft_tent, tent.data(), tent.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_ft_rsptr, t.rseg_ptr.data(), t.rseg_ptr.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
+    }
     static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
     HIPCHK(hipMemcpy(e->d_cell, t.cell.data(), t.cell.size() * sizeof(CellD), hipMemcpyHostToDevice));
     if ((rc = dev_alloc((void **)&e->d_scal_own, TOMO_S_COUNT * sizeof(double), true, e->stream))) return rc;
@@ -430,7 +502,7 @@ int tomo_destroy(tomo_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
-    void *ptrs[] = {e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -576,7 +648,7 @@ int tomo_forward_projection(tomo_engine *e, int vol, int sino)
     float *x, *g; int rc;
     if ((rc = get_vol(e, vol, &x))) return rc;
     if ((rc = sino_slot(e, sino, &g))) return rc;
-    return launch_fp<FP_STORE>(e, x, 0, (int)e->nrows, nullptr, g, e->fp_all_lpr);
+    return launch_fp_all<FP_STORE>(e, x, nullptr, g);
 }
 
 int tomo_back_projection(tomo_engine *e, int sino, int vol)
@@ -598,7 +670,7 @@ int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter)
     float *x, *r; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, e->sino[TOMO_SINO_B], r, e->fp_all_lpr))) return rc;
+        if ((rc = launch_fp_all<FP_RESID>(e, x, e->sino[TOMO_SINO_B], r))) return rc;
         if ((rc = launch_bp_all(e, x, r, nullptr, 1.f, beta, 1))) return rc;
     }
     return TOMO_OK;
@@ -612,7 +684,7 @@ int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter)
     float *x, *r, *b; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, sino_b, &b))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if ((rc = launch_fp<FP_RESID_NORM>(e, x, 0, (int)e->nrows, b, r, e->fp_all_lpr))) return rc;
+        if ((rc = launch_fp_all<FP_RESID_NORM>(e, x, b, r))) return rc;
         if ((rc = launch_bp_all(e, x, r, e->d_colsum_all, 1.f, 1.f, 1))) return rc;
     }
     return TOMO_OK;
@@ -708,7 +780,7 @@ int tomo_poisson_residual(tomo_engine *e, int vol, int sino_b, int sino_out)
     float *x, *b, *r; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = sino_slot(e, sino_b, &b)) || (rc = sino_slot(e, sino_out, &r))) return rc;
     if ((rc = reduce_begin(e))) return rc;
-    if ((rc = launch_fp<FP_POISSON>(e, x, 0, (int)e->nrows, b, r, e->fp_all_lpr))) return rc;
+    if ((rc = launch_fp_all<FP_POISSON>(e, x, b, r))) return rc;
     return reduce_end(e, TOMO_S_COST);
 }
 
@@ -740,13 +812,13 @@ int tomo_cgls(tomo_engine *e, int vol, int niter)
         hipLaunchKernelGGL(k_slice_ratio, dim3((e->sx + 255) / 256), dim3(256), 0, e->stream, num, den, e->cg_coef, e->sx);
     };
     // r = b - A x ; z = A^T r ; p = z ; gamma = |z|^2
-    if ((rc = launch_fp<FP_RESID>(e, x, 0, (int)e->nrows, b, r, e->fp_all_lpr))) return rc;
+    if ((rc = launch_fp_all<FP_RESID>(e, x, b, r))) return rc;
     if ((rc = launch_bp_all(e, e->cg_z, r, nullptr, 0.f, 1.f, 0))) return rc;
     HIPCHK(hipMemcpyAsync(e->cg_p, e->cg_z, nv * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     if ((rc = slice_sumsq(e, e->cg_z, e->npix, gam))) return rc;
     for (int it = 0; it < niter; ++it) {
         // w = A p ; alpha = gamma / |w|^2 ; x += alpha p ; r -= alpha w
-        if ((rc = launch_fp<FP_STORE>(e, e->cg_p, 0, (int)e->nrows, nullptr, e->cg_w, e->fp_all_lpr))) return rc;
+        if ((rc = launch_fp_all<FP_STORE>(e, e->cg_p, nullptr, e->cg_w))) return rc;
         if ((rc = slice_sumsq(e, e->cg_w, e->nrows, tmp))) return rc;
         ratio(gam, tmp);
         hipLaunchKernelGGL(k_slice_axpy, dim3(grid_1d(nv / 4)), dim3(256), 0, e->stream, x, e->cg_p, e->cg_coef, 1.f, nv, e->sx);
@@ -937,7 +1009,7 @@ int tomo_data_distance_sq(tomo_engine *e, int vol)
     float *x, *g; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
-    if ((rc = launch_fp<FP_DD>(e, x, 0, (int)e->nrows, e->sino[TOMO_SINO_B], g, e->fp_all_lpr))) return rc;
+    if ((rc = launch_fp_all<FP_DD>(e, x, e->sino[TOMO_SINO_B], g))) return rc;
     return reduce_end(e, TOMO_S_DD);
 }
 
@@ -1244,6 +1316,11 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_tile_scratch_mib") == 0) {   // cap of the partial-sum scratch; takes effect before the first all-angle FP
+        if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
+        e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; return TOMO_OK;
+    }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 0 direct, 8 / 16 = z-columns per workgroup
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }

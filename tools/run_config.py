@@ -14,8 +14,12 @@ ap.add_argument("--n", type=int, default=512)
 ap.add_argument("--nslice", type=int, default=512)
 ap.add_argument("--nproj", type=int, default=90)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--opt", action="append", default=[], help="engine option name=int, repeatable")
 a = ap.parse_args()
 t = tomoengine(a.nslice, a.n, np.deg2rad(tilt_angles(a.nproj)))
+for kv in a.opt:
+    k, v = kv.split("=")
+    t.set_option(k, int(v))
 t.set_volume(ellipsoids(a.nslice, a.n), VOL_ORIGINAL)
 t.create_projections()
 t.restart_recon()
