@@ -321,7 +321,7 @@ template <int J> __device__ __forceinline__ uint32_t row_ror(uint32_t v)
 __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict__ x, const uint32_t *__restrict__ slot_ptr,
                                                          const uint32_t *__restrict__ slot_seg0, const uint2 *__restrict__ tent,
                                                          float *__restrict__ part, int n, int sx, int tiles_z, int ntiles,
-                                                         int chunk0, int ncp)
+                                                         int chunk0, int ncp, int dbg)
 {
     typedef VecOf<4>::T V;
     extern __shared__ V ft_tile[];                      // [FT_PIX + 1][16]
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
         for (int k = 0; k < FT_PIX / 64; ++k) {
             int lp = (t >> 4) + 64 * k;
             int y = ty * FT_TY + lp / FT_TZ, z = tz * FT_TZ + lp % FT_TZ;
-            v[k] = (y < n && z < n) ? *reinterpret_cast<const V *>(x + ((size_t)y * n + z) * sx + (size_t)(chunk0 + c) * 64 + gl * 4)
+            v[k] = (y < n && z < n && !(dbg & 2)) ? *reinterpret_cast<const V *>(x + ((size_t)y * n + z) * sx + (size_t)(chunk0 + c) * 64 + gl * 4)
                                     : vzero<4>();
         }
 #pragma unroll
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
         FT_LOAD(0) FT_LOAD(1) FT_LOAD(2) FT_LOAD(3) FT_LOAD(4) FT_LOAD(5) FT_LOAD(6) FT_LOAD(7)           \
         E = ep[(size_t)(b + (I) + FT_PF) * FT_BATCH];                                                     \
         FT_FMA(0) FT_FMA(1) FT_FMA(2) FT_FMA(3) FT_FMA(4) FT_FMA(5) FT_FMA(6) FT_FMA(7)                   \
-        if (last) {                                                                                       \
+        if (last && !(dbg & 1)) {                                                                         \
             *reinterpret_cast<V *>(part + ((size_t)seg * ncp + c) * 64 + gl * 4) = acc;                   \
             acc = vzero<4>();                                                                             \
             ++seg;                                                                                        \
@@ -670,6 +670,109 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
             *reinterpret_cast<V *>(xp) = nv;
         }
     }
+}
+
+// ---- back-projector, all angles, tile-stationary form ------------------------------------------------------------
+// k_bp_all gathers 2 x 256 B per pixel, angle and 64-slice chunk from L2 (96 GB at 512^3 x 90).  Here a workgroup owns
+// a FT_TY x FT_TZ pixel tile x 64 slices, keeps the 512 x 64 sums in registers (8 pixels per 16-lane group) and stages,
+// FB_A angles at a time and double-buffered, the window of residual rows that cross the tile (<= FB_MAXR per angle)
+// in LDS; the two row reads per pixel and angle then come from LDS.  Cells {row offset, weight} x 2 arrive by
+// coalesced loads, 8 pixels per group and angle, and are shared by DPP row rotation as in k_fp_tile: at step J lane l
+// works on pixel (l + J) mod 8 of its group, always into acc[J], so the sums never move between lanes.
+// Same two FMAs per pixel and angle in the same order as k_bp_all: results are bit-identical.
+constexpr int FB_A = 4, FB_MAXR = 40, FB_BUF = (FB_A * FB_MAXR + 1) * 256, FB_LDS_BYTES = 2 * FB_BUF;
+constexpr int FB_SLOTS = FB_A * FB_MAXR * 16, FB_Q = (FB_SLOTS + FT_THREADS - 1) / FT_THREADS;
+
+__global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, const uint4 *__restrict__ tcell,
+                                                         const uint32_t *__restrict__ win, const float *__restrict__ r,
+                                                         const float *__restrict__ colsum, float alpha, float beta, int clamp,
+                                                         int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk)
+{
+    typedef VecOf<4>::T V;
+    extern __shared__ V fb_lds[];
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int tile = (l / nchunk) * 8 + xcd, c = l % nchunk;
+    if (tile >= ntiles) return;
+    const int ty = tile / tiles_z, tz = tile - ty * tiles_z;
+    const int t = threadIdx.x, gl = t & 15, g = t >> 4;
+    const uint32_t *wn = win + (size_t)tile * nproj;
+    const float *rc = r + (size_t)c * 64;
+    const int nstage = (nproj + FB_A - 1) / FB_A;
+    if (t < 16) { fb_lds[FB_A * FB_MAXR * 16 + t] = vzero<4>(); fb_lds[FB_BUF / 16 + FB_A * FB_MAXR * 16 + t] = vzero<4>(); }
+    V sreg[FB_Q];
+    bool sval[FB_Q];
+#define FB_STAGE_LOAD(S)                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < FB_Q; ++q) {                                                    \
+        int f = t + FT_THREADS * q;                                                                       \
+        int a = f / (FB_MAXR * 16), j = (f - a * (FB_MAXR * 16)) >> 4;                                    \
+        int i = (S) * FB_A + a;                                                                           \
+        sval[q] = false;                                                                                  \
+        if (f < FB_SLOTS && i < nproj) {                                                                  \
+            uint32_t w = wn[i];                                                                           \
+            if ((uint32_t)j < (w >> 16)) {                                                                \
+                sval[q] = true;                                                                           \
+                sreg[q] = *reinterpret_cast<const V *>(rc + ((size_t)i * n + (w & 0xFFFFu) + j) * sx + (f & 15) * 4); \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define FB_STAGE_STORE(B)                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < FB_Q; ++q)                                                      \
+        if (sval[q]) fb_lds[(B) * (FB_BUF / 16) + t + FT_THREADS * q] = sreg[q];
+    FB_STAGE_LOAD(0)
+    FB_STAGE_STORE(0)
+    __syncthreads();
+    const uint4 *cp = tcell + (size_t)tile * nproj * FT_PIX + g * 8 + (gl & 7);
+    uint4 e0 = cp[0], e1 = cp[FT_PIX], e2 = cp[2 * FT_PIX], e3 = cp[3 * FT_PIX];   // table padded by FB_A angles
+    V acc[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) acc[J] = vzero<4>();
+    const uint32_t zoff = FB_A * FB_MAXR * 256;
+#define FB_ROW(O, J) (*reinterpret_cast<const V *>(base + row_ror<J>(O)))
+#define FB_PAIR(J0)                                                                                       \
+    {                                                                                                     \
+        V a0 = FB_ROW(o0, J0), a1 = FB_ROW(o1, J0), b0 = FB_ROW(o0, J0 + 1), b1 = FB_ROW(o1, J0 + 1);     \
+        acc[J0] += __uint_as_float(row_ror<J0>(w0)) * a0;     acc[J0] += __uint_as_float(row_ror<J0>(w1)) * a1;         \
+        acc[J0 + 1] += __uint_as_float(row_ror<J0 + 1>(w0)) * b0; acc[J0 + 1] += __uint_as_float(row_ror<J0 + 1>(w1)) * b1; \
+        /* pin: pure FMAs carry no chain, the DAG would otherwise sink all of a stage's FMAs below all of its reads */ \
+        asm volatile("" : "+v"(acc[J0]), "+v"(acc[J0 + 1]));                                              \
+    }
+#define FB_STEP(E, I)                                                                                     \
+    {                                                                                                     \
+        const bool in = s * FB_A + (I) < nproj;                                                           \
+        const uint32_t o0 = in ? E.x : zoff, w0 = in ? E.y : 0u, o1 = in ? E.z : zoff, w1 = in ? E.w : 0u; \
+        E = cp[(size_t)(s * FB_A + (I) + FB_A) * FT_PIX];                                                 \
+        FB_PAIR(0) FB_PAIR(2) FB_PAIR(4) FB_PAIR(6)                                                       \
+    }
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) { FB_STAGE_LOAD(s + 1) }
+        const char *base = reinterpret_cast<const char *>(fb_lds) + (s & 1) * FB_BUF + gl * 16;
+        FB_STEP(e0, 0) FB_STEP(e1, 1) FB_STEP(e2, 2) FB_STEP(e3, 3)
+        if (s + 1 < nstage) { FB_STAGE_STORE((s + 1) & 1) }
+        __syncthreads();
+    }
+#undef FB_STEP
+#undef FB_PAIR
+#undef FB_ROW
+#undef FB_STAGE_STORE
+#undef FB_STAGE_LOAD
+    const int off = c * 64 + gl * 4;
+#define FB_OUT(J)                                                                                         \
+    {                                                                                                     \
+        int lp = g * 8 + (int)row_ror<J>((uint32_t)(gl & 7));                                             \
+        int y = ty * FT_TY + lp / FT_TZ, z = tz * FT_TZ + lp % FT_TZ;                                     \
+        if (y < n && z < n) {                                                                             \
+            size_t p = (size_t)y * n + z;                                                                 \
+            V a = acc[J];                                                                                 \
+            if (colsum) { float cs = colsum[p]; a = cs > 0.f ? a / cs : vzero<4>(); }                     \
+            float *xp = x + p * sx + off;                                                                 \
+            V nv = beta * a;                                                                              \
+            if (alpha != 0.f) nv = alpha * (*reinterpret_cast<const V *>(xp)) + nv;                       \
+            if (clamp) { nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f); } \
+            *reinterpret_cast<V *>(xp) = nv;                                                              \
+        }                                                                                                 \
+    }
+    FB_OUT(0) FB_OUT(1) FB_OUT(2) FB_OUT(3) FB_OUT(4) FB_OUT(5) FB_OUT(6) FB_OUT(7)
+#undef FB_OUT
 }
 
 // ---- ART (Kaczmarz), row-sequential by definition (ctvlib.cpp:137-155) -------------------------------

@@ -479,4 +479,54 @@ void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Ta
     }
 }
 
+// Back-projection tile tables (see sysmat.h); needs t.cell (build_tables).
+void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t)
+{
+    const int64_t npix = (int64_t)N * N;
+    const int tiles_y = (N + TY - 1) / TY, tiles_z = (N + TZ - 1) / TZ;
+    const uint32_t ntiles = (uint32_t)tiles_y * tiles_z;
+    const int TP = TY * TZ;
+    const uint32_t zero_off = (uint32_t)(stage_angles * max_rows) * (uint32_t)row_bytes;   // the zero row behind a stage buffer
+    t.bp_win.assign((size_t)ntiles * P, 0);
+    t.bp_cell.assign(((size_t)ntiles * P + pad_angles) * TP, Tables::TileCell{zero_off, 0.f, zero_off, 0.f});
+    std::vector<uint8_t> bad(ntiles, 0);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nth = (int)std::min<uint32_t>(std::max(1u, std::min(hw, 32u)), std::max(1u, ntiles / 8));
+    auto work = [&](int th) {
+        for (uint32_t k = ntiles * (uint64_t)th / nth; k < ntiles * (uint64_t)(th + 1) / nth; ++k) {
+            int y0 = (int)(k / tiles_z) * TY, z0 = (int)(k % tiles_z) * TZ;
+            for (int i = 0; i < P; ++i) {
+                const Cell *ci = t.cell.data() + (size_t)i * npix;
+                uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                for (int ly = 0; ly < TY && y0 + ly < N; ++ly)
+                    for (int lz = 0; lz < TZ && z0 + lz < N; ++lz) {
+                        const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
+                        if (c.w0 != 0.f) { lo = std::min(lo, c.r0); hi = std::max(hi, c.r0); }
+                        if (c.w1 != 0.f) { lo = std::min(lo, c.r1); hi = std::max(hi, c.r1); }
+                    }
+                uint32_t nr = (lo == 0xFFFFFFFFu) ? 0u : hi - lo + 1;
+                if (nr == 0) lo = 0;
+                if (nr > (uint32_t)max_rows) { bad[k] = 1; nr = 0; }
+                t.bp_win[(size_t)k * P + i] = lo | (nr << 16);
+                if (bad[k]) continue;
+                Tables::TileCell *out = t.bp_cell.data() + ((size_t)k * P + i) * TP;
+                uint32_t slot_base = (uint32_t)(i % stage_angles) * (uint32_t)max_rows * (uint32_t)row_bytes;
+                for (int ly = 0; ly < TY && y0 + ly < N; ++ly)
+                    for (int lz = 0; lz < TZ && z0 + lz < N; ++lz) {
+                        const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
+                        Tables::TileCell &o = out[ly * TZ + lz];
+                        if (c.w0 != 0.f) { o.off0 = slot_base + (c.r0 - lo) * (uint32_t)row_bytes; o.w0 = c.w0; }
+                        if (c.w1 != 0.f) { o.off1 = slot_base + (c.r1 - lo) * (uint32_t)row_bytes; o.w1 = c.w1; }
+                    }
+            }
+        }
+    };
+    std::vector<std::thread> thr;
+    for (int th = 1; th < nth; ++th) thr.emplace_back(work, th);
+    work(0);
+    for (auto &x : thr) x.join();
+    t.bp_tile_ok = true;
+    for (uint32_t k = 0; k < ntiles; ++k) if (bad[k]) t.bp_tile_ok = false;
+}
+
 }  // namespace tomo

@@ -52,6 +52,13 @@ struct Tables {
     std::vector<float> tile_w;                   // [nbatch*TILE_BATCH]
     std::vector<uint32_t> rseg_ptr;              // [P*N + 1] segments of a row ...
     std::vector<uint32_t> rseg_idx;              // [nseg]    ... as partial-sum ids, ascending tile
+    // Tile-stationary all-angle back-projector: per (tile, angle) the window of rays that cross the tile (staged in
+    // LDS by the kernel) and the cell table regrouped by tile, ray numbers replaced by byte offsets into the staged
+    // window (slot (angle % stage_angles), row (ray - first ray of the window)); weight 0 -> the zero row that ends a buffer.
+    struct TileCell { uint32_t off0; float w0; uint32_t off1; float w1; };
+    bool bp_tile_ok = false;                     // false: some window exceeds max_rows (kernel falls back)
+    std::vector<uint32_t> bp_win;                // [ntiles * P]  first ray | rays << 16
+    std::vector<TileCell> bp_cell;               // [(ntiles * P + pad) * TY*TZ], pixel order inside a tile: y-major
 };
 
 void build_parallel_ray(int N, int P, const double *angles_rad, Coo &out);
@@ -62,5 +69,6 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err);
 void build_walk(const Coo &m, int N, int P, Tables &t);
 void build_segments(int N, int P, int seg_len, Tables &t);
 void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t);
+void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t);
 
 }  // namespace tomo

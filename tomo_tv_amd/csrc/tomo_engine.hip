@@ -60,11 +60,15 @@ struct tomo_engine {
     uint32_t max_items = 0;
     float *sart_alt = nullptr;                    // ping-pong partner of the volume being swept
     // tile-stationary all-angle FP (k_fp_tile): tables, partial-sum scratch (one per stream that can run it)
-    int fp_tile = 1, ft_tiles_z = 0, ft_ntiles = 0;
+    int fp_tile = 1, ft_tiles_z = 0, ft_ntiles = 0, ft_debug = 0;
     uint32_t ft_nseg = 0;
     uint32_t *d_ft_slot_ptr = nullptr, *d_ft_slot_seg0 = nullptr, *d_ft_rsptr = nullptr, *d_ft_rsidx = nullptr;
     uint2 *d_ft_tent = nullptr;
     float *ft_part = nullptr, *ft_part_aux = nullptr;
+    int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
+    bool fb_ok = false;
+    uint4 *d_fb_cell = nullptr;
+    uint32_t *d_fb_win = nullptr;
     int ft_ncp = 0;                               // slice chunks per pass (bounds the scratch)
     size_t ft_scratch_cap = (size_t)4 << 30;
     // fields
@@ -235,7 +239,7 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
             ProfScope ps(e, TOMO_K_FP_TILE);
             dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * ncp)), block(FT_THREADS);
             hipLaunchKernelGGL(k_fp_tile, grid, block, FT_LDS_BYTES, e->stream, x, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, part,
-                               e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, c0, ncp);
+                               e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, c0, ncp, e->ft_debug);
             LAUNCHCHK();
         }
         int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
@@ -310,6 +314,19 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
 
 static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
 {
+    if (e->bp_tile && e->fb_ok) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_bp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES));
+            attr_set = true;
+        }
+        const int nchunk64 = e->sxc / 64;
+        dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * nchunk64)), block(FT_THREADS);
+        hipLaunchKernelGGL(k_bp_tile, grid, block, FB_LDS_BYTES, e->stream, x, e->d_fb_cell, e->d_fb_win, r, colsum, alpha, beta, clamp,
+                           e->np, e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, nchunk64);
+        LAUNCHCHK();
+        return TOMO_OK;
+    }
     int nchunk = e->sxc / (64 * e->vec);
     int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
     int64_t waves = (int64_t)ngroups * nchunk;
@@ -391,6 +408,15 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_ft_tent, tent.data(), tent.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsptr, t.rseg_ptr.data(), t.rseg_ptr.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
+        build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, FB_A, t);
+        static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
+        e->fb_ok = t.bp_tile_ok;
+        if (e->fb_ok) {
+            if ((rc = dev_alloc((void **)&e->d_fb_cell, t.bp_cell.size() * sizeof(uint4), false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_fb_win, t.bp_win.size() * 4, false, e->stream))) return rc;
+            HIPCHK(hipMemcpy(e->d_fb_cell, t.bp_cell.data(), t.bp_cell.size() * sizeof(uint4), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_fb_win, t.bp_win.data(), t.bp_win.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
     HIPCHK(hipMemcpy(e->d_cell, t.cell.data(), t.cell.size() * sizeof(CellD), hipMemcpyHostToDevice));
@@ -502,7 +528,7 @@ int tomo_destroy(tomo_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
-    void *ptrs[] = {e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -1316,6 +1342,8 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
+    if (std::strcmp(name, "ft_debug") == 0) { e->ft_debug = value; return TOMO_OK; }
+    if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_scratch_mib") == 0) {   // cap of the partial-sum scratch; takes effect before the first all-angle FP
         if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
