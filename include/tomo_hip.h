@@ -181,7 +181,14 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     FP/BP launches per angle (same arithmetic per voxel; 8 instead of 12 bytes per voxel-angle)
  *   "tv_lds" (8):     TV gradient as LDS march with that many z-columns per workgroup (0 = direct-global stencil)
  *   "fgp_fused" (1):  one fused kernel per FGP iteration (single slab)
- *   "fp_all_lpr" (16): all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks (0 = wide form) */
+ *   "fp_tile" (1):    all-angle forward projection from LDS-resident image tiles (k_fp_tile + k_fp_tile_reduce);
+ *                     0 = ray-driven form selected by "fp_all_lpr"
+ *   "fp_tile_scratch_mib" (4096): cap of the tile projector's partial-sum scratch; a larger volume is projected in
+ *                     several passes over groups of 64-slice chunks (set before the first projection)
+ *   "bp_tile" (1):    all-angle back-projection from LDS-staged residual-row windows (k_bp_tile; bit-identical to the
+ *                     pixel-driven k_bp_all it replaces; used when every tile's ray window fits, else k_bp_all)
+ *   "fp_all_lpr" (16): ray-driven all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks
+ *                     (0 = wide form) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------

@@ -100,3 +100,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "tomo_oracle" not in src, f
+
+
+@pytest.mark.parametrize("N,P,amax", [(50, 9, 89.0), (96, 17, 70.0), (33, 4, 45.0), (7, 3, 60.0), (64, 1, 0.0)])
+def test_tile_tables_replay_the_matrix(tmp_path, N, P, amax):
+    """Host tables of the tile-stationary projectors (sysmat.cpp: build_tiles, build_bp_tiles), replayed on the CPU by
+    tests/native/sysmat_tables_check.cpp: every matrix entry in exactly one stream, every tile segment used by exactly
+    one row, forward = CSR product, backward cells = the cell table, ray windows within the kernel's LDS budget."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stc")
+    src = [os.path.join(root, "tests", "native", "sysmat_tables_check.cpp"), os.path.join(root, "tomo_tv_amd", "csrc", "sysmat.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "tomo_tv_amd", "csrc"), *src, "-lpthread", "-o", exe],
+                   check=True)
+    r = subprocess.run([exe, str(N), str(P), str(amax)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr

@@ -321,7 +321,7 @@ template <int J> __device__ __forceinline__ uint32_t row_ror(uint32_t v)
 __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict__ x, const uint32_t *__restrict__ slot_ptr,
                                                          const uint32_t *__restrict__ slot_seg0, const uint2 *__restrict__ tent,
                                                          float *__restrict__ part, int n, int sx, int tiles_z, int ntiles,
-                                                         int chunk0, int ncp, int dbg)
+                                                         int chunk0, int ncp)
 {
     typedef VecOf<4>::T V;
     extern __shared__ V ft_tile[];                      // [FT_PIX + 1][16]
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
         for (int k = 0; k < FT_PIX / 64; ++k) {
             int lp = (t >> 4) + 64 * k;
             int y = ty * FT_TY + lp / FT_TZ, z = tz * FT_TZ + lp % FT_TZ;
-            v[k] = (y < n && z < n && !(dbg & 2)) ? *reinterpret_cast<const V *>(x + ((size_t)y * n + z) * sx + (size_t)(chunk0 + c) * 64 + gl * 4)
+            v[k] = (y < n && z < n) ? *reinterpret_cast<const V *>(x + ((size_t)y * n + z) * sx + (size_t)(chunk0 + c) * 64 + gl * 4)
                                     : vzero<4>();
         }
 #pragma unroll
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
         FT_LOAD(0) FT_LOAD(1) FT_LOAD(2) FT_LOAD(3) FT_LOAD(4) FT_LOAD(5) FT_LOAD(6) FT_LOAD(7)           \
         E = ep[(size_t)(b + (I) + FT_PF) * FT_BATCH];                                                     \
         FT_FMA(0) FT_FMA(1) FT_FMA(2) FT_FMA(3) FT_FMA(4) FT_FMA(5) FT_FMA(6) FT_FMA(7)                   \
-        if (last && !(dbg & 1)) {                                                                         \
+        if (last) {                                                                                       \
             *reinterpret_cast<V *>(part + ((size_t)seg * ncp + c) * 64 + gl * 4) = acc;                   \
             acc = vzero<4>();                                                                             \
             ++seg;                                                                                        \
@@ -681,6 +681,7 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
 // works on pixel (l + J) mod 8 of its group, always into acc[J], so the sums never move between lanes.
 // Same two FMAs per pixel and angle in the same order as k_bp_all: results are bit-identical.
 constexpr int FB_A = 4, FB_MAXR = 40, FB_BUF = (FB_A * FB_MAXR + 1) * 256, FB_LDS_BYTES = 2 * FB_BUF;
+constexpr int FB_MAX_PROJ = 8192;                       // ray windows of all angles sit in LDS (4 B each)
 constexpr int FB_SLOTS = FB_A * FB_MAXR * 16, FB_Q = (FB_SLOTS + FT_THREADS - 1) / FT_THREADS;
 
 __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, const uint4 *__restrict__ tcell,
@@ -699,6 +700,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
     const float *rc = r + (size_t)c * 64;
     const int nstage = (nproj + FB_A - 1) / FB_A;
     if (t < 16) { fb_lds[FB_A * FB_MAXR * 16 + t] = vzero<4>(); fb_lds[FB_BUF / 16 + FB_A * FB_MAXR * 16 + t] = vzero<4>(); }
+    // the tile's ray windows, all angles, behind the stage buffers: the staging loads then depend on an LDS read only
+    uint32_t *lwin = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(fb_lds) + FB_LDS_BYTES);
+    for (int i = t; i < nproj; i += FT_THREADS) lwin[i] = wn[i];
+    __syncthreads();
     V sreg[FB_Q];
     bool sval[FB_Q];
 #define FB_STAGE_LOAD(S)                                                                                  \
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
         int i = (S) * FB_A + a;                                                                           \
         sval[q] = false;                                                                                  \
         if (f < FB_SLOTS && i < nproj) {                                                                  \
-            uint32_t w = wn[i];                                                                           \
+            uint32_t w = lwin[i];                                                                         \
             if ((uint32_t)j < (w >> 16)) {                                                                \
                 sval[q] = true;                                                                           \
                 sreg[q] = *reinterpret_cast<const V *>(rc + ((size_t)i * n + (w & 0xFFFFu) + j) * sx + (f & 15) * 4); \
@@ -728,20 +733,23 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
     for (int J = 0; J < 8; ++J) acc[J] = vzero<4>();
     const uint32_t zoff = FB_A * FB_MAXR * 256;
 #define FB_ROW(O, J) (*reinterpret_cast<const V *>(base + row_ror<J>(O)))
-#define FB_PAIR(J0)                                                                                       \
+#define FB_HALF(J0)                                                                                       \
     {                                                                                                     \
         V a0 = FB_ROW(o0, J0), a1 = FB_ROW(o1, J0), b0 = FB_ROW(o0, J0 + 1), b1 = FB_ROW(o1, J0 + 1);     \
+        V c0 = FB_ROW(o0, J0 + 2), c1 = FB_ROW(o1, J0 + 2), d0 = FB_ROW(o0, J0 + 3), d1 = FB_ROW(o1, J0 + 3); \
         acc[J0] += __uint_as_float(row_ror<J0>(w0)) * a0;     acc[J0] += __uint_as_float(row_ror<J0>(w1)) * a1;         \
         acc[J0 + 1] += __uint_as_float(row_ror<J0 + 1>(w0)) * b0; acc[J0 + 1] += __uint_as_float(row_ror<J0 + 1>(w1)) * b1; \
+        acc[J0 + 2] += __uint_as_float(row_ror<J0 + 2>(w0)) * c0; acc[J0 + 2] += __uint_as_float(row_ror<J0 + 2>(w1)) * c1; \
+        acc[J0 + 3] += __uint_as_float(row_ror<J0 + 3>(w0)) * d0; acc[J0 + 3] += __uint_as_float(row_ror<J0 + 3>(w1)) * d1; \
         /* pin: pure FMAs carry no chain, the DAG would otherwise sink all of a stage's FMAs below all of its reads */ \
-        asm volatile("" : "+v"(acc[J0]), "+v"(acc[J0 + 1]));                                              \
+        asm volatile("" : "+v"(acc[J0]), "+v"(acc[J0 + 1]), "+v"(acc[J0 + 2]), "+v"(acc[J0 + 3]));        \
     }
 #define FB_STEP(E, I)                                                                                     \
     {                                                                                                     \
         const bool in = s * FB_A + (I) < nproj;                                                           \
         const uint32_t o0 = in ? E.x : zoff, w0 = in ? E.y : 0u, o1 = in ? E.z : zoff, w1 = in ? E.w : 0u; \
         E = cp[(size_t)(s * FB_A + (I) + FB_A) * FT_PIX];                                                 \
-        FB_PAIR(0) FB_PAIR(2) FB_PAIR(4) FB_PAIR(6)                                                       \
+        FB_HALF(0) FB_HALF(4)                                                                             \
     }
     for (int s = 0; s < nstage; ++s) {
         if (s + 1 < nstage) { FB_STAGE_LOAD(s + 1) }
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
         __syncthreads();
     }
 #undef FB_STEP
-#undef FB_PAIR
+#undef FB_HALF
 #undef FB_ROW
 #undef FB_STAGE_STORE
 #undef FB_STAGE_LOAD

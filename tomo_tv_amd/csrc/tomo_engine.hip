@@ -60,7 +60,7 @@ struct tomo_engine {
     uint32_t max_items = 0;
     float *sart_alt = nullptr;                    // ping-pong partner of the volume being swept
     // tile-stationary all-angle FP (k_fp_tile): tables, partial-sum scratch (one per stream that can run it)
-    int fp_tile = 1, ft_tiles_z = 0, ft_ntiles = 0, ft_debug = 0;
+    int fp_tile = 1, ft_tiles_z = 0, ft_ntiles = 0;
     uint32_t ft_nseg = 0;
     uint32_t *d_ft_slot_ptr = nullptr, *d_ft_slot_seg0 = nullptr, *d_ft_rsptr = nullptr, *d_ft_rsidx = nullptr;
     uint2 *d_ft_tent = nullptr;
@@ -239,7 +239,7 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
             ProfScope ps(e, TOMO_K_FP_TILE);
             dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * ncp)), block(FT_THREADS);
             hipLaunchKernelGGL(k_fp_tile, grid, block, FT_LDS_BYTES, e->stream, x, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, part,
-                               e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, c0, ncp, e->ft_debug);
+                               e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, c0, ncp);
             LAUNCHCHK();
         }
         int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
@@ -317,12 +317,12 @@ static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *
     if (e->bp_tile && e->fb_ok) {
         static bool attr_set = false;
         if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_bp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute((const void *)k_bp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES + FB_MAX_PROJ * 4));
             attr_set = true;
         }
         const int nchunk64 = e->sxc / 64;
         dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * nchunk64)), block(FT_THREADS);
-        hipLaunchKernelGGL(k_bp_tile, grid, block, FB_LDS_BYTES, e->stream, x, e->d_fb_cell, e->d_fb_win, r, colsum, alpha, beta, clamp,
+        hipLaunchKernelGGL(k_bp_tile, grid, block, FB_LDS_BYTES + e->np * 4, e->stream, x, e->d_fb_cell, e->d_fb_win, r, colsum, alpha, beta, clamp,
                            e->np, e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, nchunk64);
         LAUNCHCHK();
         return TOMO_OK;
@@ -410,7 +410,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
         build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, FB_A, t);
         static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
-        e->fb_ok = t.bp_tile_ok;
+        e->fb_ok = t.bp_tile_ok && e->np <= FB_MAX_PROJ;
         if (e->fb_ok) {
             if ((rc = dev_alloc((void **)&e->d_fb_cell, t.bp_cell.size() * sizeof(uint4), false, e->stream))) return rc;
             if ((rc = dev_alloc((void **)&e->d_fb_win, t.bp_win.size() * 4, false, e->stream))) return rc;
@@ -1342,7 +1342,6 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
-    if (std::strcmp(name, "ft_debug") == 0) { e->ft_debug = value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_scratch_mib") == 0) {   // cap of the partial-sum scratch; takes effect before the first all-angle FP

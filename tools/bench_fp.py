@@ -13,7 +13,7 @@ ap.add_argument("--nslice", type=int, default=512)
 ap.add_argument("--nproj", type=int, default=90)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--opt", action="append", default=[])
-ap.add_argument("--sweep", action="append", default=[], help="name=v1,v2,...: time the projections for each value")
+ap.add_argument("--sweep", action="append", default=[], help="name=v1,v2,...: time the projections for each value, e.g. bp_tile=0,1")
 a = ap.parse_args()
 t0 = time.perf_counter()
 t = tomoengine(a.nslice, a.n, np.deg2rad(tilt_angles(a.nproj)))
