@@ -108,6 +108,66 @@ int main(int argc, char **argv)
         }
     }
     REQUIRE(worst_bp == 0.0, "backward mismatch %g", worst_bp);
+    // ---- fused SART step: per-angle tile segments and cells
+    const int T = 16, SMAXR = 26, MS = Tables::ST_MAXSEG;
+    build_sart_tiles(m, N, P, T, SMAXR, PIXB, t);
+    REQUIRE(t.st_ok, "SART tile tables rejected");
+    const int stz = t.st_tiles_z, snt = t.st_tiles;
+    double worst_st = 0, worst_stbp = 0;
+    for (int i = 0; i < P; ++i) {
+        std::vector<double> ps(t.st_max_ids, 0.0);
+        std::vector<int> wr(t.st_max_ids, 0);
+        for (int k = 0; k < snt; ++k) {
+            int y0 = (k / stz) * T, z0 = (k % stz) * T;
+            uint32_t base = t.st_segbase[(size_t)i * snt + k];
+            bool ended = false;
+            for (int q = 0; q < MS; ++q) {
+                uint32_t b0 = t.st_seg[(((size_t)i * snt + k) * MS + q) * 2], nb = t.st_seg[(((size_t)i * snt + k) * MS + q) * 2 + 1];
+                if (nb == 0) { ended = true; continue; }
+                REQUIRE(!ended, "segment slots of a tile are not contiguous");
+                double acc = 0;
+                for (uint32_t e = 0; e < nb * NB; ++e) {
+                    uint32_t off = t.st_off[(size_t)b0 * NB + e]; float w = t.st_w[(size_t)b0 * NB + e];
+                    uint32_t lp = off / PIXB;
+                    REQUIRE(off % PIXB == 0 && lp <= (uint32_t)(T * T), "bad SART entry offset");
+                    if (lp == (uint32_t)(T * T)) { REQUIRE(w == 0.f, "padding with weight"); continue; }
+                    int y = y0 + lp / T, z = z0 + lp % T;
+                    REQUIRE(y < N && z < N, "SART entry outside the image");
+                    acc += (double)w * x[(int64_t)y * N + z];
+                }
+                REQUIRE(base + q < t.st_max_ids, "partial id out of range");
+                ps[base + q] = acc; wr[base + q]++;
+            }
+            // cells against the cell table
+            uint32_t w = t.st_win[(size_t)i * snt + k], lo = w & 0xFFFFu, nr = w >> 16;
+            REQUIRE(nr <= (uint32_t)SMAXR, "SART window too wide");
+            for (int lp = 0; lp < T * T; ++lp) {
+                int y = y0 + lp / T, z = z0 + lp % T;
+                const Tables::TileCell &c = t.st_cell[((size_t)i * snt + k) * (T * T) + lp];
+                double a = 0, ref = 0;
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t off = h ? c.off1 : c.off0; float wt = h ? c.w1 : c.w0;
+                    if (off == (uint32_t)SMAXR * PIXB) { REQUIRE(wt == 0.f, "zero row with weight"); continue; }
+                    REQUIRE(off % PIXB == 0 && off / PIXB < nr, "bad SART cell offset");
+                    a += (double)wt * rr[(int64_t)i * N + lo + off / PIXB];
+                }
+                if (y < N && z < N) {
+                    const Cell &cc = t.cell[(size_t)i * npix + (int64_t)y * N + z];
+                    if (cc.w0 != 0.f) ref += (double)cc.w0 * rr[(int64_t)i * N + cc.r0];
+                    if (cc.w1 != 0.f) ref += (double)cc.w1 * rr[(int64_t)i * N + cc.r1];
+                }
+                worst_stbp = std::max(worst_stbp, std::fabs(a - ref));
+            }
+        }
+        for (int j = 0; j < N; ++j) {
+            int64_t r = (int64_t)i * N + j;
+            double sum = 0;
+            for (uint32_t q = t.st_rptr[r]; q < t.st_rptr[r + 1]; ++q) { REQUIRE(wr[t.st_ridx[q]] == 1, "row uses an unwritten partial"); sum += ps[t.st_ridx[q]]; wr[t.st_ridx[q]] = 2; }
+            worst_st = std::max(worst_st, std::fabs(sum - g[r]));
+        }
+        for (uint32_t q = 0; q < t.st_max_ids; ++q) REQUIRE(wr[q] != 1, "partial %u of angle %d belongs to no row", q, i);
+    }
+    REQUIRE(worst_st < 1e-9 && worst_stbp == 0.0, "SART tile mismatch fp %g bp %g", worst_st, worst_stbp);
     std::printf("OK N=%d P=%d nnz=%ld nseg=%u padded=%.3f stream_imbalance=%.3f max_window=%u\n", N, P, (long)nnz, t.tile_nseg,
                 (double)t.tile_off.size() / std::max<int64_t>(1, nnz), imb, maxwin);
     return 0;

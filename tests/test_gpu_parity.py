@@ -596,3 +596,28 @@ def test_tile_projectors_match_row_and_pixel_driven_forms(gpu, N, P, Nx):
         t.set_option("fp_tile", 0); t.set_option("bp_tile", tile)
         t.set_tilt_series(out[0][0]); t.SIRT(2)
     assert np.array_equal(t0.get_volume(), t1.get_volume())
+
+
+@pytest.mark.parametrize("N,P,Nx", [(40, 7, 70), (100, 9, 128), (16, 1, 64)])
+def test_tile_sart_step_matches_ray_walk_form_and_oracle(gpu, N, P, Nx):
+    """k_sart_tile (streamed tiles) against k_sart_seg (ray walk) and the oracle, natural and permuted angle order."""
+    ang = np.linspace(-72, 66, P) if P > 1 else np.array([12.0])
+    x = ellipsoids(Nx, N, seed=11)
+    ref = oracle.ctvlib(Nx, N, P)
+    ref.load_A(oracle.parallel_ray(N, ang))
+    ref.original_volume = x.copy()
+    ref.create_projections()
+    order = np.random.default_rng(3).permutation(P).astype(np.int32)
+    vols = {}
+    for tile in (0, 1):
+        t = tomoengine(Nx, N, ang * np.pi / 180)
+        t.set_option("sart_tile", tile)
+        t.set_tilt_series(ref.b)
+        t.SART(0.7, 2)
+        a = t.get_volume()
+        t.be.c("sart", VOL_RECON, 0.7, 1, order.ctypes.data)              # permuted sweep through the C ABI
+        vols[tile] = (a, t.get_volume())
+    ref.SART(0.7, 2)
+    assert rel_l2(vols[1][0], ref.recon) < 1e-5 and rel_l2(vols[0][0], ref.recon) < 1e-5
+    assert rel_l2(vols[1][0], vols[0][0]) < 2e-6
+    assert rel_l2(vols[1][1], vols[0][1]) < 2e-6

@@ -672,6 +672,130 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
     }
 }
 
+// ---- fused SART step, tile form: BP(prev) + FP(next) on image tiles streamed through LDS -------------------------
+// k_sart_seg walks rays: every pixel is a 1-KiB gather along a ray, and the achieved HBM rate stays ~15 % under that
+// of a streaming pass (k_bp_angle).  Here a workgroup owns a ST_T x ST_T pixel tile x 64 slices: it streams the tile
+// in (coalesced), applies the pending voxel update of angle "prev" pixel-driven from the tile's window of residual rows
+// (staged in LDS; same arithmetic as k_bp_angle, bit-identical), streams the tile out, keeps the updated tile as an LDS
+// image and forms, for angle "next", the partial sums of the ray segments inside the tile from that image (one segment
+// per 16-lane group, entry batches shared by DPP rotation as in k_fp_tile).  k_resid_finish_idx adds a ray's partials
+// (ascending tile) and forms the residual.  Per angle: the slab read once and written once, plus ~9 % for the partials.
+// Two workgroups per CU (75 KB LDS each) overlap one's streaming with the other's LDS phase.  In-place is safe: a
+// workgroup reads and writes only its own tile.
+constexpr int ST_T = 16, ST_PIX = ST_T * ST_T, ST_THREADS = 512, ST_MAXR = 26, ST_MAXSEG = 32;
+constexpr int ST_LDS_V = (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16 + ST_PIX;     // image + zero pixel, window + zero row, cells
+
+template <bool FUSED>
+__global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
+                                                           const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
+                                                           const float *__restrict__ r_prev, float beta,
+                                                           const uint2 *__restrict__ segs, const uint32_t *__restrict__ segbase,
+                                                           const uint2 *__restrict__ ent, float *__restrict__ partial,
+                                                           int n, int sx, int tiles_z, int ntiles, int nchunk)
+{
+    typedef VecOf<4>::T V;
+    extern __shared__ V st_lds[];                       // ST_LDS_V float4 (75 KB: dynamic)
+    V *img = st_lds, *win = st_lds + (ST_PIX + 1) * 16;
+    uint4 *cel = reinterpret_cast<uint4 *>(st_lds + (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16);
+    // the chunks of a tile run back to back on one XCD (workgroups b and b+8 share an XCD): they stream the same
+    // pixel lines and read the same tables.  (A persistent form with the next tile prefetched into registers while
+    // the current one is in its LDS phases measured 3 % slower.)
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int tile = (l / nchunk) * 8 + xcd, c = l % nchunk;
+    if (tile >= ntiles) return;
+    const int ty = tile / tiles_z, tz = tile - ty * tiles_z;
+    const int t = threadIdx.x, gl = t & 15, g = t >> 4;
+    const int off = c * 64 + gl * 4;
+    // the group's 8 pixels: row g/2 of the tile, columns (g&1)*8 .. +7
+    const int y = ty * ST_T + (g >> 1), z0 = tz * ST_T + (g & 1) * 8;
+    V xv[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J)
+        xv[J] = (y < n && z0 + J < n) ? *reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off) : vzero<4>();
+    if (FUSED) {
+        uint32_t w = wins[tile];
+        if (t < (ST_MAXR + 1) * 16) {
+            int j = t >> 4;
+            win[t] = ((uint32_t)j < (w >> 16)) ? *reinterpret_cast<const V *>(r_prev + ((size_t)(w & 0xFFFFu) + j) * sx + off) : vzero<4>();
+        }
+        if (t < ST_PIX) cel[t] = cells[(size_t)tile * ST_PIX + t];
+    }
+    if (t < 16) img[ST_PIX * 16 + t] = vzero<4>();
+    if (FUSED) {
+        __syncthreads();
+        const char *wb = reinterpret_cast<const char *>(win) + gl * 16;
+#pragma unroll
+        for (int J = 0; J < 8; ++J) {
+            uint4 ce = cel[g * 8 + J];
+            V a0 = *reinterpret_cast<const V *>(wb + ce.x), a1 = *reinterpret_cast<const V *>(wb + ce.z);
+            float w0 = __uint_as_float(ce.y), w1 = __uint_as_float(ce.w);
+            float cs = w0 + w1;
+            V num = w0 * a0;
+            num += w1 * a1;
+            V upd = num / (cs > 0.f ? cs : 1.0f);
+            V nv = xv[J] + beta * upd;
+            nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
+            xv[J] = nv;
+            if (y < n && z0 + J < n) *reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off) = nv;
+        }
+    }
+#pragma unroll
+    for (int J = 0; J < 8; ++J) img[(g * 8 + J) * 16 + gl] = xv[J];
+    __syncthreads();
+    // forward projection of "next": group g owns the tile's g-th ray segment
+    uint2 sd = segs[(size_t)tile * ST_MAXSEG + g];
+    if (sd.y == 0) return;                                // uniform inside a 16-lane DPP row
+    const char *ib = reinterpret_cast<const char *>(img) + gl * 16;
+    const uint2 *ep = ent + (size_t)sd.x * FT_BATCH + (gl & 7);
+    V acc = vzero<4>();
+    for (uint32_t b = 0; b < sd.y; ++b) {
+        uint2 e = ep[(size_t)b * FT_BATCH];
+        V q[FT_BATCH];
+#define ST_LOAD(J) q[J] = *reinterpret_cast<const V *>(ib + row_ror<J>(e.x));
+        ST_LOAD(0) ST_LOAD(1) ST_LOAD(2) ST_LOAD(3) ST_LOAD(4) ST_LOAD(5) ST_LOAD(6) ST_LOAD(7)
+#undef ST_LOAD
+#define ST_FMA(J) acc += __uint_as_float(row_ror<J>(e.y)) * q[J];
+        ST_FMA(0) ST_FMA(1) ST_FMA(2) ST_FMA(3) ST_FMA(4) ST_FMA(5) ST_FMA(6) ST_FMA(7)
+#undef ST_FMA
+    }
+    *reinterpret_cast<V *>(partial + ((size_t)segbase[tile] + g) * sx + off) = acc;
+}
+
+// r[row][s] = (b - sum of the row's tile partials) / rowsum   (0 where rowsum == 0); one wave per (row, chunk)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_resid_finish_idx(const float *__restrict__ partial, const uint32_t *__restrict__ rptr,
+                                                           const uint32_t *__restrict__ ridx, const float *__restrict__ b,
+                                                           const float *__restrict__ rowsum, float *__restrict__ r_out,
+                                                           int row0, int nrows, int nchunk, int sx)
+{
+    typedef typename VecOf<VEC>::T V;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int gw = blockIdx.x * 4 + wave;
+    if (gw >= nrows * nchunk) return;
+    int chunk = gw / nrows;
+    int row = row0 + (gw - chunk * nrows);
+    int off = chunk * (64 * VEC) + lane * VEC;
+    uint32_t kb = rptr[row], ke = rptr[row + 1];
+    V acc = vzero<VEC>();
+    const float *pp = partial + off;
+    for (uint32_t k = kb; k < ke; k += 8) {               // 8 independent loads per trip, summed in list order
+        V tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t id = ridx[min(k + u, ke - 1)];        // wave-uniform: scalar loads
+            tv[u] = *reinterpret_cast<const V *>(pp + (size_t)id * sx);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u < ke) acc += tv[u];
+    }
+    size_t o = (size_t)row * sx + off;
+    V bv = *reinterpret_cast<const V *>(b + o);
+    float rs = rowsum[row];
+    V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
+    *reinterpret_cast<V *>(r_out + o) = r;
+}
+
 // ---- back-projector, all angles, tile-stationary form ------------------------------------------------------------
 // k_bp_all gathers 2 x 256 B per pixel, angle and 64-slice chunk from L2 (96 GB at 512^3 x 90).  Here a workgroup owns
 // a FT_TY x FT_TZ pixel tile x 64 slices, keeps the 512 x 64 sums in registers (8 pixels per 16-lane group) and stages,

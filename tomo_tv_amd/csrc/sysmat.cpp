@@ -334,22 +334,18 @@ void build_segments(int N, int P, int seg_len, Tables &t)
     }
 }
 
-// Tile tables (see sysmat.h).  Per row the entries are stably regrouped by tile (ascending pixel inside a tile, the
-// order the row-driven kernels use).  The segments of a tile go longest first to the stream with the least work so
-// far, so the 64 lane groups of a workgroup finish together.
-void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t)
+struct RowSeg { uint32_t tile, cnt; };
+
+// Per row: entries stably regrouped by image tile (ascending pixel inside a tile, the order the row-driven kernels
+// use), written CSR-aligned into tmp_lpix (pixel index inside the tile, y-major) / tmp_w; rsegs[r] lists the row's
+// (tile, entry count) runs in ascending tile order.  Threads over rows.
+static void split_rows_by_tile(const Coo &m, int N, int64_t nrows, int TY, int TZ, int tiles_z, std::vector<uint32_t> &tmp_lpix,
+                               std::vector<float> &tmp_w, std::vector<std::vector<RowSeg>> &rsegs)
 {
-    constexpr int NS = Tables::TILE_SLOTS, NB = Tables::TILE_BATCH;
-    const int64_t nrows = (int64_t)N * P;
     const int64_t nnz = m.ptr[nrows];
-    t.tile_ty = TY; t.tile_tz = TZ;
-    t.tiles_y = (N + TY - 1) / TY; t.tiles_z = (N + TZ - 1) / TZ;
-    const uint32_t ntiles = (uint32_t)t.tiles_y * t.tiles_z;
-    // pass 1 (threads over rows): entries regrouped by tile in a CSR-aligned temp, segments listed per row
-    std::vector<uint32_t> tmp_lpix(nnz ? nnz : 1);
-    std::vector<float> tmp_w(nnz ? nnz : 1);
-    struct RowSeg { uint32_t tile, cnt; };
-    std::vector<std::vector<RowSeg>> rsegs(nrows);
+    tmp_lpix.assign(nnz ? nnz : 1, 0u);
+    tmp_w.assign(nnz ? nnz : 1, 0.f);
+    rsegs.assign(nrows, {});
     unsigned hw = std::thread::hardware_concurrency();
     int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, nrows / 256));
     auto work = [&](int th) {
@@ -361,7 +357,7 @@ void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Ta
             for (int k = 0; k < n; ++k) {
                 uint32_t p = m.col[b + k];
                 uint32_t y = p / (uint32_t)N, z = p - y * (uint32_t)N;
-                key[k] = {(y / TY) * (uint32_t)t.tiles_z + z / TZ, (uint32_t)k};
+                key[k] = {(y / TY) * (uint32_t)tiles_z + z / TZ, (uint32_t)k};
             }
             std::sort(key.begin(), key.end());
             auto &rs = rsegs[r];
@@ -375,12 +371,28 @@ void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Ta
             }
         }
     };
-    {
-        std::vector<std::thread> thr;
-        for (int th = 1; th < nth; ++th) thr.emplace_back(work, th);
-        work(0);
-        for (auto &x : thr) x.join();
-    }
+    std::vector<std::thread> thr;
+    for (int th = 1; th < nth; ++th) thr.emplace_back(work, th);
+    work(0);
+    for (auto &x : thr) x.join();
+}
+
+// Tile tables of the all-angle forward projector (see sysmat.h).  The segments of a tile go longest first to the
+// stream with the least work so far, so the 64 lane groups of a workgroup finish together.
+void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t)
+{
+    constexpr int NS = Tables::TILE_SLOTS, NB = Tables::TILE_BATCH;
+    const int64_t nrows = (int64_t)N * P;
+    const int64_t nnz = m.ptr[nrows];
+    t.tile_ty = TY; t.tile_tz = TZ;
+    t.tiles_y = (N + TY - 1) / TY; t.tiles_z = (N + TZ - 1) / TZ;
+    const uint32_t ntiles = (uint32_t)t.tiles_y * t.tiles_z;
+    std::vector<uint32_t> tmp_lpix;
+    std::vector<float> tmp_w;
+    std::vector<std::vector<RowSeg>> rsegs;
+    split_rows_by_tile(m, N, nrows, TY, TZ, t.tiles_z, tmp_lpix, tmp_w, rsegs);
+    unsigned hw = std::thread::hardware_concurrency();
+    (void)nnz;
     // pass 2: bucket the segments by tile
     struct Ref { uint32_t cnt, row, src; };               // src = offset of the segment's entries in the temp
     std::vector<uint32_t> tptr(ntiles + 1, 0);
@@ -527,6 +539,108 @@ void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows
     for (auto &x : thr) x.join();
     t.bp_tile_ok = true;
     for (uint32_t k = 0; k < ntiles; ++k) if (bad[k]) t.bp_tile_ok = false;
+}
+
+// Per-angle tile tables of the fused SART step (see sysmat.h); needs t.cell (build_tables).
+void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel_bytes, Tables &t)
+{
+    constexpr int NB = Tables::TILE_BATCH, MS = Tables::ST_MAXSEG;
+    const int64_t nrows = (int64_t)N * P, npix = (int64_t)N * N;
+    const int tiles_1d = (N + T - 1) / T;
+    const uint32_t ntiles = (uint32_t)tiles_1d * tiles_1d;
+    const int TP = T * T;
+    t.st_t = T; t.st_tiles = (int)ntiles; t.st_tiles_z = tiles_1d; t.st_maxr = max_rows;
+    const uint32_t zero_row = (uint32_t)max_rows * (uint32_t)pixel_bytes, zero_pix = (uint32_t)TP * (uint32_t)pixel_bytes;
+    std::vector<uint32_t> tmp_lpix;
+    std::vector<float> tmp_w;
+    std::vector<std::vector<RowSeg>> rsegs;
+    split_rows_by_tile(m, N, nrows, T, T, tiles_1d, tmp_lpix, tmp_w, rsegs);
+    t.st_cell.assign((size_t)P * ntiles * TP, Tables::TileCell{zero_row, 0.f, zero_row, 0.f});
+    t.st_win.assign((size_t)P * ntiles, 0);
+    t.st_segbase.assign((size_t)P * ntiles, 0);
+    t.st_seg.assign((size_t)P * ntiles * MS * 2, 0);
+    t.st_rptr.assign(nrows + 1, 0);
+    for (int64_t r = 0; r < nrows; ++r) t.st_rptr[r + 1] = t.st_rptr[r] + (uint32_t)rsegs[r].size();
+    t.st_ridx.assign(std::max<size_t>(1, t.st_rptr[nrows]), 0);
+    // batches per angle (prefix over angles), so that the angles can be emitted in parallel
+    std::vector<uint64_t> angle_batches(P + 1, 0);
+    for (int i = 0; i < P; ++i) {
+        uint64_t nb = 0;
+        for (int j = 0; j < N; ++j) for (auto &s : rsegs[(int64_t)i * N + j]) nb += (s.cnt + NB - 1) / NB;
+        angle_batches[i + 1] = angle_batches[i] + nb;
+    }
+    t.st_off.assign((size_t)(angle_batches[P] + 1) * NB, zero_pix);
+    t.st_w.assign((size_t)(angle_batches[P] + 1) * NB, 0.f);
+    std::vector<uint8_t> bad(P, 0);
+    std::vector<uint32_t> ids_of(P, 0);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nth = (int)std::min<int>(std::max(1u, std::min(hw, 32u)), P);
+    auto work = [&](int th) {
+        std::vector<uint32_t> nseg(ntiles), fill(ntiles);
+        for (int i = th; i < P; i += nth) {
+            // segments of angle i per tile, in ascending row order
+            std::fill(nseg.begin(), nseg.end(), 0u);
+            for (int j = 0; j < N; ++j) for (auto &s : rsegs[(int64_t)i * N + j]) nseg[s.tile]++;
+            uint32_t id = 0;
+            for (uint32_t k = 0; k < ntiles; ++k) {
+                t.st_segbase[(size_t)i * ntiles + k] = id;
+                if (nseg[k] > (uint32_t)MS) bad[i] = 1;
+                id += nseg[k];
+            }
+            ids_of[i] = id;
+            if (bad[i]) continue;
+            std::fill(fill.begin(), fill.end(), 0u);
+            uint64_t batch = angle_batches[i];
+            for (int j = 0; j < N; ++j) {
+                int64_t r = (int64_t)i * N + j;
+                uint32_t src = (uint32_t)m.ptr[r];
+                uint32_t q = 0;
+                for (auto &s : rsegs[r]) {
+                    uint32_t k = fill[s.tile]++;
+                    uint32_t nb = (s.cnt + NB - 1) / NB;
+                    size_t slot = (((size_t)i * ntiles + s.tile) * MS + k) * 2;
+                    t.st_seg[slot] = (uint32_t)batch; t.st_seg[slot + 1] = nb;
+                    for (uint32_t e = 0; e < s.cnt; ++e) {
+                        t.st_off[(size_t)batch * NB + e] = tmp_lpix[src + e] * (uint32_t)pixel_bytes;
+                        t.st_w[(size_t)batch * NB + e] = tmp_w[src + e];
+                    }
+                    t.st_ridx[t.st_rptr[r] + q++] = t.st_segbase[(size_t)i * ntiles + s.tile] + k;
+                    batch += nb; src += s.cnt;
+                }
+            }
+            // ray windows and cells
+            const Cell *ci = t.cell.data() + (size_t)i * npix;
+            for (uint32_t k = 0; k < ntiles; ++k) {
+                int y0 = (int)(k / tiles_1d) * T, z0 = (int)(k % tiles_1d) * T;
+                uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                for (int ly = 0; ly < T && y0 + ly < N; ++ly)
+                    for (int lz = 0; lz < T && z0 + lz < N; ++lz) {
+                        const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
+                        if (c.w0 != 0.f) { lo = std::min(lo, c.r0); hi = std::max(hi, c.r0); }
+                        if (c.w1 != 0.f) { lo = std::min(lo, c.r1); hi = std::max(hi, c.r1); }
+                    }
+                uint32_t nr = (lo == 0xFFFFFFFFu) ? 0u : hi - lo + 1;
+                if (nr == 0) lo = 0;
+                if (nr > (uint32_t)max_rows) { bad[i] = 1; continue; }
+                t.st_win[(size_t)i * ntiles + k] = lo | (nr << 16);
+                Tables::TileCell *out = t.st_cell.data() + ((size_t)i * ntiles + k) * TP;
+                for (int ly = 0; ly < T && y0 + ly < N; ++ly)
+                    for (int lz = 0; lz < T && z0 + lz < N; ++lz) {
+                        const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
+                        Tables::TileCell &o = out[ly * T + lz];
+                        if (c.w0 != 0.f) { o.off0 = (c.r0 - lo) * (uint32_t)pixel_bytes; o.w0 = c.w0; }
+                        if (c.w1 != 0.f) { o.off1 = (c.r1 - lo) * (uint32_t)pixel_bytes; o.w1 = c.w1; }
+                    }
+            }
+        }
+    };
+    std::vector<std::thread> thr;
+    for (int th = 1; th < nth; ++th) thr.emplace_back(work, th);
+    work(0);
+    for (auto &x : thr) x.join();
+    t.st_ok = true;
+    t.st_max_ids = 0;
+    for (int i = 0; i < P; ++i) { if (bad[i]) t.st_ok = false; t.st_max_ids = std::max(t.st_max_ids, ids_of[i]); }
 }
 
 }  // namespace tomo

@@ -59,6 +59,22 @@ struct Tables {
     bool bp_tile_ok = false;                     // false: some window exceeds max_rows (kernel falls back)
     std::vector<uint32_t> bp_win;                // [ntiles * P]  first ray | rays << 16
     std::vector<TileCell> bp_cell;               // [(ntiles * P + pad) * TY*TZ], pixel order inside a tile: y-major
+    // Per-angle tile tables of the fused SART step (k_sart_tile): square tiles of st_t pixels, angle-major.
+    //   st_cell[(i*ntiles + tile)*T*T + pixel]  rays of angle i through the pixel as byte offsets into the tile's
+    //                                           staged ray window (zero row = row st_maxr)
+    //   st_win[i*ntiles + tile]                 first ray | rays << 16 of that window
+    //   st_seg[(i*ntiles + tile)*ST_MAXSEG + k] {first batch, batches} of the k-th ray segment of angle i in the tile
+    //   st_segbase[i*ntiles + tile]             partial-sum id (within the angle) of its first segment
+    //   st_off / st_w                           entry batches (TILE_BATCH entries, zero-weight padding -> zero pixel)
+    //   st_rptr / st_ridx                       per row: its partial-sum ids, ascending tile
+    static constexpr int ST_MAXSEG = 32;
+    bool st_ok = false;
+    int st_t = 0, st_tiles = 0, st_tiles_z = 0, st_maxr = 0;
+    uint32_t st_max_ids = 0;                     // most partial sums of one angle
+    std::vector<TileCell> st_cell;
+    std::vector<uint32_t> st_win, st_segbase, st_off, st_rptr, st_ridx;
+    std::vector<uint32_t> st_seg;                // 2 words per slot
+    std::vector<float> st_w;
 };
 
 void build_parallel_ray(int N, int P, const double *angles_rad, Coo &out);
@@ -69,6 +85,7 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err);
 void build_walk(const Coo &m, int N, int P, Tables &t);
 void build_segments(int N, int P, int seg_len, Tables &t);
 void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t);
+void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel_bytes, Tables &t);
 void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t);
 
 }  // namespace tomo

@@ -65,6 +65,15 @@ struct tomo_engine {
     uint32_t *d_ft_slot_ptr = nullptr, *d_ft_slot_seg0 = nullptr, *d_ft_rsptr = nullptr, *d_ft_rsidx = nullptr;
     uint2 *d_ft_tent = nullptr;
     float *ft_part = nullptr, *ft_part_aux = nullptr;
+    int num_cu = 256;
+    int sart_tile = 1;                            // fused SART step on streamed image tiles (k_sart_tile) when the geometry allows it
+    bool st_ok = false;
+    int st_ntiles = 0, st_tiles_z = 0;
+    uint32_t st_max_ids = 0;
+    uint4 *d_st_cell = nullptr;
+    uint32_t *d_st_win = nullptr, *d_st_segbase = nullptr, *d_st_rptr = nullptr, *d_st_ridx = nullptr;
+    uint2 *d_st_seg = nullptr, *d_st_ent = nullptr;
+    float *st_partial = nullptr;
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
     bool fb_ok = false;
     uint4 *d_fb_cell = nullptr;
@@ -312,6 +321,45 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
     return TOMO_OK;
 }
 
+// tile form of the per-angle step (k_sart_tile): FUSED -> BP(prev) + FP(next), in place; else plain FP(next).
+// Leaves the residual rows of `next` in r.
+template <bool FUSED>
+static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float *r, float beta)
+{
+    int rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
+        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
+        attr_set = true;
+    }
+    if (!e->st_partial) {
+        if ((rc = dev_alloc((void **)&e->st_partial, (size_t)std::max<uint32_t>(1, e->st_max_ids) * e->sx * sizeof(float), true, e->stream))) return rc;
+    }
+    const int nchunk64 = e->sxc / 64;
+    const size_t nt = (size_t)e->st_ntiles;
+    {
+        ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE);
+        dim3 grid((unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64)), block(ST_THREADS);
+        hipLaunchKernelGGL((k_sart_tile<FUSED>), grid, block, ST_LDS_V * 16, e->stream, x, x,
+                           FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
+                           FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
+                           e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segbase + (size_t)next * nt, e->d_st_ent, e->st_partial,
+                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64);
+        LAUNCHCHK();
+    }
+    int nchunk = e->sxc / (64 * e->vec);
+    int64_t waves = (int64_t)e->n * nchunk;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (e->vec) {
+    case 4: hipLaunchKernelGGL((k_resid_finish_idx<4>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+    case 2: hipLaunchKernelGGL((k_resid_finish_idx<2>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+    default: hipLaunchKernelGGL((k_resid_finish_idx<1>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+    }
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
 static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
 {
     if (e->bp_tile && e->fb_ok) {
@@ -353,6 +401,11 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
+    {
+        int ncu = 0;
+        HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, e->device));
+        e->num_cu = std::max(8, (ncu / 8) * 8);
+    }
     std::vector<uint32_t> ptr32(m.nrow + 1);
     for (int64_t r = 0; r <= m.nrow; ++r) ptr32[r] = (uint32_t)m.ptr[r];
     std::vector<uint2> ent(e->nnz ? e->nnz : 1);
@@ -408,6 +461,29 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_ft_tent, tent.data(), tent.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsptr, t.rseg_ptr.data(), t.rseg_ptr.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
+        build_sart_tiles(m, e->n, e->np, ST_T, ST_MAXR, 256, t);
+        static_assert(Tables::ST_MAXSEG == ST_MAXSEG, "segment slots per tile");
+        e->st_ok = t.st_ok;
+        if (e->st_ok) {
+            e->st_ntiles = t.st_tiles; e->st_tiles_z = t.st_tiles_z; e->st_max_ids = t.st_max_ids;
+            std::vector<uint2> sent(t.st_off.size());
+            for (size_t k = 0; k < sent.size(); ++k) { uint32_t bits; std::memcpy(&bits, &t.st_w[k], 4); sent[k] = make_uint2(t.st_off[k], bits); }
+            if ((rc = dev_alloc((void **)&e->d_st_cell, t.st_cell.size() * sizeof(uint4), false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_win, t.st_win.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_segbase, t.st_segbase.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_seg, t.st_seg.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_ent, sent.size() * sizeof(uint2), false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_rptr, t.st_rptr.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_ridx, t.st_ridx.size() * 4, false, e->stream))) return rc;
+            HIPCHK(hipMemcpy(e->d_st_cell, t.st_cell.data(), t.st_cell.size() * sizeof(uint4), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_win, t.st_win.data(), t.st_win.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_segbase, t.st_segbase.data(), t.st_segbase.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_seg, t.st_seg.data(), t.st_seg.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_ent, sent.data(), sent.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_rptr, t.st_rptr.data(), t.st_rptr.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_ridx, t.st_ridx.data(), t.st_ridx.size() * 4, hipMemcpyHostToDevice));
+        }
+        { decltype(t.st_cell)().swap(t.st_cell); decltype(t.st_off)().swap(t.st_off); decltype(t.st_w)().swap(t.st_w); }
         build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, FB_A, t);
         static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
         e->fb_ok = t.bp_tile_ok && e->np <= FB_MAX_PROJ;
@@ -528,7 +604,7 @@ int tomo_destroy(tomo_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
-    void *ptrs[] = {e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->d_st_cell, e->d_st_win, e->d_st_segbase, e->d_st_seg, e->d_st_ent, e->d_st_rptr, e->d_st_ridx, e->st_partial, e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -749,6 +825,20 @@ int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, c
     }
     // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
     if (steps <= 0) return TOMO_OK;
+    if (e->sart_tile && e->st_ok) {   // tile form, in place
+        if ((rc = launch_sart_tile<false>(e, x, 0, angle_at(0), r, beta))) return rc;
+        for (int64_t k = 1; k < steps; ++k) {
+            int prev = angle_at(k - 1), next = angle_at(k);
+            if (prev == next) {
+                if ((rc = launch_bp_angle(e, x, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc;
+                if ((rc = launch_sart_tile<false>(e, x, 0, next, r, beta))) return rc;
+                continue;
+            }
+            if ((rc = launch_sart_tile<true>(e, x, prev, next, r, beta))) return rc;
+        }
+        int last = angle_at(steps - 1);
+        return launch_bp_angle(e, x, last, r + (size_t)last * e->n * e->sx, beta);
+    }
     float *alt;
     if ((rc = get_scratch(e, &e->sart_alt, &alt))) return rc;
     float *cur = x;
@@ -1342,6 +1432,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_tile") == 0) { e->sart_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_scratch_mib") == 0) {   // cap of the partial-sum scratch; takes effect before the first all-angle FP
