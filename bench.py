@@ -53,6 +53,8 @@ def cpu_baseline(n, nproj, budget_s=20.0):
     """The C oracle (OpenMP over slices, like ctvlib.cpp:207) on a bounded sample of the same workload."""
     import oracle
     from tomo_tv_amd.phantom import ellipsoids, tilt_angles
+    if "OMP_NUM_THREADS" not in os.environ:
+        oracle.set_num_threads(oracle.usable_cpus())   # the baseline uses every CPU the host grants
     threads = oracle.num_threads()
     ns = max(8, 2 * threads)
     ang = tilt_angles(nproj)
@@ -145,7 +147,10 @@ def main():
     for _ in range(args.warmup):
         asd_pocs_step(t, st)
     sync()
-    kernels = {"k_sart_seg<4,8,true>": K_SART_FUSED, "k_bp_angle<4,4>": K_BP_ANGLE, "k_sart_seg<4,8,false>": 1}   # names as rocprofv3 prints them
+    # the fused step and the plain per-angle FP run as k_sart_tile<..> unless --opt sart_tile=0 selects the ray-walk form
+    tile = not any(o.replace(" ", "") == "sart_tile=0" for o in args.opt)
+    K_FUSED_NAME, K_FP_NAME = ("k_sart_tile<true>", "k_sart_tile<false>") if tile else ("k_sart_seg<4,8,true>", "k_sart_seg<4,8,false>")
+    kernels = {K_FUSED_NAME: K_SART_FUSED, "k_bp_angle<4,4>": K_BP_ANGLE, K_FP_NAME: 1}   # names as rocprofv3 prints them
     for kid in kernels.values():
         _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
     t0 = time.perf_counter()
@@ -169,12 +174,12 @@ def main():
         vox_total = nloc * world * n * n
         # Algorithmic bytes per launch (SURVEY.md section 8d, V = voxels of this GPU's slab, fp32):
         #   k_bp_angle          single-angle voxel update: slab in + slab out + that angle's residual rows = 8V + 4 Nx N
-        #   k_sart_seg<..true>  BP(a_k)+FP(a_k+1): slab in + slab out + residual rows in + b rows in + residual rows
-        #                       out = 8V + 12 Nx N
-        #   k_sart_seg<..false> plain FP of one angle: slab in + b rows in + residual rows out = 4V + 8 Nx N
+        #   fused step          BP(a_k)+FP(a_k+1): slab in + slab out + residual rows in + b rows in + residual rows
+        #                       out = 8V + 12 Nx N   (the tile form's partial sums are traffic, not algorithmic bytes)
+        #   per-angle FP        slab in + b rows in + residual rows out = 4V + 8 Nx N
         V = float(nloc) * n * n
-        alg_bytes = {"k_bp_angle<4,4>": 8.0 * V + 4.0 * nloc * n, "k_sart_seg<4,8,true>": 8.0 * V + 12.0 * nloc * n,
-                     "k_sart_seg<4,8,false>": 4.0 * V + 8.0 * nloc * n}
+        alg_bytes = {"k_bp_angle<4,4>": 8.0 * V + 4.0 * nloc * n, K_FUSED_NAME: 8.0 * V + 12.0 * nloc * n,
+                     K_FP_NAME: 4.0 * V + 8.0 * nloc * n}
         roofs = {}
         for name, (cnt, tot) in prof.items():
             avg_ms = tot / cnt if cnt else 0.0
@@ -186,9 +191,11 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
             match = {"k_sart_seg<4,8,true>": "k_sart_seg<4, 8, true>", "k_bp_angle<4,4>": "k_bp_angle<4, 4>",
-                     "k_sart_seg<4,8,false>": "k_sart_seg<4, 8, false>"}
+                     "k_sart_seg<4,8,false>": "k_sart_seg<4, 8, false>", "k_sart_tile<true>": "k_sart_tile<true>",
+                     "k_sart_tile<false>": "k_sart_tile<false>"}
             if (nloc, n, nproj) == (512, 512, 90):
-                for name, key in match.items():
+                for name in roofs:
+                    key = match[name]
                     hit = [v for k, v in pmc.items() if key in k]
                     if hit:
                         roofs[name]["traffic"] = hit[0]["hbm_bytes_per_launch"]
@@ -216,7 +223,7 @@ def main():
             "final_dd": dd, "final_tv": tv,
             "roofline": dominant,
             "roofline_bp_angle": roofs["k_bp_angle<4,4>"],
-            "roofline_fp_angle": roofs["k_sart_seg<4,8,false>"],
+            "roofline_fp_angle": roofs[K_FP_NAME],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, nproj)

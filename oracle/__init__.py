@@ -76,8 +76,38 @@ def lib():
         L.orc_poisson_ml.restype = f64
         L.orc_poisson_ml.argtypes = [i32, i64, i64, P, P, P, P, P, f32, f32]
         L.orc_num_threads.restype = i32
+        L.orc_set_num_threads.restype = None
+        L.orc_set_num_threads.argtypes = [i32]
         _lib = L
+        if "OMP_NUM_THREADS" not in os.environ:
+            L.orc_set_num_threads(min(usable_cpus(), 32))      # parity cases are small; bench.py raises it for its baseline
     return _lib
+
+
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask, capped by a cgroup CPU quota when one is set (an OpenMP team
+    larger than that spins against the quota: a 16 x 16 x 2 TV step was seen to take seconds on such a host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
 
 
 def _p(a):

@@ -605,6 +605,16 @@ double orc_poisson_ml(int nslice, int64_t nrow, int64_t ncol, const int64_t *ptr
     return cost;
 }
 
+/* The checker runs on whatever host the tests land on: the caller bounds the team (usable CPUs, cgroup quota). */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -761,7 +761,9 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     *reinterpret_cast<V *>(partial + ((size_t)segbase[tile] + g) * sx + off) = acc;
 }
 
-// r[row][s] = (b - sum of the row's tile partials) / rowsum   (0 where rowsum == 0); one wave per (row, chunk)
+// r[row][s] = (b - sum of the row's tile partials) / rowsum   (0 where rowsum == 0).  One workgroup per (row, chunk):
+// its four waves each add a quarter of the row's list (a ray crosses ~N/11 tiles), the quarters are combined in fixed
+// order through LDS -- four times the loads in flight of a one-wave-per-row form (13.9 -> 8 us at 512^2 x 512).
 template <int VEC>
 __global__ __launch_bounds__(256) void k_resid_finish_idx(const float *__restrict__ partial, const uint32_t *__restrict__ rptr,
                                                            const uint32_t *__restrict__ ridx, const float *__restrict__ b,
@@ -769,14 +771,15 @@ __global__ __launch_bounds__(256) void k_resid_finish_idx(const float *__restric
                                                            int row0, int nrows, int nchunk, int sx)
 {
     typedef typename VecOf<VEC>::T V;
+    __shared__ V red[3][64];
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
-    int gw = blockIdx.x * 4 + wave;
-    if (gw >= nrows * nchunk) return;
-    int chunk = gw / nrows;
-    int row = row0 + (gw - chunk * nrows);
+    int chunk = blockIdx.x / nrows;
+    int row = row0 + (blockIdx.x - chunk * nrows);
     int off = chunk * (64 * VEC) + lane * VEC;
-    uint32_t kb = rptr[row], ke = rptr[row + 1];
+    uint32_t kb0 = rptr[row], ke0 = rptr[row + 1];
+    uint32_t q = (ke0 - kb0 + 3u) >> 2;
+    uint32_t kb = min(kb0 + wave * q, ke0), ke = min(kb + q, ke0);
     V acc = vzero<VEC>();
     const float *pp = partial + off;
     for (uint32_t k = kb; k < ke; k += 8) {               // 8 independent loads per trip, summed in list order
@@ -789,6 +792,10 @@ __global__ __launch_bounds__(256) void k_resid_finish_idx(const float *__restric
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (k + u < ke) acc += tv[u];
     }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
     size_t o = (size_t)row * sx + off;
     V bv = *reinterpret_cast<const V *>(b + o);
     float rs = rowsum[row];

@@ -349,8 +349,7 @@ static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float 
         LAUNCHCHK();
     }
     int nchunk = e->sxc / (64 * e->vec);
-    int64_t waves = (int64_t)e->n * nchunk;
-    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
     switch (e->vec) {
     case 4: hipLaunchKernelGGL((k_resid_finish_idx<4>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
     case 2: hipLaunchKernelGGL((k_resid_finish_idx<2>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
