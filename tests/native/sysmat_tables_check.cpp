@@ -119,7 +119,6 @@ int main(int argc, char **argv)
         std::vector<int> wr(t.st_max_ids, 0);
         for (int k = 0; k < snt; ++k) {
             int y0 = (k / stz) * T, z0 = (k % stz) * T;
-            uint32_t base = t.st_segbase[(size_t)i * snt + k];
             bool ended = false;
             for (int q = 0; q < MS; ++q) {
                 uint32_t b0 = t.st_seg[(((size_t)i * snt + k) * MS + q) * 2], nb = t.st_seg[(((size_t)i * snt + k) * MS + q) * 2 + 1];
@@ -135,8 +134,9 @@ int main(int argc, char **argv)
                     REQUIRE(y < N && z < N, "SART entry outside the image");
                     acc += (double)w * x[(int64_t)y * N + z];
                 }
-                REQUIRE(base + q < t.st_max_ids, "partial id out of range");
-                ps[base + q] = acc; wr[base + q]++;
+                uint32_t pid = t.st_segid[((size_t)i * snt + k) * MS + q];
+                REQUIRE(pid < t.st_max_ids, "partial id out of range");
+                ps[pid] = acc; wr[pid]++;
             }
             // cells against the cell table
             uint32_t w = t.st_win[(size_t)i * snt + k], lo = w & 0xFFFFu, nr = w >> 16;
@@ -162,7 +162,7 @@ int main(int argc, char **argv)
         for (int j = 0; j < N; ++j) {
             int64_t r = (int64_t)i * N + j;
             double sum = 0;
-            for (uint32_t q = t.st_rptr[r]; q < t.st_rptr[r + 1]; ++q) { REQUIRE(wr[t.st_ridx[q]] == 1, "row uses an unwritten partial"); sum += ps[t.st_ridx[q]]; wr[t.st_ridx[q]] = 2; }
+            for (uint32_t q = t.st_row_first[r]; q < t.st_row_first[r] + t.st_row_nseg[r]; ++q) { REQUIRE(q < t.st_max_ids && wr[q] == 1, "row uses an unwritten partial"); sum += ps[q]; wr[q] = 2; }
             worst_st = std::max(worst_st, std::fabs(sum - g[r]));
         }
         for (uint32_t q = 0; q < t.st_max_ids; ++q) REQUIRE(wr[q] != 1, "partial %u of angle %d belongs to no row", q, i);

@@ -584,7 +584,9 @@ __global__ __launch_bounds__(64) void k_sart_seg(const float *__restrict__ x_old
     *reinterpret_cast<V *>(partial + (size_t)it.id * sx + off) = acc;
 }
 
-// r[row][s] = (b - sum_segments partial) / rowsum   (0 where rowsum == 0); one wave per (row, chunk)
+// r[row][s] = (b - sum of the row's partials) / rowsum   (0 where rowsum == 0).  A row's partials have consecutive ids.
+// One workgroup per (row, chunk): its four waves each add a quarter of the list (the tile form leaves ~N/11 partials
+// per ray), the quarters are combined in fixed order through LDS.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ partial,
                                                        const uint32_t *__restrict__ row_first,
@@ -593,23 +595,28 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
                                                        float *__restrict__ r_out, int row0, int nrows, int nchunk, int sx)
 {
     typedef typename VecOf<VEC>::T V;
+    __shared__ V red[3][64];
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
-    int gw = blockIdx.x * 4 + wave;
-    if (gw >= nrows * nchunk) return;
-    int chunk = gw / nrows;
-    int row = row0 + (gw - chunk * nrows);
+    int chunk = blockIdx.x / nrows;
+    int row = row0 + (blockIdx.x - chunk * nrows);
     int off = chunk * (64 * VEC) + lane * VEC;
     uint32_t first = row_first[row], ns = row_nseg[row];
+    uint32_t q = (ns + 3u) >> 2;
+    uint32_t sb = min(wave * q, ns), se = min(sb + q, ns);
     V acc = vzero<VEC>();
     const float *pp = partial + (size_t)first * sx + off;
-    for (uint32_t s = 0; s < ns; s += 8) {            // 8 independent loads per trip, summed in segment order
+    for (uint32_t s = sb; s < se; s += 8) {           // 8 independent loads per trip, summed in segment order
         V t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (s + u < ns) ? *reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx) : vzero<VEC>();
+        for (int u = 0; u < 8; ++u) t[u] = (s + u < se) ? *reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx) : vzero<VEC>();
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += t[u];
     }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
     size_t o = (size_t)row * sx + off;
     V bv = *reinterpret_cast<const V *>(b + o);
     float rs = rowsum[row];
@@ -678,8 +685,8 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
 // in (coalesced), applies the pending voxel update of angle "prev" pixel-driven from the tile's window of residual rows
 // (staged in LDS; same arithmetic as k_bp_angle, bit-identical), streams the tile out, keeps the updated tile as an LDS
 // image and forms, for angle "next", the partial sums of the ray segments inside the tile from that image (one segment
-// per 16-lane group, entry batches shared by DPP rotation as in k_fp_tile).  k_resid_finish_idx adds a ray's partials
-// (ascending tile) and forms the residual.  Per angle: the slab read once and written once, plus ~9 % for the partials.
+// per 16-lane group, entry batches shared by DPP rotation as in k_fp_tile).  k_resid_finish adds a ray's partials
+// (consecutive ids, ascending tile) and forms the residual.  Per angle: the slab read once and written once, plus ~9 % for the partials.
 // Two workgroups per CU (75 KB LDS each) overlap one's streaming with the other's LDS phase.  In-place is safe: a
 // workgroup reads and writes only its own tile.
 constexpr int ST_T = 16, ST_PIX = ST_T * ST_T, ST_THREADS = 512, ST_MAXR = 26, ST_MAXSEG = 32;
@@ -689,7 +696,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
                                                            const float *__restrict__ r_prev, float beta,
-                                                           const uint2 *__restrict__ segs, const uint32_t *__restrict__ segbase,
+                                                           const uint2 *__restrict__ segs, const uint32_t *__restrict__ segid,
                                                            const uint2 *__restrict__ ent, float *__restrict__ partial,
                                                            int n, int sx, int tiles_z, int ntiles, int nchunk)
 {
@@ -744,6 +751,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     __syncthreads();
     // forward projection of "next": group g owns the tile's g-th ray segment
     uint2 sd = segs[(size_t)tile * ST_MAXSEG + g];
+    uint32_t pid = segid[(size_t)tile * ST_MAXSEG + g];
     if (sd.y == 0) return;                                // uniform inside a 16-lane DPP row
     const char *ib = reinterpret_cast<const char *>(img) + gl * 16;
     const uint2 *ep = ent + (size_t)sd.x * FT_BATCH + (gl & 7);
@@ -758,49 +766,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
         ST_FMA(0) ST_FMA(1) ST_FMA(2) ST_FMA(3) ST_FMA(4) ST_FMA(5) ST_FMA(6) ST_FMA(7)
 #undef ST_FMA
     }
-    *reinterpret_cast<V *>(partial + ((size_t)segbase[tile] + g) * sx + off) = acc;
-}
-
-// r[row][s] = (b - sum of the row's tile partials) / rowsum   (0 where rowsum == 0).  One workgroup per (row, chunk):
-// its four waves each add a quarter of the row's list (a ray crosses ~N/11 tiles), the quarters are combined in fixed
-// order through LDS -- four times the loads in flight of a one-wave-per-row form (13.9 -> 8 us at 512^2 x 512).
-template <int VEC>
-__global__ __launch_bounds__(256) void k_resid_finish_idx(const float *__restrict__ partial, const uint32_t *__restrict__ rptr,
-                                                           const uint32_t *__restrict__ ridx, const float *__restrict__ b,
-                                                           const float *__restrict__ rowsum, float *__restrict__ r_out,
-                                                           int row0, int nrows, int nchunk, int sx)
-{
-    typedef typename VecOf<VEC>::T V;
-    __shared__ V red[3][64];
-    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    int chunk = blockIdx.x / nrows;
-    int row = row0 + (blockIdx.x - chunk * nrows);
-    int off = chunk * (64 * VEC) + lane * VEC;
-    uint32_t kb0 = rptr[row], ke0 = rptr[row + 1];
-    uint32_t q = (ke0 - kb0 + 3u) >> 2;
-    uint32_t kb = min(kb0 + wave * q, ke0), ke = min(kb + q, ke0);
-    V acc = vzero<VEC>();
-    const float *pp = partial + off;
-    for (uint32_t k = kb; k < ke; k += 8) {               // 8 independent loads per trip, summed in list order
-        V tv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            uint32_t id = ridx[min(k + u, ke - 1)];        // wave-uniform: scalar loads
-            tv[u] = *reinterpret_cast<const V *>(pp + (size_t)id * sx);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (k + u < ke) acc += tv[u];
-    }
-    if (wave > 0) red[wave - 1][lane] = acc;
-    __syncthreads();
-    if (wave != 0) return;
-    acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
-    size_t o = (size_t)row * sx + off;
-    V bv = *reinterpret_cast<const V *>(b + o);
-    float rs = rowsum[row];
-    V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
-    *reinterpret_cast<V *>(r_out + o) = r;
+    *reinterpret_cast<V *>(partial + (size_t)pid * sx + off) = acc;
 }
 
 // ---- back-projector, all angles, tile-stationary form ------------------------------------------------------------

@@ -557,11 +557,10 @@ void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel
     split_rows_by_tile(m, N, nrows, T, T, tiles_1d, tmp_lpix, tmp_w, rsegs);
     t.st_cell.assign((size_t)P * ntiles * TP, Tables::TileCell{zero_row, 0.f, zero_row, 0.f});
     t.st_win.assign((size_t)P * ntiles, 0);
-    t.st_segbase.assign((size_t)P * ntiles, 0);
+    t.st_segid.assign((size_t)P * ntiles * MS, 0);
     t.st_seg.assign((size_t)P * ntiles * MS * 2, 0);
-    t.st_rptr.assign(nrows + 1, 0);
-    for (int64_t r = 0; r < nrows; ++r) t.st_rptr[r + 1] = t.st_rptr[r] + (uint32_t)rsegs[r].size();
-    t.st_ridx.assign(std::max<size_t>(1, t.st_rptr[nrows]), 0);
+    t.st_row_first.assign(nrows, 0);
+    t.st_row_nseg.assign(nrows, 0);
     // batches per angle (prefix over angles), so that the angles can be emitted in parallel
     std::vector<uint64_t> angle_batches(P + 1, 0);
     for (int i = 0; i < P; ++i) {
@@ -582,10 +581,11 @@ void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel
             std::fill(nseg.begin(), nseg.end(), 0u);
             for (int j = 0; j < N; ++j) for (auto &s : rsegs[(int64_t)i * N + j]) nseg[s.tile]++;
             uint32_t id = 0;
-            for (uint32_t k = 0; k < ntiles; ++k) {
-                t.st_segbase[(size_t)i * ntiles + k] = id;
-                if (nseg[k] > (uint32_t)MS) bad[i] = 1;
-                id += nseg[k];
+            for (uint32_t k = 0; k < ntiles; ++k) if (nseg[k] > (uint32_t)MS) bad[i] = 1;
+            for (int j = 0; j < N; ++j) {
+                int64_t r = (int64_t)i * N + j;
+                t.st_row_first[r] = id; t.st_row_nseg[r] = (uint32_t)rsegs[r].size();
+                id += (uint32_t)rsegs[r].size();
             }
             ids_of[i] = id;
             if (bad[i]) continue;
@@ -604,7 +604,7 @@ void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel
                         t.st_off[(size_t)batch * NB + e] = tmp_lpix[src + e] * (uint32_t)pixel_bytes;
                         t.st_w[(size_t)batch * NB + e] = tmp_w[src + e];
                     }
-                    t.st_ridx[t.st_rptr[r] + q++] = t.st_segbase[(size_t)i * ntiles + s.tile] + k;
+                    t.st_segid[((size_t)i * ntiles + s.tile) * MS + k] = t.st_row_first[r] + q++;
                     batch += nb; src += s.cnt;
                 }
             }

@@ -64,15 +64,15 @@ struct Tables {
     //                                           staged ray window (zero row = row st_maxr)
     //   st_win[i*ntiles + tile]                 first ray | rays << 16 of that window
     //   st_seg[(i*ntiles + tile)*ST_MAXSEG + k] {first batch, batches} of the k-th ray segment of angle i in the tile
-    //   st_segbase[i*ntiles + tile]             partial-sum id (within the angle) of its first segment
+    //   st_segid[same index]                    its partial-sum id within the angle: a row's segments (ascending tile)
+    //                                           have consecutive ids, st_row_first[row] + 0 .. st_row_nseg[row] - 1
     //   st_off / st_w                           entry batches (TILE_BATCH entries, zero-weight padding -> zero pixel)
-    //   st_rptr / st_ridx                       per row: its partial-sum ids, ascending tile
     static constexpr int ST_MAXSEG = 32;
     bool st_ok = false;
     int st_t = 0, st_tiles = 0, st_tiles_z = 0, st_maxr = 0;
     uint32_t st_max_ids = 0;                     // most partial sums of one angle
     std::vector<TileCell> st_cell;
-    std::vector<uint32_t> st_win, st_segbase, st_off, st_rptr, st_ridx;
+    std::vector<uint32_t> st_win, st_segid, st_off, st_row_first, st_row_nseg;
     std::vector<uint32_t> st_seg;                // 2 words per slot
     std::vector<float> st_w;
 };

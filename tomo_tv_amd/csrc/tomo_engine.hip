@@ -71,7 +71,7 @@ struct tomo_engine {
     int st_ntiles = 0, st_tiles_z = 0;
     uint32_t st_max_ids = 0;
     uint4 *d_st_cell = nullptr;
-    uint32_t *d_st_win = nullptr, *d_st_segbase = nullptr, *d_st_rptr = nullptr, *d_st_ridx = nullptr;
+    uint32_t *d_st_win = nullptr, *d_st_segid = nullptr, *d_st_row_first = nullptr, *d_st_row_nseg = nullptr;
     uint2 *d_st_seg = nullptr, *d_st_ent = nullptr;
     float *st_partial = nullptr;
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
@@ -309,8 +309,7 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
         LAUNCHCHK();
     }
     {
-        int64_t waves = (int64_t)e->n * nchunk;
-        dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
         switch (e->vec) {
         case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
         case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
@@ -344,16 +343,16 @@ static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float 
         hipLaunchKernelGGL((k_sart_tile<FUSED>), grid, block, ST_LDS_V * 16, e->stream, x, x,
                            FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
                            FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
-                           e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segbase + (size_t)next * nt, e->d_st_ent, e->st_partial,
+                           e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, e->st_partial,
                            e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64);
         LAUNCHCHK();
     }
     int nchunk = e->sxc / (64 * e->vec);
     dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
     switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_resid_finish_idx<4>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-    case 2: hipLaunchKernelGGL((k_resid_finish_idx<2>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-    default: hipLaunchKernelGGL((k_resid_finish_idx<1>), grid, block, 0, e->stream, e->st_partial, e->d_st_rptr, e->d_st_ridx, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+    case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+    case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+    default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, e->stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
     }
     LAUNCHCHK();
     return TOMO_OK;
@@ -469,18 +468,18 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             for (size_t k = 0; k < sent.size(); ++k) { uint32_t bits; std::memcpy(&bits, &t.st_w[k], 4); sent[k] = make_uint2(t.st_off[k], bits); }
             if ((rc = dev_alloc((void **)&e->d_st_cell, t.st_cell.size() * sizeof(uint4), false, e->stream))) return rc;
             if ((rc = dev_alloc((void **)&e->d_st_win, t.st_win.size() * 4, false, e->stream))) return rc;
-            if ((rc = dev_alloc((void **)&e->d_st_segbase, t.st_segbase.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_segid, t.st_segid.size() * 4, false, e->stream))) return rc;
             if ((rc = dev_alloc((void **)&e->d_st_seg, t.st_seg.size() * 4, false, e->stream))) return rc;
             if ((rc = dev_alloc((void **)&e->d_st_ent, sent.size() * sizeof(uint2), false, e->stream))) return rc;
-            if ((rc = dev_alloc((void **)&e->d_st_rptr, t.st_rptr.size() * 4, false, e->stream))) return rc;
-            if ((rc = dev_alloc((void **)&e->d_st_ridx, t.st_ridx.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_row_first, t.st_row_first.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_st_row_nseg, t.st_row_nseg.size() * 4, false, e->stream))) return rc;
             HIPCHK(hipMemcpy(e->d_st_cell, t.st_cell.data(), t.st_cell.size() * sizeof(uint4), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_st_win, t.st_win.data(), t.st_win.size() * 4, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(e->d_st_segbase, t.st_segbase.data(), t.st_segbase.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_segid, t.st_segid.data(), t.st_segid.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_st_seg, t.st_seg.data(), t.st_seg.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_st_ent, sent.data(), sent.size() * sizeof(uint2), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(e->d_st_rptr, t.st_rptr.data(), t.st_rptr.size() * 4, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(e->d_st_ridx, t.st_ridx.data(), t.st_ridx.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_row_first, t.st_row_first.data(), t.st_row_first.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_st_row_nseg, t.st_row_nseg.data(), t.st_row_nseg.size() * 4, hipMemcpyHostToDevice));
         }
         { decltype(t.st_cell)().swap(t.st_cell); decltype(t.st_off)().swap(t.st_off); decltype(t.st_w)().swap(t.st_w); }
         build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, FB_A, t);
@@ -603,7 +602,7 @@ int tomo_destroy(tomo_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
-    void *ptrs[] = {e->d_st_cell, e->d_st_win, e->d_st_segbase, e->d_st_seg, e->d_st_ent, e->d_st_rptr, e->d_st_ridx, e->st_partial, e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->d_st_cell, e->d_st_win, e->d_st_segid, e->d_st_seg, e->d_st_ent, e->d_st_row_first, e->d_st_row_nseg, e->st_partial, e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
