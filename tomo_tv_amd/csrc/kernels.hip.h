@@ -777,8 +777,10 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
 // coalesced loads, 8 pixels per group and angle, and are shared by DPP row rotation as in k_fp_tile: at step J lane l
 // works on pixel (l + J) mod 8 of its group, always into acc[J], so the sums never move between lanes.
 // Same two FMAs per pixel and angle in the same order as k_bp_all: results are bit-identical.
-constexpr int FB_A = 4, FB_MAXR = 40, FB_BUF = (FB_A * FB_MAXR + 1) * 256, FB_LDS_BYTES = 2 * FB_BUF;
-constexpr int FB_MAX_PROJ = 8192;                       // ray windows of all angles sit in LDS (4 B each)
+constexpr int FB_A = 4, FB_MAXR = 40, FB_BUF = (FB_A * FB_MAXR + 1) * 256;
+constexpr int FB_LDS_BYTES = FT_PIX * 256;              // two stage buffers (82 KB); the epilogue reuses it as a 128 KiB tile image
+static_assert(2 * FB_BUF <= FB_LDS_BYTES, "stage buffers must fit the tile image");
+constexpr int FB_MAX_PROJ = 4096;                       // ray windows of all angles sit in LDS (4 B each)
 constexpr int FB_SLOTS = FB_A * FB_MAXR * 16, FB_Q = (FB_SLOTS + FT_THREADS - 1) / FT_THREADS;
 
 __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, const uint4 *__restrict__ tcell,
@@ -860,24 +862,30 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
 #undef FB_ROW
 #undef FB_STAGE_STORE
 #undef FB_STAGE_LOAD
+    // Un-rotate through LDS (the stage buffers are dead): lane l holds pixel (l + J) mod 8 in acc[J]; stored as is,
+    // a wave instruction would scatter 16-byte pieces over 8 pixels (PMC: 3.1x the bytes written).  Afterwards
+    // every group reads its pixels in order and the x read / write are whole 256-byte pieces.
+    __syncthreads();
+#define FB_PUT(J) fb_lds[(g * 8 + (int)row_ror<J>((uint32_t)(gl & 7))) * 16 + gl] = acc[J];
+    FB_PUT(0) FB_PUT(1) FB_PUT(2) FB_PUT(3) FB_PUT(4) FB_PUT(5) FB_PUT(6) FB_PUT(7)
+#undef FB_PUT
+    __syncthreads();
     const int off = c * 64 + gl * 4;
-#define FB_OUT(J)                                                                                         \
-    {                                                                                                     \
-        int lp = g * 8 + (int)row_ror<J>((uint32_t)(gl & 7));                                             \
-        int y = ty * FT_TY + lp / FT_TZ, z = tz * FT_TZ + lp % FT_TZ;                                     \
-        if (y < n && z < n) {                                                                             \
-            size_t p = (size_t)y * n + z;                                                                 \
-            V a = acc[J];                                                                                 \
-            if (colsum) { float cs = colsum[p]; a = cs > 0.f ? a / cs : vzero<4>(); }                     \
-            float *xp = x + p * sx + off;                                                                 \
-            V nv = beta * a;                                                                              \
-            if (alpha != 0.f) nv = alpha * (*reinterpret_cast<const V *>(xp)) + nv;                       \
-            if (clamp) { nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f); } \
-            *reinterpret_cast<V *>(xp) = nv;                                                              \
-        }                                                                                                 \
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        int lp = g * 8 + J;
+        int y = ty * FT_TY + lp / FT_TZ, z = tz * FT_TZ + lp % FT_TZ;
+        if (y < n && z < n) {
+            size_t p = (size_t)y * n + z;
+            V a = fb_lds[lp * 16 + gl];
+            if (colsum) { float cs = colsum[p]; a = cs > 0.f ? a / cs : vzero<4>(); }
+            float *xp = x + p * sx + off;
+            V nv = beta * a;
+            if (alpha != 0.f) nv = alpha * (*reinterpret_cast<const V *>(xp)) + nv;
+            if (clamp) { nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f); }
+            *reinterpret_cast<V *>(xp) = nv;
+        }
     }
-    FB_OUT(0) FB_OUT(1) FB_OUT(2) FB_OUT(3) FB_OUT(4) FB_OUT(5) FB_OUT(6) FB_OUT(7)
-#undef FB_OUT
 }
 
 // ---- ART (Kaczmarz), row-sequential by definition (ctvlib.cpp:137-155) -------------------------------
