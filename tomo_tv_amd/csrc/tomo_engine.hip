@@ -65,7 +65,7 @@ struct tomo_engine {
     uint32_t *d_ft_slot_ptr = nullptr, *d_ft_slot_seg0 = nullptr, *d_ft_rsptr = nullptr, *d_ft_rsidx = nullptr;
     uint2 *d_ft_tent = nullptr;
     float *ft_part = nullptr, *ft_part_aux = nullptr;
-    int num_cu = 256;
+    bool attr_fp = false, attr_bp = false, attr_st = false;   // dynamic-LDS limits raised on this engine's device
     int sart_tile = 1;                            // fused SART step on streamed image tiles (k_sart_tile) when the geometry allows it
     bool st_ok = false;
     int st_ntiles = 0, st_tiles_z = 0;
@@ -230,10 +230,9 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
         int ncp = (int)std::min<size_t>(nchunk, std::max<size_t>(1, e->ft_scratch_cap / per_chunk));
         if (ncp >= 4) ncp &= ~3; else if (ncp >= 2) ncp &= ~1;
         e->ft_ncp = ncp;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!e->attr_fp) {   // per engine: the attribute belongs to the (function, device) pair
             HIPCHK(hipFuncSetAttribute((const void *)k_fp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FT_LDS_BYTES));
-            attr_set = true;
+            e->attr_fp = true;
         }
     }
     float **slot = (e->aux && e->stream == e->aux) ? &e->ft_part_aux : &e->ft_part;
@@ -326,11 +325,10 @@ template <bool FUSED>
 static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float *r, float beta)
 {
     int rc;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!e->attr_st) {
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
-        attr_set = true;
+        e->attr_st = true;
     }
     if (!e->st_partial) {
         if ((rc = dev_alloc((void **)&e->st_partial, (size_t)std::max<uint32_t>(1, e->st_max_ids) * e->sx * sizeof(float), true, e->stream))) return rc;
@@ -361,10 +359,9 @@ static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float 
 static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
 {
     if (e->bp_tile && e->fb_ok) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!e->attr_bp) {
             HIPCHK(hipFuncSetAttribute((const void *)k_bp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES + FB_MAX_PROJ * 4));
-            attr_set = true;
+            e->attr_bp = true;
         }
         const int nchunk64 = e->sxc / 64;
         dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * nchunk64)), block(FT_THREADS);
@@ -399,11 +396,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
-    {
-        int ncu = 0;
-        HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, e->device));
-        e->num_cu = std::max(8, (ncu / 8) * 8);
-    }
+
     std::vector<uint32_t> ptr32(m.nrow + 1);
     for (int64_t r = 0; r <= m.nrow; ++r) ptr32[r] = (uint32_t)m.ptr[r];
     std::vector<uint2> ent(e->nnz ? e->nnz : 1);
