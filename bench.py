@@ -5,7 +5,8 @@
 
 A step = one ASD-POCS outer iteration (examples/sim_ASD.py:66-94): copy_recon, one SART sweep over all
 tilts, step norm, data distance (a full forward projection), copy_recon, 10 TV gradient-descent steps, step
-norm.  Synthetic phantom + tilt series are resident in HBM before the timed region.  N > 1: one rank per GPU,
+norm (the engine forms the two norms and snapshot copies inside the sweep's last back-projection and the last
+descent step: tomo_sart_tracked / tomo_tv_gd_tracked).  Synthetic phantom + tilt series are resident in HBM before the timed region.  N > 1: one rank per GPU,
 each owns a 512-slice slab (weak scaling); the only cross-rank traffic is scalar all-reduces and TV halo planes.
 Prints ONE JSON line (rank 0).
 """
@@ -25,21 +26,28 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 def asd_pocs_step(t, st):
     """One outer iteration, state dict st carries beta / dPOCS (defaults of gpu/reconstructor.py:158-161)."""
-    t.copy_recon()
-    t.SART(st["beta"], 1)
-    st["beta"] *= 0.9985
-    if st["i"] == 0:
-        st["dPOCS"] = t.matrix_2norm() * 0.2
-        dp = st["dPOCS"] / 0.2
-    else:
-        dp = t.matrix_2norm()
-    t.copy_recon()
-    if hasattr(t, "data_distance_begin"):      # engine: residual of the SART result on the second stream, under the TV steps
+    if hasattr(t, "SART_tracked"):
+        # engine (= TomoGPU.asd_pocs): the step norms and snapshot copies ride on the last back-projection / last
+        # descent pass; the residual of the SART result runs on the second stream under the TV steps
+        if st["i"] == 0:
+            t.copy_recon()
+        dp = t.SART_tracked(st["beta"], 1)
+        st["beta"] *= 0.9985
+        if st["i"] == 0:
+            st["dPOCS"] = dp * 0.2
         t.data_distance_begin()
-        tv = t.tv_gd(10, st["dPOCS"])
-        dg = t.matrix_2norm()
+        tv, dg = t.tv_gd_tracked(10, st["dPOCS"])
         dd = t.data_distance_end() / st["norm"]
-    else:                                      # oracle (cpu_baseline): same work, sequentially
+    else:                                      # oracle (cpu_baseline): the same work as separate calls
+        t.copy_recon()
+        t.SART(st["beta"], 1)
+        st["beta"] *= 0.9985
+        if st["i"] == 0:
+            st["dPOCS"] = t.matrix_2norm() * 0.2
+            dp = st["dPOCS"] / 0.2
+        else:
+            dp = t.matrix_2norm()
+        t.copy_recon()
         dd = t.data_distance() / st["norm"]
         tv = t.tv_gd(10, st["dPOCS"])
         dg = t.matrix_2norm()
@@ -150,7 +158,8 @@ def main():
     # the fused step and the plain per-angle FP run as k_sart_tile<..> unless --opt sart_tile=0 selects the ray-walk form
     tile = not any(o.replace(" ", "") == "sart_tile=0" for o in args.opt)
     K_FUSED_NAME, K_FP_NAME = ("k_sart_tile<true>", "k_sart_tile<false>") if tile else ("k_sart_seg<4,8,true>", "k_sart_seg<4,8,false>")
-    kernels = {K_FUSED_NAME: K_SART_FUSED, "k_bp_angle<4,4>": K_BP_ANGLE, K_FP_NAME: 1}   # names as rocprofv3 prints them
+    K_BP_NAME = "k_bp_angle<4,4,true>"   # the sweep's last back-projection, tracked form (also step norm + snapshot copy)
+    kernels = {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1}   # names as rocprofv3 prints them
     for kid in kernels.values():
         _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
     t0 = time.perf_counter()
@@ -173,12 +182,13 @@ def main():
     if rank == 0:
         vox_total = nloc * world * n * n
         # Algorithmic bytes per launch (SURVEY.md section 8d, V = voxels of this GPU's slab, fp32):
-        #   k_bp_angle          single-angle voxel update: slab in + slab out + that angle's residual rows = 8V + 4 Nx N
+        #   k_bp_angle<..true>  single-angle voxel update that also forms the step norm and refreshes the snapshot:
+        #                       slab + snapshot in, slab + snapshot out, that angle's residual rows = 16V + 4 Nx N
         #   fused step          BP(a_k)+FP(a_k+1): slab in + slab out + residual rows in + b rows in + residual rows
         #                       out = 8V + 12 Nx N   (the tile form's partial sums are traffic, not algorithmic bytes)
         #   per-angle FP        slab in + b rows in + residual rows out = 4V + 8 Nx N
         V = float(nloc) * n * n
-        alg_bytes = {"k_bp_angle<4,4>": 8.0 * V + 4.0 * nloc * n, K_FUSED_NAME: 8.0 * V + 12.0 * nloc * n,
+        alg_bytes = {K_BP_NAME: 16.0 * V + 4.0 * nloc * n, K_FUSED_NAME: 8.0 * V + 12.0 * nloc * n,
                      K_FP_NAME: 4.0 * V + 8.0 * nloc * n}
         roofs = {}
         for name, (cnt, tot) in prof.items():
@@ -190,7 +200,7 @@ def main():
         # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), null if absent
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            match = {"k_sart_seg<4,8,true>": "k_sart_seg<4, 8, true>", "k_bp_angle<4,4>": "k_bp_angle<4, 4>",
+            match = {"k_sart_seg<4,8,true>": "k_sart_seg<4, 8, true>", "k_bp_angle<4,4,true>": "k_bp_angle<4, 4, true>",
                      "k_sart_seg<4,8,false>": "k_sart_seg<4, 8, false>", "k_sart_tile<true>": "k_sart_tile<true>",
                      "k_sart_tile<false>": "k_sart_tile<false>"}
             if (nloc, n, nproj) == (512, 512, 90):
@@ -222,7 +232,7 @@ def main():
                        "slices_per_gpu": nloc, "nray": n, "nproj": nproj, "sharding": f"tilt-axis slabs x{world}"},
             "final_dd": dd, "final_tv": tv,
             "roofline": dominant,
-            "roofline_bp_angle": roofs["k_bp_angle<4,4>"],
+            "roofline_bp_angle": roofs[K_BP_NAME],
             "roofline_fp_angle": roofs[K_FP_NAME],
         }
         if world == 1 and not args.no_cpu_baseline:

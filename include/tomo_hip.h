@@ -105,6 +105,10 @@ int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter);
  * (sequential)  tomoengine.cpp:151-179 */
 int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *order);
 int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order); /* multimodal.cpp:377-396 */
+/* The sweep of tomo_sart_data whose last back-projection also leaves ||x_new - track_vol||^2 in scalar `slot` and
+ * copies x_new into track_vol: the `matrix_2norm()` + `copy_recon()` pair that follows the SART sweep in the ASD-POCS
+ * loop (examples/sim_ASD.py:70-78, gpu/reconstructor.py:168-176) without two more passes over the slab. */
+int tomo_sart_tracked(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order, int track_vol, int slot);
 /* tomoengine::CGLS(nIter): CGLS restarted from the current volume, per slice, then positivity  tomoengine.cpp:207-229 */
 int tomo_cgls(tomo_engine *e, int vol, int niter);
 /* tomoengine::FBP(apply_positivity): recon = scale * A^T (taps * b), taps[0..Nray-1] = symmetric real-space filter
@@ -154,6 +158,8 @@ int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last);
 int tomo_tv_partial(tomo_engine *e, int vol, float eps);                /* tv_gd.cu:27-47 -> TOMO_S_TV */
 int tomo_tv_grad(tomo_engine *e, float eps);                            /* ctvlib.cpp:415-449 -> TOMO_S_GNORM */
 int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp);             /* ctvlib.cpp:452-458 (+461 when clamp) */
+/* the same step, also ||recon_new - track_vol||^2 -> scalar `slot` and track_vol = recon_new (sim_ASD.py:86-88) */
+int tomo_tv_update_tracked(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot);
 int tomo_fgp_begin(tomo_engine *e);                                     /* tv_fgp.cu:216-227 */
 int tomo_fgp_begin_vol(tomo_engine *e, int vol);                        /* one element of cuda_tv_fgp_4D (chemistry/.../tv_fgp.cu:192) */
 int tomo_fgp_obj(tomo_engine *e, float lambda);                         /* :44-65 + :143-154 */
@@ -163,6 +169,7 @@ int tomo_fgp_end(tomo_engine *e, int iters);                            /* :272 
 /* whole-call forms for a single slab (= the reference's single-GPU calls) */
 int tomo_tv(tomo_engine *e, int vol, float eps);                        /* tomoengine.cpp:439-442 tv_3D -> TOMO_S_TV */
 int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps);         /* :445 tv_gd_3D; TV before descent -> TOMO_S_TV */
+int tomo_tv_gd_tracked(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot); /* last step tracked */
 int tomo_tv_fgp(tomo_engine *e, int iters, float lambda);               /* :448-450 tv_fgp_3D; TV of input -> TOMO_S_TV */
 int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda);  /* multimodal.cpp:497 tv_fgp_4D, one element */
 

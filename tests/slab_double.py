@@ -105,6 +105,17 @@ class OracleSlabBackend:
         assert vid == VOL_RECON and order is None
         self.t.SART(beta, niter)
 
+    def c_sart_tracked(self, vid, sino, beta, niter, order, track, slot):
+        assert vid == VOL_RECON and sino == 0 and order is None
+        self.t.SART(beta, niter)
+        self.c_diff_norm_sq(vid, track, slot)
+        self._v(track)[:] = self._v(vid)
+
+    def c_tv_update_tracked(self, dPOCS, clamp, track, slot):
+        self.c_tv_update(dPOCS, clamp)
+        self.c_diff_norm_sq(VOL_RECON, track, slot)
+        self._v(track)[:] = self._v(VOL_RECON)
+
     def c_data_distance_sq(self, vid):
         self.t.forward_projection()
         d = (self.t.g.astype(np.float64) - self.t.b) if False else (self.t.g - self.t.b)

@@ -37,6 +37,7 @@ def _worker(rank, world, port, N, P, Nx, out_path):
         from tomo_tv_amd import engine
         from tomo_tv_amd.distributed import SlabComm
         from tomo_tv_amd.phantom import ellipsoids
+        from tomo_tv_amd._lib import VOL_TEMP
 
         class ShardedEngine(engine.tomoengine):
             _backend_cls = OracleSlabBackend
@@ -64,6 +65,11 @@ def _worker(rank, world, port, N, P, Nx, out_path):
         res["tv_fgp0"] = t.tv_fgp(3, 0.05)
         vol_fgp = t.get_volume()
         mid = t.get_recon(Nx // 2)              # collective: broadcast from the owner
+        # tracked forms (norm + snapshot inside the last pass) against the separate calls
+        t.copy_recon()
+        res["dp_trk"] = t.SART_tracked(0.5, 1)
+        res["tv_trk"], res["dg_trk"] = t.tv_gd_tracked(2, 0.1)
+        vol_trk, tmp_trk = t.get_volume(), t.get_volume(VOL_TEMP)
         first, nloc = t.first, t.nloc
         parts = [None] * world
         dist.all_gather_object(parts, (first, nloc))
@@ -78,9 +84,16 @@ def _worker(rank, world, port, N, P, Nx, out_path):
             ref_gd = full.recon.copy()
             want["tv_fgp0"] = full.tv_fgp(3, 0.05)
             ref_fgp = full.recon.copy()
+            full.copy_recon()
+            full.SART(0.5, 1)
+            want["dp_trk"] = full.matrix_2norm()
+            full.copy_recon()
+            want["tv_trk"] = full.tv_gd(2, 0.1)
+            want["dg_trk"] = full.matrix_2norm()
+            ref_trk = full.recon.copy()
             np.savez(out_path, keys=np.array(sorted(want)), got=np.array([res[k] for k in sorted(want)]),
                      want=np.array([want[k] for k in sorted(want)]), vol_gd=vol_gd, ref_gd=ref_gd, vol_fgp=vol_fgp,
-                     ref_fgp=ref_fgp, mid=mid, parts=np.array(parts))
+                     ref_fgp=ref_fgp, mid=mid, parts=np.array(parts), vol_trk=vol_trk, tmp_trk=tmp_trk, ref_trk=ref_trk)
     finally:
         dist.destroy_process_group()
 
@@ -95,6 +108,7 @@ def test_sharded_equals_single_process(tmp_path, world, Nx):
     assert np.allclose(r["vol_gd"], r["ref_gd"], rtol=0, atol=2e-6)
     assert np.allclose(r["vol_fgp"], r["ref_fgp"], rtol=0, atol=2e-6)
     assert np.array_equal(r["mid"], r["vol_fgp"][Nx // 2])
+    assert np.allclose(r["vol_trk"], r["ref_trk"], rtol=0, atol=2e-6) and np.array_equal(r["vol_trk"], r["tmp_trk"])
     parts = r["parts"]
     assert parts[0][0] == 0 and sum(p[1] for p in parts) == Nx
     assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))

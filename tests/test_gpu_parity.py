@@ -646,3 +646,36 @@ def test_matrix_whose_ray_windows_defeat_the_tile_kernels(gpu):
     for _ in range(3):
         dev.SIRT(1.0 / L); ref.SIRT(1.0 / L)
     assert rel_l2(dev.get_volume(), ref.recon) < 1e-5
+
+
+@pytest.mark.parametrize("opts", [{}, {"sart_tile": 0}, {"sart_fused": 0}])
+def test_tracked_sart_and_tv_equal_the_separate_calls(gpu, opts):
+    """tomo_sart_tracked / tomo_tv_gd_tracked = SART; matrix_2norm; copy_recon and tv_gd; matrix_2norm; copy_recon
+    (examples/sim_ASD.py:68-88) with the norm and the snapshot formed inside the last pass: same volumes bit for bit."""
+    N, P, Nx = 48, 7, 130
+    ang = np.linspace(-70, 70, P)
+    x = ellipsoids(Nx, N, seed=8)
+    a, b = tomoengine(Nx, N, ang * np.pi / 180), tomoengine(Nx, N, ang * np.pi / 180)
+    for t in (a, b):
+        for k, v in opts.items():
+            t.set_option(k, v)
+        t.set_volume(x, VOL_ORIGINAL)
+        t.create_projections()
+        t.restart_recon()
+        t.copy_recon()
+    for it in range(3):
+        a.SART(0.5, 1); dp_a = a.matrix_2norm(); a.copy_recon()
+        dp_b = b.SART_tracked(0.5, 1)
+        assert abs(dp_a - dp_b) <= 1e-10 * dp_a
+        assert np.array_equal(a.get_volume(VOL_TEMP), b.get_volume(VOL_TEMP))
+        b.data_distance_begin()                          # reads TEMP on the second stream while TV runs
+        tv_a = a.tv_gd(4, 0.2 * dp_a); dg_a = a.matrix_2norm(); a.copy_recon()
+        tv_b, dg_b = b.tv_gd_tracked(4, 0.2 * dp_b)
+        dd_b = b.data_distance_end()
+        assert abs(tv_a - tv_b) <= 1e-10 * tv_a and abs(dg_a - dg_b) <= 1e-10 * dg_a
+        assert np.array_equal(a.get_volume(), b.get_volume())
+        assert np.array_equal(a.get_volume(VOL_TEMP), b.get_volume(VOL_TEMP))
+        assert dd_b > 0
+    # zero TV steps: positivity only, still tracked
+    tv_b, dg_b = b.tv_gd_tracked(0, 0.1)
+    assert dg_b == 0.0 or dg_b < 1e-3

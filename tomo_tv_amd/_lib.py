@@ -79,6 +79,9 @@ SIGNATURES = {
     "tomo_fbp": [_p, _p, _f, _i],
     "tomo_sirt_data": [_p, _i, _i, _i],
     "tomo_sart_data": [_p, _i, _i, _f, _i, _p],
+    "tomo_sart_tracked": [_p, _i, _i, _f, _i, _p, _i, _i],
+    "tomo_tv_update_tracked": [_p, _f, _i, _i, _i],
+    "tomo_tv_gd_tracked": [_p, _i, _f, _f, _i, _i],
     "tomo_poisson_residual": [_p, _i, _i, _i],
     "tomo_scale_volume": [_p, _i, _f],
     "tomo_sino_diff_norm_sq": [_p, _i, _i, _i],

@@ -459,10 +459,13 @@ __global__ __launch_bounds__(256) void k_fp_tile_reduce(const float *__restrict_
 // normalised residual rows (N rows, L2 resident).  One wave owns PPW consecutive pixels of a slice chunk.
 struct CellD { uint32_t r0; float w0; uint32_t r1; float w1; };
 
-template <int VEC, int PPW>
+// TRACK: the same pass also leaves sum (x_new - track)^2 in part[] and overwrites track with x_new -- the step norm and the
+// snapshot copy that an ASD-POCS iteration takes after its SART sweep, without two more passes over the slab.
+template <int VEC, int PPW, bool TRACK>
 __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const CellD *__restrict__ cell,
                                                    const float *__restrict__ r, float beta, int npix, int sx,
-                                                   int ngroups, int nchunk)
+                                                   int ngroups, int nchunk, float *__restrict__ track,
+                                                   double *__restrict__ part)
 {
     typedef typename VecOf<VEC>::T V;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
     int p0 = grp * PPW;
     if (p0 >= npix || chunk >= nchunk) return;   // grid is rounded up to whole workgroups
     int off = chunk * (64 * VEC) + lane * VEC;
-    V xv[PPW], r0[PPW], r1[PPW];
+    V xv[PPW], r0[PPW], r1[PPW], tk[PPW];
     CellD c[PPW];
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
@@ -482,7 +485,9 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
         xv[q] = *reinterpret_cast<const V *>(x + (size_t)p * sx + off);
         r0[q] = *reinterpret_cast<const V *>(r + (size_t)c[q].r0 * sx + off);
         r1[q] = *reinterpret_cast<const V *>(r + (size_t)c[q].r1 * sx + off);
+        if (TRACK) tk[q] = *reinterpret_cast<const V *>(track + (size_t)p * sx + off);
     }
+    double local = 0.0;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         int p = p0 + q;
@@ -495,7 +500,16 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
 #pragma unroll
             for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
             *reinterpret_cast<V *>(x + (size_t)p * sx + off) = nv;
+            if (TRACK) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { float d = velem<VEC>(nv, i) - velem<VEC>(tk[q], i); local += (double)(d * d); }
+                *reinterpret_cast<V *>(track + (size_t)p * sx + off) = nv;
+            }
         }
+    }
+    if (TRACK) {
+        local = wave_sum(local);
+        if (lane == 0) atomicAdd(&part[blockIdx.x & (NPART - 1)], local);
     }
 }
 
@@ -1350,16 +1364,25 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
 }
 
 // x -= dPOCS * g / ||g||   (ctvlib.cpp:452-458); gnorm2 = global sum g^2 on the device; optional clamp (:461)
+// TRACK: also sum (x_new - track)^2 -> part[] and track = x_new (the step norm and snapshot after the TV descent)
+template <bool TRACK>
 __global__ __launch_bounds__(256) void k_tv_update(f4 *__restrict__ x, const f4 *__restrict__ g,
                                                     const double *__restrict__ gnorm2, float dPOCS, int clamp,
-                                                    int64_t n4)
+                                                    int64_t n4, f4 *__restrict__ track, double *__restrict__ part)
 {
     float nrm = (float)sqrt(*gnorm2);
+    double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f4 v = x[i] - (dPOCS * g[i]) / nrm;
         if (clamp) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         x[i] = v;
+        if (TRACK) {
+            f4 d = v - track[i];
+            acc += (double)(d.x * d.x) + (double)(d.y * d.y) + (double)(d.z * d.z) + (double)(d.w * d.w);
+            track[i] = v;
+        }
     }
+    if (TRACK) block_accumulate(acc, part);
 }
 
 // FGP-TV (tv_fgp.cu).  Non-periodic: i-1 below the first GLOBAL slice and i+1 above the last are "0" terms.

@@ -266,7 +266,7 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
 
 constexpr int BP_PPW = 4;
 
-static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_angle, float beta)
+static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_angle, float beta, float *track = nullptr)
 {
     ProfScope ps(e, TOMO_K_BP_ANGLE);
     int nchunk = e->sxc / (64 * e->vec);
@@ -274,10 +274,19 @@ static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_a
     int64_t waves = (int64_t)ngroups * nchunk;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const CellD *cell = e->d_cell + (size_t)angle * e->npix;
+    if (track) {   // caller brackets with reduce_begin / reduce_end
+        switch (e->vec) {
+        case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, true>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part); break;
+        case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, true>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part); break;
+        default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, true>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part); break;
+        }
+        LAUNCHCHK();
+        return TOMO_OK;
+    }
     switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
-    case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
-    default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
+    case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, false>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr); break;
+    case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, false>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr); break;
+    default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, false>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr); break;
     }
     LAUNCHCHK();
     return TOMO_OK;
@@ -788,11 +797,24 @@ int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *ord
     return tomo_sart_data(e, vol, TOMO_SINO_B, beta, niter, order);
 }
 
-int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order)
+// track_vol >= 0: the last back-projection of the sweep also leaves ||x_new - track||^2 in scalar `slot` and copies x_new
+// into track_vol (tomo_sart_tracked)
+static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order, int track_vol, int slot)
 {
     NEED(e);
-    float *x, *r; int rc;
+    float *x, *r, *track = nullptr; int rc;
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, sino_b, &e->cur_b))) return rc;
+    if (track_vol >= 0) {
+        if (track_vol == vol) return fail(TOMO_ERR_ARG, "the tracked volume must differ from the swept one");
+        if (slot < 0 || slot >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
+        if ((rc = get_vol(e, track_vol, &track))) return rc;
+        if ((int64_t)niter * e->np <= 0) {   // nothing is swept: the plain pair of passes
+            if ((rc = tomo_diff_norm_sq(e, vol, track_vol, slot))) return rc;
+            return tomo_copy_volume(e, track_vol, vol);
+        }
+        if ((rc = reduce_begin(e))) return rc;
+    }
+    auto finish = [&]() -> int { return track ? reduce_end(e, slot) : TOMO_OK; };
     if (order) {
         std::vector<char> seen(e->np, 0);
         for (int q = 0; q < e->np; ++q) {
@@ -810,9 +832,9 @@ int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, c
                 ProfScope ps(e, TOMO_K_FP_ANGLE);
                 if ((rc = launch_fp<FP_RESID_NORM>(e, x, i * e->n, e->n, e->cur_b, r))) return rc;
             }
-            if ((rc = launch_bp_angle(e, x, i, r + (size_t)i * e->n * e->sx, beta))) return rc;
+            if ((rc = launch_bp_angle(e, x, i, r + (size_t)i * e->n * e->sx, beta, k == steps - 1 ? track : nullptr))) return rc;
         }
-        return TOMO_OK;
+        return finish();
     }
     // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
     if (steps <= 0) return TOMO_OK;
@@ -828,7 +850,8 @@ int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, c
             if ((rc = launch_sart_tile<true>(e, x, prev, next, r, beta))) return rc;
         }
         int last = angle_at(steps - 1);
-        return launch_bp_angle(e, x, last, r + (size_t)last * e->n * e->sx, beta);
+        if ((rc = launch_bp_angle(e, x, last, r + (size_t)last * e->n * e->sx, beta, track))) return rc;
+        return finish();
     }
     float *alt;
     if ((rc = get_scratch(e, &e->sart_alt, &alt))) return rc;
@@ -845,9 +868,19 @@ int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, c
         std::swap(cur, alt);
     }
     int last = angle_at(steps - 1);
-    if ((rc = launch_bp_angle(e, cur, last, r + (size_t)last * e->n * e->sx, beta))) return rc;
+    if ((rc = launch_bp_angle(e, cur, last, r + (size_t)last * e->n * e->sx, beta, track))) return rc;
     if (cur != x) { e->vol[vol] = cur; e->sart_alt = x; }   // the swept volume now lives in the partner buffer
-    return TOMO_OK;
+    return finish();
+}
+
+int tomo_sart_data(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order)
+{
+    return sart_impl(e, vol, sino_b, beta, niter, order, -1, 0);
+}
+
+int tomo_sart_tracked(tomo_engine *e, int vol, int sino_b, float beta, int niter, const int32_t *order, int track_vol, int slot)
+{
+    return sart_impl(e, vol, sino_b, beta, niter, order, track_vol, slot);
 }
 
 int tomo_art(tomo_engine *e, float beta) { return tomo_art_order(e, beta, nullptr); }
@@ -1296,18 +1329,35 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
 
 int tomo_tv_grad(tomo_engine *e, float eps) { return tv_grad_impl(e, eps, false); }
 
-int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp)
+static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot)
 {
     NEED(e);
-    float *x = e->vol[TOMO_VOL_RECON], *g; int rc;
+    float *x = e->vol[TOMO_VOL_RECON], *g, *track = nullptr; int rc;
     if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
+    if (track_vol >= 0) {
+        if (track_vol == TOMO_VOL_RECON) return fail(TOMO_ERR_ARG, "the tracked volume must differ from the reconstruction");
+        if (slot < 0 || slot >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
+        if ((rc = get_vol(e, track_vol, &track))) return rc;
+        // an evaluation in flight on the second stream may still read the tracked volume (ASD-POCS: the data distance
+        // of the snapshot): order this write behind it on the device; tomo_async_wait later is still valid
+        if (e->async_pending) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        if ((rc = reduce_begin(e))) return rc;
+    }
     int64_t n4 = e->vol_elems() / 4;
     {
         ProfScope ps(e, TOMO_K_TV_UPDATE);
-        hipLaunchKernelGGL(k_tv_update, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4);
+        if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)track, e->d_part);
+        else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr);
     }
     LAUNCHCHK();
-    return TOMO_OK;
+    return track ? reduce_end(e, slot) : TOMO_OK;
+}
+
+int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp) { return tv_update_impl(e, dPOCS, clamp, -1, 0); }
+
+int tomo_tv_update_tracked(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot)
+{
+    return tv_update_impl(e, dPOCS, clamp, track_vol, slot);
 }
 
 int tomo_fgp_begin(tomo_engine *e) { return tomo_fgp_begin_vol(e, TOMO_VOL_RECON); }
@@ -1364,7 +1414,7 @@ int tomo_tv(tomo_engine *e, int vol, float eps)
     return tomo_tv_partial(e, vol, eps);
 }
 
-int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps)
+static int tv_gd_impl(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot)
 {
     int rc;
     // the TV value before descent comes out of the first gradient pass (its denominators are the TV integrand)
@@ -1374,10 +1424,24 @@ int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps)
     for (int g = 0; g < ng; ++g) {
         if (g > 0 && (rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc;
         if ((rc = tv_grad_impl(e, eps, fold_tv && g == 0))) return rc;
-        if ((rc = tomo_tv_update(e, dPOCS, g == ng - 1))) return rc;
+        if ((rc = tv_update_impl(e, dPOCS, g == ng - 1, g == ng - 1 ? track_vol : -1, slot))) return rc;
     }
-    if (ng <= 0) return tomo_positivity(e, TOMO_VOL_RECON);
+    if (ng <= 0) {
+        if ((rc = tomo_positivity(e, TOMO_VOL_RECON))) return rc;
+        if (track_vol >= 0) {
+            if ((rc = tomo_diff_norm_sq(e, TOMO_VOL_RECON, track_vol, slot))) return rc;
+            return tomo_copy_volume(e, track_vol, TOMO_VOL_RECON);
+        }
+    }
     return TOMO_OK;
+}
+
+int tomo_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps) { return tv_gd_impl(e, ng, dPOCS, eps, -1, 0); }
+
+int tomo_tv_gd_tracked(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot)
+{
+    if (track_vol < 0) return fail(TOMO_ERR_ARG, "bad tracked volume");
+    return tv_gd_impl(e, ng, dPOCS, eps, track_vol, slot);
 }
 
 int tomo_tv_fgp(tomo_engine *e, int iters, float lambda) { return tomo_tv_fgp_vol(e, TOMO_VOL_RECON, iters, lambda); }

@@ -307,7 +307,8 @@ class _EngineBase:
         return float(np.sqrt(self._scalar(S_DD)))
 
     def data_distance_begin(self, vol=VOL_TEMP):
-        """Start ||A vol - b|| on the engine's second stream; ``vol`` must not be written until ``data_distance_end``.
+        """Start ||A vol - b|| on the engine's second stream; ``vol`` must not be written until ``data_distance_end``
+        (the tracked TV step, which refreshes TEMP, orders itself behind the evaluation on the device).
         (ASD-POCS: the residual of the SART result, held in the TEMP copy, overlaps the TV descent on recon.)"""
         self.be.c("data_distance_sq_async", vol)
 
@@ -465,6 +466,46 @@ class tomoengine(_EngineBase):
             self.be.c("sart", VOL_RECON, float(beta), int(nIter), _ptr(order))
         else:
             self.be.c("sart", VOL_RECON, float(beta), int(nIter), None)
+
+    def SART_tracked(self, beta=1.0, nIter=1):
+        """``SART(beta, nIter)`` followed by ``matrix_2norm()`` and ``copy_recon()`` (the three calls after which the
+        ASD-POCS loop continues, examples/sim_ASD.py:70-78) with the norm and the snapshot produced by the sweep's last
+        back-projection pass.  The snapshot (TEMP) must equal recon's state before the sweep.  Returns the step norm."""
+        order = None
+        if self.projOrder == "random":
+            order = np.ascontiguousarray(self._order_rng.permutation(self.Nproj), dtype=np.int32)
+            if self.comm is not None and self.comm.world > 1:
+                import torch
+                t = torch.from_numpy(order.astype(np.int64)).to(self.be.halo_tensors()[0].device)
+                self.comm.broadcast(t, 0)
+                order = np.ascontiguousarray(t.cpu().numpy(), dtype=np.int32)
+        self.be.c("sart_tracked", VOL_RECON, SINO_B, float(beta), int(nIter), _ptr(order) if order is not None else None,
+                  VOL_TEMP, S_DIFF)
+        return float(np.sqrt(self._scalar(S_DIFF)))
+
+    def tv_gd_tracked(self, ng, dPOCS):
+        """``tv_gd(ng, dPOCS)`` followed by ``matrix_2norm()`` and ``copy_recon()`` in one call (the last descent step
+        also forms the norm and refreshes the snapshot).  Returns (TV before descent, step norm)."""
+        ng = int(ng)
+        if self.comm is None:
+            self.be.c("tv_gd_tracked", ng, float(dPOCS), self.tv_eps, VOL_TEMP, S_DIFF)
+            return self._scalar(S_TV), float(np.sqrt(self._scalar(S_DIFF)))
+        if ng <= 0:
+            tv0 = self.tv_gd(ng, dPOCS)
+            nrm = self.matrix_2norm()
+            self.copy_recon()
+            return tv0, nrm
+        tv0 = self._tv_of(VOL_RECON, self.tv_eps)
+        for g in range(ng):
+            if g > 0:
+                self._exchange(VOL_RECON)
+            self.be.c("tv_grad", self.tv_eps)
+            self.comm.allreduce_sum(self.be.scalar_tensor(S_GNORM))   # stays on the device
+            if g == ng - 1:
+                self.be.c("tv_update_tracked", float(dPOCS), 1, VOL_TEMP, S_DIFF)
+            else:
+                self.be.c("tv_update", float(dPOCS), 0)
+        return tv0, float(np.sqrt(self._scalar(S_DIFF)))
 
     def poisson_ML(self, lam):
         self.be.c("poisson_ml", float(lam))

@@ -127,21 +127,19 @@ class TomoGPU:
         self.dd_vec, self.tv_vec = np.zeros(Niter), np.zeros(Niter)
         dPOCS = 0.0
         norm = float(t.Nslice_ * t.Nrow) if normalize_dd else 1.0
+        t.copy_recon()
         for i in range(Niter):
-            t.copy_recon()
-            pytvlib.run(t, "sart", beta)
+            # sim_ASD.py:68-78: copy_recon; SART; dp = matrix_2norm; copy_recon -- the step norm and the new snapshot
+            # (TEMP) come out of the sweep's last back-projection pass; TEMP == recon holds on entry
+            dp = t.SART_tracked(beta)
             beta *= beta_reduce
             if i == 0:
-                dPOCS = t.matrix_2norm() * alpha
-                dp = dPOCS / alpha
-            else:
-                dp = t.matrix_2norm()
+                dPOCS = dp * alpha
             # the residual of the SART result is independent of the TV descent: evaluate it on the snapshot (TEMP)
             # on the engine's second stream while the TV steps run
-            t.copy_recon()
             t.data_distance_begin()
-            self.tv_vec[i] = t.tv_gd(nTViter, dPOCS)
-            dg = t.matrix_2norm()
+            # sim_ASD.py:84-88: tv_gd; dg = matrix_2norm (and the copy_recon that opens the next iteration)
+            self.tv_vec[i], dg = t.tv_gd_tracked(nTViter, dPOCS)
             self.dd_vec[i] = t.data_distance_end() / norm
             if dg > dp * r_max and self.dd_vec[i] > eps:
                 dPOCS *= alpha_reduce
