@@ -1164,6 +1164,13 @@ __global__ void k_halo_pack(const float *__restrict__ x, float *__restrict__ dst
     if (i < npix) dst[i] = x[(size_t)i * sx + s];
 }
 
+// periodic wrap of a single slab in one launch: lo = last slice, hi = slice 0
+__global__ void k_halo_wrap(const float *__restrict__ x, float *__restrict__ lo, float *__restrict__ hi, int npix, int sx, int nx)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npix) { lo[i] = x[(size_t)i * sx + nx - 1]; hi[i] = x[(size_t)i * sx]; }
+}
+
 // sum sqrt(eps + (x - x_ip)^2 + (x - x_jp)^2 + (x - x_kp)^2)     (ctvlib.cpp:336-367, tv_gd.cu:27-47)
 __global__ __launch_bounds__(256) void k_tv_value(const float *__restrict__ x, Halo h, double *__restrict__ part,
                                                    float eps, int n, int nx, int sx)
@@ -1254,9 +1261,11 @@ constexpr int TVL_PITCH = 66;      // 64 slices + halo each side
 
 __device__ __forceinline__ float tv_ld(const float *__restrict__ x, const Halo &h, int pix, int s, int nx, int sx)
 {
-    if (s < 0) return h.lo[pix];
-    if (s >= nx) return h.hi[pix];
-    return x[(size_t)pix * sx + s];
+    // one load through a selected address (three guarded loads compile to a branch ladder per element)
+    const float *p = x + (size_t)pix * sx + s;
+    p = (s < 0) ? h.lo + pix : p;
+    p = (s >= nx) ? h.hi + pix : p;
+    return *p;
 }
 
 // WITH_TV: D(p) is exactly the TV integrand (ctvlib.cpp:336-367), so the first gradient pass of a tv_gd call also

@@ -1262,9 +1262,12 @@ int tomo_halo_pack(tomo_engine *e, int field, int last, void *device_dst)
 
 int tomo_halo_local(tomo_engine *e, int field)
 {
-    int rc;
-    if ((rc = tomo_halo_pack(e, field, 1, e->halo_lo))) return rc;   // below slice 0 sits the last slice
-    return tomo_halo_pack(e, field, 0, e->halo_hi);                  // above the last slice sits slice 0
+    NEED(e);
+    float *x; int rc; if ((rc = field_ptr(e, field, &x))) return rc;
+    // below slice 0 sits the last slice, above the last slice sits slice 0
+    hipLaunchKernelGGL(k_halo_wrap, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, x, e->halo_lo, e->halo_hi, (int)e->npix, e->sx, e->nx);
+    LAUNCHCHK();
+    return TOMO_OK;
 }
 
 int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last)
