@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RMW_CEILING_GBS = 5300.0  # measured: tools/micro/copy_patterns.hip (read + write of the slab in place), DESIGN.md section 3
 
 
 def asd_pocs_step(t, st):
@@ -196,7 +197,10 @@ def main():
             ach = alg_bytes[name] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofs[name] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": cnt, "avg_ms": avg_ms,
-                           "total_ms": tot, "algorithmic_bytes_per_launch": alg_bytes[name]}
+                           "total_ms": tot, "algorithmic_bytes_per_launch": alg_bytes[name],
+                           # what an in-place read-modify-write pass over the slab reaches on this part in any access
+                           # pattern (tools/micro/copy_patterns.hip: 5.2-5.5 TB/s) -- informative, not the peak
+                           "frac_of_measured_rmw_ceiling": ach / RMW_CEILING_GBS}
         # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), null if absent
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]

@@ -1374,10 +1374,13 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
 
 // x -= dPOCS * g / ||g||   (ctvlib.cpp:452-458); gnorm2 = global sum g^2 on the device; optional clamp (:461)
 // TRACK: also sum (x_new - track)^2 -> part[] and track = x_new (the step norm and snapshot after the TV descent)
+// wrap_lo / wrap_hi (single slab, periodic in the slice direction): the pass also leaves the new last / first slice
+// in the halo planes the next gradient pass reads, instead of a gather launch between the two.
 template <bool TRACK>
 __global__ __launch_bounds__(256) void k_tv_update(f4 *__restrict__ x, const f4 *__restrict__ g,
                                                     const double *__restrict__ gnorm2, float dPOCS, int clamp,
-                                                    int64_t n4, f4 *__restrict__ track, double *__restrict__ part)
+                                                    int64_t n4, f4 *__restrict__ track, double *__restrict__ part,
+                                                    float *__restrict__ wrap_lo, float *__restrict__ wrap_hi, int nx, int sx4)
 {
     float nrm = (float)sqrt(*gnorm2);
     double acc = 0.0;
@@ -1385,6 +1388,13 @@ __global__ __launch_bounds__(256) void k_tv_update(f4 *__restrict__ x, const f4 
         f4 v = x[i] - (dPOCS * g[i]) / nrm;
         if (clamp) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         x[i] = v;
+        if (wrap_lo) {
+            int64_t pix = i / sx4;
+            int s = (int)(i - pix * sx4) * 4;
+            if (s == 0) wrap_hi[pix] = v.x;
+            int d = nx - 1 - s;
+            if (d >= 0 && d < 4) wrap_lo[pix] = d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w;
+        }
         if (TRACK) {
             f4 d = v - track[i];
             acc += (double)(d.x * d.x) + (double)(d.y * d.y) + (double)(d.z * d.z) + (double)(d.w * d.w);

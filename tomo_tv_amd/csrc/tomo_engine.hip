@@ -1332,7 +1332,7 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
 
 int tomo_tv_grad(tomo_engine *e, float eps) { return tv_grad_impl(e, eps, false); }
 
-static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot)
+static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot, bool wrap = false)
 {
     NEED(e);
     float *x = e->vol[TOMO_VOL_RECON], *g, *track = nullptr; int rc;
@@ -1349,8 +1349,9 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
     int64_t n4 = e->vol_elems() / 4;
     {
         ProfScope ps(e, TOMO_K_TV_UPDATE);
-        if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)track, e->d_part);
-        else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr);
+        float *wl = wrap ? e->halo_lo : nullptr, *wh = wrap ? e->halo_hi : nullptr;
+        if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)track, e->d_part, wl, wh, e->nx, e->sx / 4);
+        else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr, wl, wh, e->nx, e->sx / 4);
     }
     LAUNCHCHK();
     return track ? reduce_end(e, slot) : TOMO_OK;
@@ -1425,9 +1426,9 @@ static int tv_gd_impl(tomo_engine *e, int ng, float dPOCS, float eps, int track_
     if (fold_tv) { if ((rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc; }
     else if ((rc = tomo_tv(e, TOMO_VOL_RECON, eps))) return rc;
     for (int g = 0; g < ng; ++g) {
-        if (g > 0 && (rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc;
+        // single slab: every descent step but the last also writes the wrapped halo planes of its result
         if ((rc = tv_grad_impl(e, eps, fold_tv && g == 0))) return rc;
-        if ((rc = tv_update_impl(e, dPOCS, g == ng - 1, g == ng - 1 ? track_vol : -1, slot))) return rc;
+        if ((rc = tv_update_impl(e, dPOCS, g == ng - 1, g == ng - 1 ? track_vol : -1, slot, g < ng - 1))) return rc;
     }
     if (ng <= 0) {
         if ((rc = tomo_positivity(e, TOMO_VOL_RECON))) return rc;
