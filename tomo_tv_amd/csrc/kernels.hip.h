@@ -1270,7 +1270,8 @@ __device__ __forceinline__ float tv_ld(const float *__restrict__ x, const Halo &
 
 // WITH_TV: D(p) is exactly the TV integrand (ctvlib.cpp:336-367), so the first gradient pass of a tv_gd call also
 // returns the TV value "before descent" (tv_gd.cu:177-183) without a separate pass over the volume.
-template <int TZ, bool WITH_TV>
+// GRAD = false: the TV value alone (the march with its single read of x, without the gradient stencil and the g store).
+template <int TZ, bool WITH_TV, bool GRAD = true>
 __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x, Halo h, float *__restrict__ g,
                                                       double *__restrict__ part, float eps, int n, int nx, int sx,
                                                       int yseg, double *__restrict__ part_tv)
@@ -1348,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
         compute_r(m1, m2, rc, true);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < TZ / 4; ++q) {
+        for (int q = 0; GRAD && q < TZ / 4; ++q) {
             int zi = 1 + wave * (TZ / 4) + q;
             int z = z0 + zi - 1;
             if (z < n && s < nx) {
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
         if (more) stash(m3);                   // plane y+2 into the free slot
         __syncthreads();
     }
-    block_accumulate(acc, part);
+    if (GRAD) block_accumulate(acc, part);
     if (WITH_TV) {
         __syncthreads();
         block_accumulate(tvacc, part_tv);

@@ -1415,7 +1415,20 @@ int tomo_tv(tomo_engine *e, int vol, float eps)
 {
     int rc;
     if ((rc = tomo_halo_local(e, vol))) return rc;
-    return tomo_tv_partial(e, vol, eps);
+    if (e->tv_lds != 8) return tomo_tv_partial(e, vol, eps);
+    // the LDS march without its gradient half: x is read once (the direct-global k_tv_value reads it twice)
+    float *x;
+    if ((rc = get_vol(e, vol, &x))) return rc;
+    if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
+    HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
+    Halo h{e->halo_lo, e->halo_hi};
+    const int yseg = 32;
+    dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+    hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part_tv, e->d_scal + TOMO_S_TV);
+    LAUNCHCHK();
+    return TOMO_OK;
 }
 
 static int tv_gd_impl(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot)
