@@ -1474,8 +1474,9 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
                                                     const float *__restrict__ P2i, const float *__restrict__ P3i,
                                                     float *__restrict__ P1o, float *__restrict__ P2o,
                                                     float *__restrict__ P3o, float lambda, float multip, int n, int nx,
-                                                    int sx, int yseg)
+                                                    int sx, int yseg, int zero_p)
 {
+    // zero_p: first iteration of a call, P = 0 is known and neither zero-filled beforehand nor read here
     __shared__ float pl[3][2][TVL_TZ + 2][TVL_PITCH];     // P1,P2,P3 planes (parity ring); row zi = column z0-1+zi
     __shared__ float al[TVL_TZ + 2][TVL_PITCH];           // A plane being turned into D
     __shared__ float dl[2][TVL_TZ + 1][TVL_PITCH];        // D planes: row zi' = column z0+zi', element si' = slice s0+si'
@@ -1497,14 +1498,16 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
         for (int t = 0; t < 3; ++t) {
             int r = wave + 4 * t;
             bool ok = r < TVL_TZ + 2;
-            rg[0][t] = ok ? ld(P1i, y, r, lane + 1) : 0.f;
-            rg[1][t] = ok ? ld(P2i, y, r, lane + 1) : 0.f;
-            rg[2][t] = ok ? ld(P3i, y, r, lane + 1) : 0.f;
+            const bool okp = ok && !zero_p;
+            rg[0][t] = okp ? ld(P1i, y, r, lane + 1) : 0.f;
+            rg[1][t] = okp ? ld(P2i, y, r, lane + 1) : 0.f;
+            rg[2][t] = okp ? ld(P3i, y, r, lane + 1) : 0.f;
             rg[3][t] = ok ? ld(A, y, r, lane + 1) : 0.f;
         }
         if (wave == 3 && lane < 2 * (TVL_TZ + 2)) {
             int r = lane >> 1, si = (lane & 1) ? 65 : 0;
-            rh[0] = ld(P1i, y, r, si); rh[1] = ld(P2i, y, r, si); rh[2] = ld(P3i, y, r, si); rh[3] = ld(A, y, r, si);
+            rh[0] = zero_p ? 0.f : ld(P1i, y, r, si); rh[1] = zero_p ? 0.f : ld(P2i, y, r, si);
+            rh[2] = zero_p ? 0.f : ld(P3i, y, r, si); rh[3] = ld(A, y, r, si);
         }
     };
     auto stash = [&](int par) {

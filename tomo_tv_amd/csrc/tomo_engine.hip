@@ -1366,7 +1366,7 @@ int tomo_tv_update_tracked(tomo_engine *e, float dPOCS, int clamp, int track_vol
 
 int tomo_fgp_begin(tomo_engine *e) { return tomo_fgp_begin_vol(e, TOMO_VOL_RECON); }
 
-int tomo_fgp_begin_vol(tomo_engine *e, int vol)
+static int fgp_begin_impl(tomo_engine *e, int vol, bool zero_p)
 {
     NEED(e);
     float *d, *p; int rc;
@@ -1376,10 +1376,12 @@ int tomo_fgp_begin_vol(tomo_engine *e, int vol)
     HIPCHK(hipMemsetAsync(d, 0, e->vol_elems() * sizeof(float), e->stream));
     for (int i = 0; i < 3; ++i) {
         if ((rc = get_scratch(e, &e->fgp_p[i], &p))) return rc;
-        HIPCHK(hipMemsetAsync(p, 0, e->vol_elems() * sizeof(float), e->stream));
+        if (zero_p) HIPCHK(hipMemsetAsync(p, 0, e->vol_elems() * sizeof(float), e->stream));
     }
     return TOMO_OK;
 }
+
+int tomo_fgp_begin_vol(tomo_engine *e, int vol) { return fgp_begin_impl(e, vol, true); }
 
 int tomo_fgp_obj(tomo_engine *e, float lambda)
 {
@@ -1467,10 +1469,11 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
 {
     int rc;
     if ((rc = tomo_tv(e, vol, 1e-6f))) return rc;    // tv_fgp.cu:170-189,231-238
-    if ((rc = tomo_fgp_begin_vol(e, vol))) return rc;
+    const bool fused = e && e->fgp_fused && iters > 1;
+    if ((rc = fgp_begin_impl(e, vol, !fused))) return rc;    // the fused form's first iteration takes P = 0 as known
     int f = e->is_first, l = e->is_last;
     e->is_first = e->is_last = 1;
-    if (e->fgp_fused && iters > 1) {
+    if (fused) {
         // iterations 0..iters-2: one fused kernel each (D stays on chip); the last iteration only needs D (tv_fgp.cu:272)
         float *q;
         for (int i = 0; i < 3 && !rc; ++i) rc = get_scratch(e, &e->fgp_q[i], &q);
@@ -1482,7 +1485,7 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
             {
                 ProfScope ps(e, TOMO_K_FGP_GRAD);
                 hipLaunchKernelGGL(k_fgp_fused, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
-                                   e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg);
+                                   e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, i == 0 ? 1 : 0);
             }
             if (hipGetLastError() != hipSuccess) rc = fail(TOMO_ERR_HIP, "k_fgp_fused launch failed");
             for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
