@@ -1407,7 +1407,8 @@ __global__ __launch_bounds__(256) void k_tv_update(f4 *__restrict__ x, const f4 
 
 // FGP-TV (tv_fgp.cu).  Non-periodic: i-1 below the first GLOBAL slice and i+1 above the last are "0" terms.
 // D = max(0, A - lambda (P1 + P2 + P3 - P1[i-1] - P2[j-1] - P3[k-1]))        (:44-65, :143-154)
-__global__ __launch_bounds__(256) void k_fgp_obj(const float *__restrict__ A, float *__restrict__ D,
+// D may be A itself (the fused single-slab form finishes in place: each voxel reads only its own A)
+__global__ __launch_bounds__(256) void k_fgp_obj(const float *A, float *D,
                                                   const float *__restrict__ P1, const float *__restrict__ P2,
                                                   const float *__restrict__ P3, const float *__restrict__ p1_lo,
                                                   int first, float lambda, int n, int nx, int sx)

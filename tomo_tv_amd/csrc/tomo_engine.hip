@@ -1372,8 +1372,10 @@ static int fgp_begin_impl(tomo_engine *e, int vol, bool zero_p)
     float *d, *p; int rc;
     if ((rc = get_vol(e, vol, &d))) return rc;
     e->fgp_target = vol;
-    if ((rc = get_scratch(e, &e->tvg, &d))) return rc;
-    HIPCHK(hipMemsetAsync(d, 0, e->vol_elems() * sizeof(float), e->stream));
+    if (zero_p) {   // step form: D and P start as zero fields (tv_fgp.cu:216-227); the fused form needs neither
+        if ((rc = get_scratch(e, &e->tvg, &d))) return rc;
+        HIPCHK(hipMemsetAsync(d, 0, e->vol_elems() * sizeof(float), e->stream));
+    }
     for (int i = 0; i < 3; ++i) {
         if ((rc = get_scratch(e, &e->fgp_p[i], &p))) return rc;
         if (zero_p) HIPCHK(hipMemsetAsync(p, 0, e->vol_elems() * sizeof(float), e->stream));
@@ -1490,7 +1492,14 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
             if (hipGetLastError() != hipSuccess) rc = fail(TOMO_ERR_HIP, "k_fgp_fused launch failed");
             for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
         }
-        if (!rc) rc = tomo_fgp_obj(e, lambda);
+        if (!rc) {   // the last iteration only needs D (tv_fgp.cu:272), written straight over the target volume
+            ProfScope ps(e, TOMO_K_FGP_OBJ);
+            float *a = e->vol[e->fgp_target];
+            hipLaunchKernelGGL(k_fgp_obj, dim3(tv_grid(e)), dim3(256), 0, e->stream, a, a, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->halo_lo, e->is_first, lambda, e->n, e->nx, e->sx);
+            if (hipGetLastError() != hipSuccess) rc = fail(TOMO_ERR_HIP, "k_fgp_obj launch failed");
+        }
+        e->is_first = f; e->is_last = l;
+        return rc;
     } else {
         for (int i = 0; i < iters; ++i) {
             if ((rc = tomo_fgp_obj(e, lambda)) || (rc = tomo_fgp_grad(e, lambda))) break;
