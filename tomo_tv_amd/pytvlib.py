@@ -1,9 +1,10 @@
 """String -> method dispatch, mirroring tomofusion/pytvlib.py:5-39 (GPU engines) and
-tomofusion/cpu/utils/pytvlib.py:171-213 (ctvlib harness helpers).  File IO helpers of the reference
-(HDF5/TIFF, pytvlib.py:57-162) are out of this build's scope."""
+tomofusion/cpu/utils/pytvlib.py:171-213 (ctvlib harness helpers).  The file helpers of the reference
+(pytvlib.py:57-162) live in ``tomo_tv_amd/io.py`` and are re-exported here under the same names."""
 import numpy as np
 
 from .engine import system_matrix
+from .io import load_data, load_h5_data, mpi_save_results, save_gif, save_recon, save_results  # noqa: F401
 
 
 def initialize_algorithm(tomo, alg, initAlg=""):
