@@ -840,7 +840,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
     FB_STAGE_STORE(0)
     __syncthreads();
     const uint4 *cp = tcell + (size_t)tile * nproj * FT_PIX + g * 8 + (gl & 7);
-    uint4 e0 = cp[0], e1 = cp[FT_PIX], e2 = cp[2 * FT_PIX], e3 = cp[3 * FT_PIX];   // table padded by FB_A angles
+    uint4 e0 = cp[0], e1 = cp[FT_PIX], e2 = cp[2 * FT_PIX], e3 = cp[3 * FT_PIX];   // table padded by 2*FB_A angles:
+    // the in-place reloads of the last stage reach angle 4*nstage + 3 <= P + 2*FB_A - 2
     V acc[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J) acc[J] = vzero<4>();

@@ -454,7 +454,11 @@ void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Ta
         t.tile_slot_seg0[q] = segid;
         segid += nseg_of[q];
     }
-    const size_t nent = ((size_t)t.tile_slot_ptr.back() + 16) * NB;   // + 16 batches: the kernel prefetches past a stream's end
+    // The kernel's ring prefetches up to 15 batches past the point where the LONGEST stream of a wave ends, counted from
+    // each lane group's own stream start: pad by the longest stream + 16 batches so the last streams stay in bounds.
+    uint32_t longest = 0;
+    for (size_t q = 0; q < (size_t)ntiles * NS; ++q) longest = std::max(longest, nbatch_of[q]);
+    const size_t nent = ((size_t)t.tile_slot_ptr.back() + longest + 16) * NB;
     t.tile_off.assign(nent, 0u);
     t.tile_w.assign(nent, 0.f);
     auto emit_work = [&](int th) {

@@ -484,7 +484,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             HIPCHK(hipMemcpy(e->d_st_row_nseg, t.st_row_nseg.data(), t.st_row_nseg.size() * 4, hipMemcpyHostToDevice));
         }
         { decltype(t.st_cell)().swap(t.st_cell); decltype(t.st_off)().swap(t.st_off); decltype(t.st_w)().swap(t.st_w); }
-        build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, FB_A, t);
+        build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, 2 * FB_A, t);   // the cell ring prefetches up to angle P + 2*FB_A - 2
         static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
         e->fb_ok = t.bp_tile_ok && e->np <= FB_MAX_PROJ;
         if (e->fb_ok) {
