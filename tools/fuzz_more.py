@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Open-ended random-shape parity sweep on the GPU (a superset of tests/test_gpu_fuzz.py): fuzz_more.py SEED CASES.
+Every kernel family against the oracle at random (N, P, Nx, angles); prints the stage reached before each call so a
+device fault names its case."""
 import sys, os, numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from tomo_tv_amd._lib import VOL_ORIGINAL
 from tomo_tv_amd.engine import tomoengine
