@@ -192,7 +192,7 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     form (k_sart_seg); equal at 512 slices per GPU, 14-18 % faster on slabs of <= 128 slices
  *   "fp_tile" (1):    all-angle forward projection from LDS-resident image tiles (k_fp_tile + k_fp_tile_reduce);
  *                     0 = ray-driven form selected by "fp_all_lpr"
- *   "fp_tile_scratch_mib" (4096): cap of the tile projector's partial-sum scratch; a larger volume is projected in
+ *   "fp_tile_scratch_mib" (8192): cap of the tile projector's partial-sum scratch; a larger volume is projected in
  *                     several passes over groups of 64-slice chunks (set before the first projection)
  *   "bp_tile" (1):    all-angle back-projection from LDS-staged residual-row windows (k_bp_tile; bit-identical to the
  *                     pixel-driven k_bp_all it replaces; used when every tile's ray window fits, else k_bp_all)

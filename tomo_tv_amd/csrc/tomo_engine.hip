@@ -79,7 +79,7 @@ struct tomo_engine {
     uint4 *d_fb_cell = nullptr;
     uint32_t *d_fb_win = nullptr;
     int ft_ncp = 0;                               // slice chunks per pass (bounds the scratch)
-    size_t ft_scratch_cap = (size_t)4 << 30;
+    size_t ft_scratch_cap = (size_t)8 << 30;      // >= 4 chunks per pass up to 1024^2 x 120 (one pass measured 12 % faster than one chunk per pass)
     // fields
     float *vol[TOMO_VOL_SLOTS] = {};
     float *sino[TOMO_SINO_SLOTS] = {};
