@@ -194,6 +194,7 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     0 = ray-driven form selected by "fp_all_lpr"
  *   "fp_tile_scratch_mib" (8192): cap of the tile projector's partial-sum scratch; a larger volume is projected in
  *                     several passes over groups of 64-slice chunks (set before the first projection)
+ *   "fp_tile_chunks_per_pass" (0): that number of 64-slice chunks per pass instead (0 = derived from the cap)
  *   "bp_tile" (1):    all-angle back-projection from LDS-staged residual-row windows (k_bp_tile; bit-identical to the
  *                     pixel-driven k_bp_all it replaces; used when every tile's ray window fits, else k_bp_all)
  *   "fp_all_lpr" (16): ray-driven all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks

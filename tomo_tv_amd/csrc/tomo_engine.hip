@@ -78,7 +78,7 @@ struct tomo_engine {
     bool fb_ok = false;
     uint4 *d_fb_cell = nullptr;
     uint32_t *d_fb_win = nullptr;
-    int ft_ncp = 0;                               // slice chunks per pass (bounds the scratch)
+    int ft_ncp = 0, ft_ncp_forced = 0;            // slice chunks per pass (bounds the scratch); forced value for tests
     size_t ft_scratch_cap = (size_t)8 << 30;      // >= 4 chunks per pass up to 1024^2 x 120 (one pass measured 12 % faster than one chunk per pass)
     // fields
     float *vol[TOMO_VOL_SLOTS] = {};
@@ -228,7 +228,8 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
     if (!e->ft_ncp) {
         size_t per_chunk = (size_t)std::max<uint32_t>(1, e->ft_nseg) * 64 * sizeof(float);
         int ncp = (int)std::min<size_t>(nchunk, std::max<size_t>(1, e->ft_scratch_cap / per_chunk));
-        if (ncp >= 4) ncp &= ~3; else if (ncp >= 2) ncp &= ~1;
+        if (e->ft_ncp_forced > 0) ncp = std::min(nchunk, e->ft_ncp_forced);
+        else if (ncp >= 4) ncp &= ~3; else if (ncp >= 2) ncp &= ~1;
         e->ft_ncp = ncp;
         if (!e->attr_fp) {   // per engine: the attribute belongs to the (function, device) pair
             HIPCHK(hipFuncSetAttribute((const void *)k_fp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FT_LDS_BYTES));
@@ -1519,6 +1520,10 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_tile") == 0) { e->sart_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_tile_chunks_per_pass") == 0) {   // any count >= 1 (0 = from the scratch cap); before the first projection
+        if (value < 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_chunks_per_pass must be set before the first projection");
+        e->ft_ncp_forced = value; e->ft_ncp = 0; return TOMO_OK;
+    }
     if (std::strcmp(name, "fp_tile_scratch_mib") == 0) {   // cap of the partial-sum scratch; takes effect before the first all-angle FP
         if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
         e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; return TOMO_OK;
