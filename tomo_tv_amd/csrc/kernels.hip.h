@@ -729,10 +729,22 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     const int off = c * 64 + gl * 4;
     // the group's 8 pixels: row g/2 of the tile, columns (g&1)*8 .. +7
     const int y = ty * ST_T + (g >> 1), z0 = tz * ST_T + (g & 1) * 8;
+    // the group's ray segment of "next" and all its entry batches (<= 4: a ray crosses <= 31 pixels of a 16x16 tile) are
+    // fetched first, so the forward-projection phase at the end touches LDS only (its two dependent loads cost 10 us
+    // per launch when issued there)
+    const uint2 sd = segs[(size_t)tile * ST_MAXSEG + g];
+    const uint32_t pid = segid[(size_t)tile * ST_MAXSEG + g];
     V xv[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
         xv[J] = (y < n && z0 + J < n) ? *reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off) : vzero<4>();
+    constexpr int ST_MAXB = 4;
+    uint2 eb[ST_MAXB];
+    {
+        const uint2 *ep = ent + (size_t)sd.x * FT_BATCH + (gl & 7);
+#pragma unroll
+        for (int b = 0; b < ST_MAXB; ++b) eb[b] = ((uint32_t)b < sd.y) ? ep[(size_t)b * FT_BATCH] : make_uint2((uint32_t)ST_PIX * 256u, 0u);
+    }
     if (FUSED) {
         uint32_t w = wins[tile];
         if (t < (ST_MAXR + 1) * 16) {
@@ -764,21 +776,33 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     for (int J = 0; J < 8; ++J) img[(g * 8 + J) * 16 + gl] = xv[J];
     __syncthreads();
     // forward projection of "next": group g owns the tile's g-th ray segment
-    uint2 sd = segs[(size_t)tile * ST_MAXSEG + g];
-    uint32_t pid = segid[(size_t)tile * ST_MAXSEG + g];
     if (sd.y == 0) return;                                // uniform inside a 16-lane DPP row
     const char *ib = reinterpret_cast<const char *>(img) + gl * 16;
-    const uint2 *ep = ent + (size_t)sd.x * FT_BATCH + (gl & 7);
     V acc = vzero<4>();
-    for (uint32_t b = 0; b < sd.y; ++b) {
-        uint2 e = ep[(size_t)b * FT_BATCH];
-        V q[FT_BATCH];
 #define ST_LOAD(J) q[J] = *reinterpret_cast<const V *>(ib + row_ror<J>(e.x));
-        ST_LOAD(0) ST_LOAD(1) ST_LOAD(2) ST_LOAD(3) ST_LOAD(4) ST_LOAD(5) ST_LOAD(6) ST_LOAD(7)
-#undef ST_LOAD
 #define ST_FMA(J) acc += __uint_as_float(row_ror<J>(e.y)) * q[J];
-        ST_FMA(0) ST_FMA(1) ST_FMA(2) ST_FMA(3) ST_FMA(4) ST_FMA(5) ST_FMA(6) ST_FMA(7)
+#pragma unroll
+    for (int b = 0; b < ST_MAXB; ++b) {
+        if ((uint32_t)b < sd.y) {
+            uint2 e = eb[b];
+            V q[FT_BATCH];
+            ST_LOAD(0) ST_LOAD(1) ST_LOAD(2) ST_LOAD(3) ST_LOAD(4) ST_LOAD(5) ST_LOAD(6) ST_LOAD(7)
+            ST_FMA(0) ST_FMA(1) ST_FMA(2) ST_FMA(3) ST_FMA(4) ST_FMA(5) ST_FMA(6) ST_FMA(7)
+        }
+    }
 #undef ST_FMA
+#undef ST_LOAD
+    if (sd.y > ST_MAXB) {                                 // longer segments (only a user matrix can have them)
+        const uint2 *ep = ent + (size_t)sd.x * FT_BATCH + (gl & 7);
+        for (uint32_t b = ST_MAXB; b < sd.y; ++b) {
+            uint2 e = ep[(size_t)b * FT_BATCH];
+#pragma unroll
+            for (int J = 0; J < 8; ++J) {
+                // generic lane exchange (__shfl) instead of the compile-time DPP rotation: rare path
+                uint32_t ox = (uint32_t)__shfl((int)e.x, (gl + J) & 7, 16), wy = (uint32_t)__shfl((int)e.y, (gl + J) & 7, 16);
+                acc += __uint_as_float(wy) * *reinterpret_cast<const V *>(ib + ox);
+            }
+        }
     }
     *reinterpret_cast<V *>(partial + (size_t)pid * sx + off) = acc;
 }
@@ -1286,8 +1310,9 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
     int y0 = blockIdx.y * yseg;
     int y1 = min(y0 + yseg, n);
     int z0 = bz * TZ, s0 = bs * 64;
-    auto zcol = [&](int zi) { int z = z0 - 1 + zi; return z < 0 ? z + n : (z >= n ? z - n : z); };
-    auto yrow = [&](int y) { return y < 0 ? y + n : (y >= n ? y - n : y); };
+    // full modulo: with n < TZ + 2 the halo columns (and with n = 1 the prefetched rows) wrap more than once
+    auto zcol = [&](int zi) { int z = (z0 - 1 + zi) % n; return z < 0 ? z + n : z; };
+    auto yrow = [&](int y) { int r = y % n; return r < 0 ? r + n : r; };
     constexpr int NR = (TZ + 2 + 3) / 4;       // plane rows per wave
     float v[NR], vh;
     auto fetch = [&](int y) {                  // rows (wave, wave+4, ...) x column lane+1, + halo columns
