@@ -186,7 +186,9 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
 /* Engine options (A/B switches for measurement; defaults are the fast paths):
  *   "sart_fused" (1): run a SART sweep as FP(a0), [BP(a_k)+FP(a_k+1)] fused steps, BP(a_last) instead of separate
  *                     FP/BP launches per angle (same arithmetic per voxel; 8 instead of 12 bytes per voxel-angle)
- *   "tv_lds" (8):     TV gradient as LDS march with that many z-columns per workgroup (0 = direct-global stencil)
+ *   "tv_lds" (1):     TV gradient kernel: 1 = register march (one wave = 8 z-columns x 64 slices, rows in registers,
+ *                     slice neighbours by DPP; bit-identical to the LDS march and 13 % faster), 8 / 16 = LDS march with that
+ *                     many z-columns per workgroup, 0 = direct-global stencil
  *   "fgp_fused" (1):  one fused kernel per FGP iteration (single slab)
  *   "sart_tile" (1):  fused SART steps on image tiles streamed through LDS (k_sart_tile, in place) instead of the ray-walk
  *                     form (k_sart_seg); equal at 512 slices per GPU, 14-18 % faster on slabs of <= 128 slices

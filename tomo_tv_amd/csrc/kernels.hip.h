@@ -1399,6 +1399,126 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
     }
 }
 
+// ---- TV gradient, register march: no LDS, no barriers -----------------------------------------------------------
+// What-if timing of k_tv_grad_lds shows half of its time in its own skeleton (LDS stash, two barriers per
+// row, 15 LDS operations per output).  Here ONE WAVE owns TZ z-columns x 64 slices and marches along y with the rows
+// y-1, y, y+1 of its TZ+2 columns in registers: z neighbours are other registers of the same lane, y neighbours are the
+// rolling rows, slice neighbours come by DPP wave_shr / wave_shl.  The two values beyond a chunk's edges (slices s0-1
+// and s0+64) are loaded into lanes 0 and 63 of a per-column edge register, which is exactly the DPP `old` operand the
+// shifts leave in those lanes; R of the phantom slice s0-1 (needed by lane 0's R(p-i)) is the same formula evaluated on
+// the edge registers.  Same arithmetic, operand order and rounding sequence as k_tv_grad_lds.
+template <int TZ, bool WITH_TV>
+__global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x, Halo h, float *__restrict__ g,
+                                                      double *__restrict__ part, float eps, int n, int nx, int sx,
+                                                      int yseg, double *__restrict__ part_tv)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
+    double acc = 0.0, tvacc = 0.0;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;            // (y segment, z block, chunk), chunk fastest
+    if (item < (int64_t)nzb * nchunk * nys) {
+        const int bs = (int)(item % nchunk), bz = (int)((item / nchunk) % nzb), ys = (int)(item / ((int64_t)nchunk * nzb));
+        const int y0 = ys * yseg, y1 = min(y0 + yseg, n);
+        const int z0 = bz * TZ, s0 = bs * 64, s = s0 + lane;
+        // edge register: lane 0 <- slice s0-1, lane 63 <- slice s0+64; the other lanes re-read their own slice (same
+        // cache lines as the column load: an unconditional load costs less than a two-lane branch per column)
+        const int se = lane == 0 ? s0 - 1 : (lane == 63 ? s0 + 64 : s);
+        int zc[TZ + 2];
+#pragma unroll
+        for (int j = 0; j < TZ + 2; ++j) { int z = (z0 - 1 + j) % n; zc[j] = z < 0 ? z + n : z; }
+        auto yrow = [&](int y) { int r = y % n; return r < 0 ? r + n : r; };
+        float cm[TZ + 2], c0[TZ + 2], cp[TZ + 2], cn[TZ + 2], E0[TZ + 2], Ep[TZ + 2], En[TZ + 2], Rm[TZ + 1], R0[TZ + 1];
+        // a chunk strictly inside the slab needs no halo planes: wave-uniform row pointers + a lane offset
+        const bool interior = s0 > 0 && s0 + 64 < nx;
+        auto fetch = [&](int y, float *c, float *E) {
+            int yy = yrow(y) * n;
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < TZ + 2; ++j) {
+                    const float *rp = x + (size_t)(yy + zc[j]) * sx;
+                    c[j] = rp[s];
+                    E[j] = rp[se];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TZ + 2; ++j) {
+                    c[j] = tv_ld(x, h, yy + zc[j], s, nx, sx);
+                    E[j] = tv_ld(x, h, yy + zc[j], se, nx, sx);
+                }
+            }
+        };
+        // R = 1/sqrt(q), q = eps + d1^2 + d2^2 + d3^2: the rounding sequence of k_tv_grad_lds::compute_r
+#define TVR_RINV(C, IP, JP, KP, RR, DD)                                                                   \
+        {                                                                                                 \
+            float d1_ = (C) - (IP), d2_ = (C) - (JP), d3_ = (C) - (KP);                                   \
+            float q_ = __fmaf_rn(d3_, d3_, __fmaf_rn(d2_, d2_, __fmaf_rn(d1_, d1_, eps)));                \
+            float y_ = __frsqrt_rn(q_);                                                                   \
+            float e_ = __fmaf_rn(-__fmul_rn(q_, y_), __fmul_rn(0.5f, y_), 0.5f);                          \
+            RR = __fmaf_rn(y_, e_, y_);                                                                   \
+            DD = __fmul_rn(q_, RR);                                                                       \
+        }
+        auto shr = [&](float old, float v) {                    // lane l <- lane l-1 ; lane 0 keeps `old`
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+        };
+        auto shl = [&](float old, float v) {                    // lane l <- lane l+1 ; lane 63 keeps `old`
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+        };
+        fetch(y0 - 1, cm, En);
+        fetch(y0, c0, E0);
+        fetch(y0 + 1, cp, Ep);
+        // R of row y0-1 for the output columns (its +y neighbour is row y0)
+#pragma unroll
+        for (int j = 1; j <= TZ; ++j) {
+            float xip = shl(En[j], cm[j]), dd;
+            TVR_RINV(cm[j], xip, c0[j], cm[j + 1], Rm[j], dd)
+            (void)dd;
+        }
+        for (int y = y0; y < y1; ++y) {
+            if (y + 1 < y1) fetch(y + 2, cn, En);               // in flight while this row is computed
+            float xip[TZ + 1];
+#pragma unroll
+            for (int j = 0; j <= TZ; ++j) {
+                float dd;
+                xip[j] = shl(E0[j], c0[j]);
+                TVR_RINV(c0[j], xip[j], cp[j], c0[j + 1], R0[j], dd)
+                if (WITH_TV && j >= 1 && z0 + j - 1 < n && s < nx) tvacc += (double)dd;
+            }
+#pragma unroll
+            for (int j = 1; j <= TZ; ++j) {
+                // R at the phantom slice s0-1 (lane 0 of the edge registers), then R(p-i) by the shift
+                float re, dd;
+                TVR_RINV(E0[j], c0[j], Ep[j], E0[j + 1], re, dd)
+                (void)dd;
+                float rim = shr(re, R0[j]);
+                float xim = shr(E0[j], c0[j]);
+                float c = c0[j];
+                float v1n = 3.0f * c - xip[j] - cp[j] - c0[j + 1];
+                float gv = v1n * R0[j];
+                gv += (c - xim) * rim;
+                gv += (c - cm[j]) * Rm[j];
+                gv += (c - c0[j - 1]) * R0[j - 1];
+                int z = z0 + j - 1;
+                if (z < n && s < nx) {
+                    g[(size_t)(y * n + z) * sx + s] = gv;
+                    acc += (double)(gv * gv);
+                }
+            }
+            // rotate the rows by register moves (rotating them by name, a 4x unrolled loop, costs a wave of occupancy:
+            // 141 VGPRs, 10 % slower)
+#pragma unroll
+            for (int j = 0; j < TZ + 2; ++j) { cm[j] = c0[j]; c0[j] = cp[j]; cp[j] = cn[j]; E0[j] = Ep[j]; Ep[j] = En[j]; }
+#pragma unroll
+            for (int j = 1; j <= TZ; ++j) Rm[j] = R0[j];
+        }
+#undef TVR_RINV
+    }
+    block_accumulate(acc, part);
+    if (WITH_TV) {
+        __syncthreads();
+        block_accumulate(tvacc, part_tv);
+    }
+}
+
 // x -= dPOCS * g / ||g||   (ctvlib.cpp:452-458); gnorm2 = global sum g^2 on the device; optional clamp (:461)
 // TRACK: also sum (x_new - track)^2 -> part[] and track = x_new (the step norm and snapshot after the TV descent)
 // wrap_lo / wrap_hi (single slab, periodic in the slice direction): the pass also leaves the new last / first slice

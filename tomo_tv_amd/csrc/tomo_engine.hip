@@ -51,7 +51,7 @@ struct tomo_engine {
     uint2 *d_went = nullptr;
     float lipschitz = 0.f;
     int sart_fused = 1;                      // 1: SART sweep as a chain of fused BP+FP steps; 0: separate FP and BP per angle
-    int tv_lds = 8, fp_all_lpr = 16;
+    int tv_lds = 1, fp_all_lpr = 16;
     // fp_all_lpr: all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
     SegItemD *d_seg_exec = nullptr;
     std::vector<uint32_t> h_seg_exec_ptr;
@@ -1302,14 +1302,20 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
     if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     Halo h{e->halo_lo, e->halo_hi};
-    if (with_tv && e->tv_lds != 8) with_tv = false;
+    if (with_tv && e->tv_lds != 8 && e->tv_lds != 1) with_tv = false;
     if (with_tv) {
         if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
         HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
     }
     {
         ProfScope ps(e, TOMO_K_TV_GRAD);
-        if (e->tv_lds) {
+        if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
+            int yseg = 32;   // 8 .. 64 rows per wave measured the same; longer segments leave too few waves
+            int64_t items = (int64_t)((e->n + 7) / 8) * (e->sxc / 64) * ((e->n + yseg - 1) / yseg);
+            dim3 grid((unsigned)((items + 3) / 4));
+            if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+            else hipLaunchKernelGGL((k_tv_grad_reg<8, false>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr);
+        } else if (e->tv_lds) {
             int yseg = 32;
             if (e->tv_lds == 16) {
                 dim3 grid((unsigned)(((e->n + 15) / 16) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
@@ -1420,7 +1426,7 @@ int tomo_tv(tomo_engine *e, int vol, float eps)
 {
     int rc;
     if ((rc = tomo_halo_local(e, vol))) return rc;
-    if (e->tv_lds != 8) return tomo_tv_partial(e, vol, eps);
+    if (e->tv_lds != 8 && e->tv_lds != 1) return tomo_tv_partial(e, vol, eps);
     // the LDS march without its gradient half: x is read once (the direct-global k_tv_value reads it twice)
     float *x;
     if ((rc = get_vol(e, vol, &x))) return rc;
@@ -1440,7 +1446,7 @@ static int tv_gd_impl(tomo_engine *e, int ng, float dPOCS, float eps, int track_
 {
     int rc;
     // the TV value before descent comes out of the first gradient pass (its denominators are the TV integrand)
-    const bool fold_tv = ng > 0 && e && e->tv_lds == 8;
+    const bool fold_tv = ng > 0 && e && (e->tv_lds == 8 || e->tv_lds == 1);
     if (fold_tv) { if ((rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc; }
     else if ((rc = tomo_tv(e, TOMO_VOL_RECON, eps))) return rc;
     for (int g = 0; g < ng; ++g) {
@@ -1528,7 +1534,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
         e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; return TOMO_OK;
     }
-    if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 0 direct, 8 / 16 = z-columns per workgroup
+    if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 1 register march, 8 / 16 LDS march (z-columns per workgroup), 0 direct
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
 
