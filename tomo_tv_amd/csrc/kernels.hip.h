@@ -1435,9 +1435,9 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
             if (interior) {
 #pragma unroll
                 for (int j = 0; j < TZ + 2; ++j) {
-                    const float *rp = x + (size_t)(yy + zc[j]) * sx;
-                    c[j] = rp[s];
-                    E[j] = rp[se];
+                    const float *rp = x + (size_t)(yy + zc[j]) * sx;   // wave-uniform; unsigned lane offsets -> saddr form
+                    c[j] = rp[(unsigned)s];
+                    E[j] = rp[(unsigned)se];
                 }
             } else {
 #pragma unroll
@@ -1499,7 +1499,8 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                 gv += (c - c0[j - 1]) * R0[j - 1];
                 int z = z0 + j - 1;
                 if (z < n && s < nx) {
-                    g[(size_t)(y * n + z) * sx + s] = gv;
+                    float *gr = g + (size_t)(y * n + z) * sx;
+                    gr[(unsigned)s] = gv;
                     acc += (double)(gv * gv);
                 }
             }
