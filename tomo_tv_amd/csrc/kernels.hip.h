@@ -1407,7 +1407,8 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
 // and s0+64) are loaded into lanes 0 and 63 of a per-column edge register, which is exactly the DPP `old` operand the
 // shifts leave in those lanes; R of the phantom slice s0-1 (needed by lane 0's R(p-i)) is the same formula evaluated on
 // the edge registers.  Same arithmetic, operand order and rounding sequence as k_tv_grad_lds.
-template <int TZ, bool WITH_TV>
+// GRAD = false: the TV value alone (rows y, y+1 only; no phantom slice, no gradient, no store).
+template <int TZ, bool WITH_TV, bool GRAD = true>
 __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x, Halo h, float *__restrict__ g,
                                                       double *__restrict__ part, float eps, int n, int nx, int sx,
                                                       int yseg, double *__restrict__ part_tv)
@@ -1463,12 +1464,12 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
         auto shl = [&](float old, float v) {                    // lane l <- lane l+1 ; lane 63 keeps `old`
             return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
         };
-        fetch(y0 - 1, cm, En);
+        if (GRAD) fetch(y0 - 1, cm, En);
         fetch(y0, c0, E0);
         fetch(y0 + 1, cp, Ep);
         // R of row y0-1 for the output columns (its +y neighbour is row y0)
 #pragma unroll
-        for (int j = 1; j <= TZ; ++j) {
+        for (int j = 1; GRAD && j <= TZ; ++j) {
             float xip = shl(En[j], cm[j]), dd;
             TVR_RINV(cm[j], xip, c0[j], cm[j + 1], Rm[j], dd)
             (void)dd;
@@ -1484,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                 if (WITH_TV && j >= 1 && z0 + j - 1 < n && s < nx) tvacc += (double)dd;
             }
 #pragma unroll
-            for (int j = 1; j <= TZ; ++j) {
+            for (int j = 1; GRAD && j <= TZ; ++j) {
                 // R at the phantom slice s0-1 (lane 0 of the edge registers), then R(p-i) by the shift
                 float re, dd;
                 TVR_RINV(E0[j], c0[j], Ep[j], E0[j + 1], re, dd)
@@ -1513,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
         }
 #undef TVR_RINV
     }
-    block_accumulate(acc, part);
+    if (GRAD) block_accumulate(acc, part);
     if (WITH_TV) {
         __syncthreads();
         block_accumulate(tvacc, part_tv);

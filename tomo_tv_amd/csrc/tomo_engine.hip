@@ -1434,8 +1434,13 @@ int tomo_tv(tomo_engine *e, int vol, float eps)
     HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
     Halo h{e->halo_lo, e->halo_hi};
     const int yseg = 32;
-    dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
-    hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+    if (e->tv_lds == 1) {
+        int64_t items = (int64_t)((e->n + 7) / 8) * (e->sxc / 64) * ((e->n + yseg - 1) / yseg);
+        hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+    } else {
+        dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+        hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+    }
     LAUNCHCHK();
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part_tv, e->d_scal + TOMO_S_TV);
     LAUNCHCHK();
