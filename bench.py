@@ -226,6 +226,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "iters_per_s": args.steps / el,
+            # every angle of the SART sweep updates every voxel (SURVEY.md section 8d asks for this figure as well)
+            "sart_gvoxel_angle_updates_per_s": vox_total * nproj * args.steps / el / 1e9,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
