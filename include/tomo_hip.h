@@ -190,6 +190,8 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     slice neighbours by DPP; bit-identical to the LDS march and 13 % faster), 8 / 16 = LDS march with that
  *                     many z-columns per workgroup, 0 = direct-global stencil
  *   "fgp_fused" (1):  one fused kernel per FGP iteration (single slab)
+ *   "art_chain" (1):  tomo_art in natural row order as per-angle FP + ray recurrence + BP (k_art_chain) instead of
+ *                     row-by-row steps (k_art, which still serves tomo_art_order with a permutation)
  *   "sart_tile" (1):  fused SART steps on image tiles streamed through LDS (k_sart_tile, in place) instead of the ray-walk
  *                     form (k_sart_seg); equal at 512 slices per GPU, 14-18 % faster on slabs of <= 128 slices
  *   "fp_tile" (1):    all-angle forward projection from LDS-resident image tiles (k_fp_tile + k_fp_tile_reduce);

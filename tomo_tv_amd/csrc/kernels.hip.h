@@ -973,6 +973,73 @@ __global__ __launch_bounds__(1024) void k_art(float *__restrict__ x, const uint3
     }
 }
 
+// ---- ART in natural row order, one angle at a time ------------------------------------------------------------------
+// Two rays of one angle that are not neighbours share no pixel (a unit pixel is crossed by at most two unit-spaced rays).
+// So within an angle the Kaczmarz chain a_j = (b_j - A_j x^{(j)}) / |A_j|^2, x^{(j+1)} = x^{(j)} + beta a_j A_j^T only
+// couples neighbours:  A_j x^{(j)} = A_j x^{(0)} + beta a_{j-1} (A_j . A_{j-1}).  One angle of the sweep is therefore
+//   d = A_i x (a forward projection of the angle),
+//   a_j = (b_j - d_j - beta a_{j-1} G_{j-1}) / |A_j|^2   (k_art_chain: a scalar recurrence along the rays, lanes = slices),
+//   x += beta A_i^T a (k_bp_art: the two updates of a pixel in ray order, (w a) beta like ctvlib.cpp:152),
+// the same iterates as the row-sequential k_art up to the rounding of the dot products (d + correction instead of a dot
+// over the updated pixels): 60 x 3 launches instead of 15360 row steps with two barriers each at 256^3 x 60.
+__global__ __launch_bounds__(256) void k_art_chain(const float *__restrict__ d, const float *__restrict__ b,
+                                                    const float *__restrict__ inner, const float *__restrict__ cross,
+                                                    float *__restrict__ a_out, float beta, int row0, int nray, int sx)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= sx) return;
+    float aprev = 0.f, gprev = 0.f;
+    constexpr int U = 16;                                // the loads of U rays are independent of the chain: issue them together
+    for (int j0 = 0; j0 < nray; j0 += U) {
+        float dv[U], bv[U], ipv[U], gv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + min(j0 + u, nray - 1);
+            const size_t o = (size_t)row * sx + s;
+            dv[u] = d[o]; bv[u] = b[o]; ipv[u] = inner[row]; gv[u] = cross[row];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j0 + u < nray) {
+                float a = 0.f;
+                if (ipv[u] > 0.f) a = (bv[u] - (dv[u] + beta * aprev * gprev)) / ipv[u];   // an empty ray is skipped (a = 0)
+                a_out[(size_t)(row0 + j0 + u) * sx + s] = a;
+                aprev = a; gprev = gv[u];
+            }
+        }
+    }
+}
+
+template <int VEC, int PPW>
+__global__ __launch_bounds__(256) void k_bp_art(float *__restrict__ x, const CellD *__restrict__ cell,
+                                                 const float *__restrict__ a, float beta, int npix, int sx,
+                                                 int ngroups, int nchunk)
+{
+    typedef typename VecOf<VEC>::T V;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int gw = blockIdx.x * 4 + wave;
+    int chunk = gw / ngroups;
+    int grp = gw - chunk * ngroups;
+    int p0 = grp * PPW;
+    if (p0 >= npix || chunk >= nchunk) return;   // grid is rounded up to whole workgroups
+    int off = chunk * (64 * VEC) + lane * VEC;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        int p = p0 + q;
+        if (p >= npix) break;
+        CellD c = cell[p];
+        if (c.w0 == 0.f && c.w1 == 0.f) continue;
+        V xv = *reinterpret_cast<const V *>(x + (size_t)p * sx + off);
+        // ascending ray order, each term rounded like `val * a * beta`
+        uint32_t ra = c.r0, rb = c.r1; float wa = c.w0, wb = c.w1;
+        if (wb != 0.f && (wa == 0.f || rb < ra)) { uint32_t tr = ra; ra = rb; rb = tr; float tw = wa; wa = wb; wb = tw; }
+        if (wa != 0.f) xv += (wa * *reinterpret_cast<const V *>(a + (size_t)ra * sx + off)) * beta;
+        if (wb != 0.f) xv += (wb * *reinterpret_cast<const V *>(a + (size_t)rb * sx + off)) * beta;
+        *reinterpret_cast<V *>(x + (size_t)p * sx + off) = xv;
+    }
+}
+
 // ---- element-wise and reductions (float4 grid-stride; n4 = element count / 4) -------------------------
 typedef float f4 __attribute__((ext_vector_type(4)));
 

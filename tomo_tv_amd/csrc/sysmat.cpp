@@ -234,6 +234,24 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err)
     float L = 0.f;
     for (int64_t p = 0; p < npix; ++p) L = std::max(L, ata1[p]);
     t.lipschitz = L;
+    // inner products of neighbouring rays (fp64 accumulation, ascending pixel) and the neighbour property
+    t.rowcross.assign(m.nrow, 0.f);
+    t.art_chain_ok = true;
+    {
+        std::vector<double> cross(m.nrow, 0.0);
+        for (int i = 0; i < P; ++i) {
+            const Cell *ci = t.cell.data() + (size_t)i * npix;
+            double *cr = cross.data() + (size_t)i * N;
+            for (int64_t p = 0; p < npix; ++p) {
+                const Cell &c = ci[p];
+                if (c.w0 == 0.f || c.w1 == 0.f) continue;
+                uint32_t lo = std::min(c.r0, c.r1), hi = std::max(c.r0, c.r1);
+                if (hi != lo + 1) { t.art_chain_ok = false; continue; }
+                cr[lo] += (double)c.w0 * (double)c.w1;
+            }
+        }
+        for (int64_t r = 0; r < m.nrow; ++r) t.rowcross[r] = (float)cross[r];
+    }
     return true;
 }
 

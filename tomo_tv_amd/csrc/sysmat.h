@@ -19,6 +19,11 @@ struct Cell {  // the (at most two) rays of one angle that cross one pixel
 
 struct Tables {
     std::vector<float> rowsum, rowinner, colsum_all;
+    // rowcross[r] = A_r . A_{r+1} for two rays of one angle (0 for an angle's last ray).  art_chain_ok: every pixel's
+    // two rays of an angle are neighbours (r1 = r0 + 1), so rays two apart share no pixel and one angle of a Kaczmarz
+    // sweep is a forward projection + a scalar recurrence along the rays + a back-projection (k_art_chain).
+    std::vector<float> rowcross;
+    bool art_chain_ok = false;
     std::vector<Cell> cell;  // [P][N*N]
     float lipschitz = 0.f;
     // "walk" lists for the fused SART step: per ray, its matrix entries plus a share of the angle's

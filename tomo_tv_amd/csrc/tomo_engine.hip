@@ -45,7 +45,9 @@ struct tomo_engine {
     // tables
     uint32_t *d_rptr = nullptr;
     uint2 *d_rent = nullptr;
-    float *d_rowsum = nullptr, *d_rowinner = nullptr, *d_colsum_all = nullptr;
+    float *d_rowsum = nullptr, *d_rowinner = nullptr, *d_colsum_all = nullptr, *d_rowcross = nullptr;
+    bool art_chain_ok = false;
+    int art_chain = 1;                            // natural-order ART: per-angle FP + ray recurrence + BP instead of row steps
     CellD *d_cell = nullptr;
     uint32_t *d_wptr = nullptr;                   // walk lists of the fused SART step
     uint2 *d_went = nullptr;
@@ -417,12 +419,15 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
     if ((rc = dev_alloc((void **)&e->d_rowsum, t.rowsum.size() * 4, false, e->stream))) return rc;
     if ((rc = dev_alloc((void **)&e->d_rowinner, t.rowinner.size() * 4, false, e->stream))) return rc;
     if ((rc = dev_alloc((void **)&e->d_colsum_all, t.colsum_all.size() * 4, false, e->stream))) return rc;
+    if ((rc = dev_alloc((void **)&e->d_rowcross, t.rowcross.size() * 4, false, e->stream))) return rc;
+    e->art_chain_ok = t.art_chain_ok;
     if ((rc = dev_alloc((void **)&e->d_cell, t.cell.size() * sizeof(CellD), false, e->stream))) return rc;
     HIPCHK(hipMemcpy(e->d_rptr, ptr32.data(), ptr32.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_rent, ent.data(), (size_t)e->nnz * sizeof(uint2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_rowsum, t.rowsum.data(), t.rowsum.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_rowinner, t.rowinner.data(), t.rowinner.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_colsum_all, t.colsum_all.data(), t.colsum_all.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_rowcross, t.rowcross.data(), t.rowcross.size() * 4, hipMemcpyHostToDevice));
     build_walk(m, e->n, e->np, t);
     {
         std::vector<uint2> went(t.walk_pix.size() ? t.walk_pix.size() : 1);
@@ -605,7 +610,7 @@ int tomo_destroy(tomo_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
-    void *ptrs[] = {e->d_st_cell, e->d_st_win, e->d_st_segid, e->d_st_seg, e->d_st_ent, e->d_st_row_first, e->d_st_row_nseg, e->st_partial, e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
+    void *ptrs[] = {e->d_st_cell, e->d_st_win, e->d_st_segid, e->d_st_seg, e->d_st_ent, e->d_st_row_first, e->d_st_row_nseg, e->st_partial, e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_rowcross, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
                     e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -900,6 +905,29 @@ int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
         int rc = ensure_stage(e, e->nrows * sizeof(int32_t)); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(e->stage, order_host, e->nrows * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
         d_order = (int32_t *)e->stage;
+    }
+    if (!order_host && e->art_chain && e->art_chain_ok) {
+        // natural order: one angle = forward projection + recurrence along the rays + back-projection (k_art_chain)
+        float *d, *a; int rc;
+        if ((rc = get_sino(e, &e->sino[TOMO_SINO_G], &d)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &a))) return rc;
+        const float *b = e->sino[TOMO_SINO_B];
+        int nchunk = e->sxc / (64 * e->vec);
+        int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
+        dim3 bgrid((unsigned)(((int64_t)ngroups * nchunk + 3) / 4));
+        for (int i = 0; i < e->np; ++i) {
+            if ((rc = launch_fp<FP_STORE>(e, x, i * e->n, e->n, nullptr, d))) return rc;
+            hipLaunchKernelGGL(k_art_chain, dim3((unsigned)((e->sx + 255) / 256)), dim3(256), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx);
+            LAUNCHCHK();
+            const CellD *cell = e->d_cell + (size_t)i * e->npix;
+            const float *ai = a + (size_t)i * e->n * e->sx;
+            switch (e->vec) {
+            case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
+            case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
+            default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
+            }
+            LAUNCHCHK();
+        }
+        return tomo_positivity(e, TOMO_VOL_RECON);
     }
     hipLaunchKernelGGL(k_art, dim3(e->sxc / 64), dim3(64 * ART_WAVES), 0, e->stream, x, e->d_rptr, e->d_rent, e->sino[TOMO_SINO_B], e->d_rowinner, beta, (int)e->nrows, e->sx, d_order);
     LAUNCHCHK();
@@ -1528,6 +1556,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
+    if (std::strcmp(name, "art_chain") == 0) { e->art_chain = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { e->sart_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
