@@ -646,6 +646,9 @@ def test_matrix_whose_ray_windows_defeat_the_tile_kernels(gpu):
     for _ in range(3):
         dev.SIRT(1.0 / L); ref.SIRT(1.0 / L)
     assert rel_l2(dev.get_volume(), ref.recon) < 1e-5
+    dev.row_inner_product(); ref.row_inner_product()
+    dev.ART(0.6); ref.ART(0.6)                   # neighbouring rays are not neighbours here: the row-sequential kernel runs
+    assert rel_l2(dev.get_volume(), ref.recon) < 1e-5
 
 
 @pytest.mark.parametrize("opts", [{}, {"sart_tile": 0}, {"sart_fused": 0}])
@@ -714,3 +717,25 @@ def test_tv_gradient_kernels_are_bit_identical(gpu, N, Nx):
         out[opt] = (tv, t.get_volume(), t.tv())
     assert np.array_equal(out[1][1], out[8][1]) and out[1][0] == out[8][0] and out[1][2] == out[8][2]
     assert np.abs(out[1][1] - out[0][1]).max() < 1e-6 and abs(out[1][0] - out[0][0]) <= 1e-6 * out[0][0]
+
+
+@pytest.mark.parametrize("N,P,Nx", [(48, 7, 70), (33, 5, 130), (16, 1, 3)])
+def test_chained_art_equals_row_sequential_art(gpu, N, P, Nx):
+    """tomo_art in natural order: per-angle FP + recurrence along the rays + BP (k_art_chain) against the row-by-row
+    kernel (k_art) and the oracle; two sweeps."""
+    ang = np.linspace(-75, 72, P) if P > 1 else np.array([33.0])
+    A = oracle.parallel_ray(N, ang)
+    x = ellipsoids(Nx, N, seed=6)
+    ref = oracle.ctvlib(Nx, N, P); ref.load_A(A); ref.original_volume = x.copy(); ref.create_projections()
+    ref.row_inner_product()
+    vols = {}
+    for chain in (1, 0):
+        dev = ctvlib(Nx, N, P); dev.load_A(A)
+        dev.set_option("art_chain", chain)
+        dev.set_tilt_series(ref.b)
+        dev.row_inner_product()
+        dev.ART(0.8); dev.ART(0.8)
+        vols[chain] = dev.get_volume()
+    ref.ART(0.8); ref.ART(0.8)
+    assert rel_l2(vols[1], vols[0]) < 2e-6
+    assert rel_l2(vols[1], ref.recon) < 1e-5 and rel_l2(vols[0], ref.recon) < 1e-5
