@@ -1312,15 +1312,33 @@ static int tv_grid(tomo_engine *e)
     return (int)std::min<int64_t>((items + 3) / 4, 256 * 16);
 }
 
+// TV of a volume with the halo planes as they are (step form: the caller has exchanged or wrapped them)
 int tomo_tv_partial(tomo_engine *e, int vol, float eps)
 {
     NEED(e);
     float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
-    if ((rc = reduce_begin(e))) return rc;
     Halo h{e->halo_lo, e->halo_hi};
-    hipLaunchKernelGGL(k_tv_value, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx);
+    if (e->tv_lds != 8 && e->tv_lds != 1) {   // direct-global stencil (reads x twice)
+        if ((rc = reduce_begin(e))) return rc;
+        hipLaunchKernelGGL(k_tv_value, dim3(tv_grid(e)), dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx);
+        LAUNCHCHK();
+        return reduce_end(e, TOMO_S_TV);
+    }
+    // the march of the gradient kernels without their gradient half: x is read once
+    if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
+    HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
+    const int yseg = 32;
+    if (e->tv_lds == 1) {
+        int64_t items = (int64_t)((e->n + 7) / 8) * (e->sxc / 64) * ((e->n + yseg - 1) / yseg);
+        hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+    } else {
+        dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+        hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+    }
     LAUNCHCHK();
-    return reduce_end(e, TOMO_S_TV);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part_tv, e->d_scal + TOMO_S_TV);
+    LAUNCHCHK();
+    return TOMO_OK;
 }
 
 static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
@@ -1454,25 +1472,7 @@ int tomo_tv(tomo_engine *e, int vol, float eps)
 {
     int rc;
     if ((rc = tomo_halo_local(e, vol))) return rc;
-    if (e->tv_lds != 8 && e->tv_lds != 1) return tomo_tv_partial(e, vol, eps);
-    // the LDS march without its gradient half: x is read once (the direct-global k_tv_value reads it twice)
-    float *x;
-    if ((rc = get_vol(e, vol, &x))) return rc;
-    if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
-    HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
-    Halo h{e->halo_lo, e->halo_hi};
-    const int yseg = 32;
-    if (e->tv_lds == 1) {
-        int64_t items = (int64_t)((e->n + 7) / 8) * (e->sxc / 64) * ((e->n + yseg - 1) / yseg);
-        hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
-    } else {
-        dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
-        hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
-    }
-    LAUNCHCHK();
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part_tv, e->d_scal + TOMO_S_TV);
-    LAUNCHCHK();
-    return TOMO_OK;
+    return tomo_tv_partial(e, vol, eps);
 }
 
 static int tv_gd_impl(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot)
