@@ -157,6 +157,8 @@ int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last);
 /* step forms (use the halo buffers as they are) */
 int tomo_tv_partial(tomo_engine *e, int vol, float eps);                /* tv_gd.cu:27-47 -> TOMO_S_TV */
 int tomo_tv_grad(tomo_engine *e, float eps);                            /* ctvlib.cpp:415-449 -> TOMO_S_GNORM */
+/* the same pass, also the TV value of recon -> TOMO_S_TV (tv_gd.cu:177-183: the value "before descent") */
+int tomo_tv_grad_tv(tomo_engine *e, float eps);
 int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp);             /* ctvlib.cpp:452-458 (+461 when clamp) */
 /* the same step, also ||recon_new - track_vol||^2 -> scalar `slot` and track_vol = recon_new (sim_ASD.py:86-88) */
 int tomo_tv_update_tracked(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot);

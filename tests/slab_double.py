@@ -161,6 +161,10 @@ class OracleSlabBackend:
         self.g = (v1n / v1d + v2n / v2d + v3n / v3d + v4n / v4d).astype(np.float32)
         self.scal[S_GNORM] = float((self.g.astype(np.float64) ** 2).sum())
 
+    def c_tv_grad_tv(self, eps):
+        self.c_tv_partial(VOL_RECON, eps)
+        self.c_tv_grad(eps)
+
     def c_tv_update(self, dPOCS, clamp):
         nrm = np.float32(np.sqrt(float(self.scal[S_GNORM])))
         self.t.recon -= (np.float32(dPOCS) * self.g) / nrm

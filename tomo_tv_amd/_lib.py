@@ -65,6 +65,7 @@ SIGNATURES = {
     "tomo_set_slab_edges": [_p, _i, _i],
     "tomo_tv_partial": [_p, _i, _f],
     "tomo_tv_grad": [_p, _f],
+    "tomo_tv_grad_tv": [_p, _f],
     "tomo_tv_update": [_p, _f, _i],
     "tomo_fgp_begin": [_p],
     "tomo_fgp_obj": [_p, _f],

@@ -1384,6 +1384,14 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
 }
 
 int tomo_tv_grad(tomo_engine *e, float eps) { return tv_grad_impl(e, eps, false); }
+int tomo_tv_grad_tv(tomo_engine *e, float eps)
+{
+    if (e && e->tv_lds != 8 && e->tv_lds != 1) {   // kernels without the folded value: a separate pass
+        int rc = tomo_tv_partial(e, TOMO_VOL_RECON, eps);
+        return rc ? rc : tv_grad_impl(e, eps, false);
+    }
+    return tv_grad_impl(e, eps, true);
+}
 
 static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot, bool wrap = false)
 {

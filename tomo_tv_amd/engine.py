@@ -337,16 +337,17 @@ class _EngineBase:
         if self.comm is None:
             self.be.c("tv_gd", ng, float(dPOCS), self.tv_eps)
             return self._scalar(S_TV)
-        tv0 = self._tv_of(VOL_RECON, self.tv_eps)
+        if ng <= 0:
+            tv0 = self._tv_of(VOL_RECON, self.tv_eps)
+            self.be.c("positivity", VOL_RECON)
+            return tv0
         for g in range(ng):
-            if g > 0:
-                self._exchange(VOL_RECON)
-            self.be.c("tv_grad", self.tv_eps)
+            self._exchange(VOL_RECON)
+            # the first gradient pass also leaves the slab's share of the TV value "before descent"
+            self.be.c("tv_grad_tv" if g == 0 else "tv_grad", self.tv_eps)
             self.comm.allreduce_sum(self.be.scalar_tensor(S_GNORM))   # stays on the device
             self.be.c("tv_update", float(dPOCS), int(g == ng - 1))
-        if ng <= 0:
-            self.be.c("positivity", VOL_RECON)
-        return tv0
+        return self._scalar(S_TV)
 
     def tv_fgp(self, ng, lam, vol=VOL_RECON):
         """FGP-TV prox on recon (tv_fgp.cu:192-281), or on another volume slot; returns TV of the input."""
@@ -495,17 +496,15 @@ class tomoengine(_EngineBase):
             nrm = self.matrix_2norm()
             self.copy_recon()
             return tv0, nrm
-        tv0 = self._tv_of(VOL_RECON, self.tv_eps)
         for g in range(ng):
-            if g > 0:
-                self._exchange(VOL_RECON)
-            self.be.c("tv_grad", self.tv_eps)
+            self._exchange(VOL_RECON)
+            self.be.c("tv_grad_tv" if g == 0 else "tv_grad", self.tv_eps)
             self.comm.allreduce_sum(self.be.scalar_tensor(S_GNORM))   # stays on the device
             if g == ng - 1:
                 self.be.c("tv_update_tracked", float(dPOCS), 1, VOL_TEMP, S_DIFF)
             else:
                 self.be.c("tv_update", float(dPOCS), 0)
-        return tv0, float(np.sqrt(self._scalar(S_DIFF)))
+        return self._scalar(S_TV), float(np.sqrt(self._scalar(S_DIFF)))
 
     def poisson_ML(self, lam):
         self.be.c("poisson_ml", float(lam))
