@@ -149,6 +149,7 @@ int tomo_bind_scalar_buffer(tomo_engine *e, void *device_doubles);      /* >= TO
  * (mpi_ctvlib.cpp:400-422) and leaves the received planes in the bound buffers. */
 int tomo_bind_halo(tomo_engine *e, void *device_lo, void *device_hi);
 int tomo_halo_pack(tomo_engine *e, int field, int last, void *device_dst); /* field: tomo_volume or TOMO_FIELD_* */
+int tomo_halo_pack_both(tomo_engine *e, int field, void *first_plane, void *last_plane);  /* both planes, one launch */
 int tomo_halo_local(tomo_engine *e, int field);
 enum tomo_field { TOMO_FIELD_FGP_D = 100, TOMO_FIELD_FGP_P1 = 101 };
 /* global-edge flags for the non-periodic FGP stencil (tv_fgp.cu:57,81) */
@@ -160,6 +161,9 @@ int tomo_tv_grad(tomo_engine *e, float eps);                            /* ctvli
 /* the same pass, also the TV value of recon -> TOMO_S_TV (tv_gd.cu:177-183: the value "before descent") */
 int tomo_tv_grad_tv(tomo_engine *e, float eps);
 int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp);             /* ctvlib.cpp:452-458 (+461 when clamp) */
+/* the same step, also leaving the new first and last slice in two device planes (N*N floats each): what the ring
+ * exchange of the slab-sharded descent sends before the next gradient pass, without a gather launch */
+int tomo_tv_update_planes(tomo_engine *e, float dPOCS, int clamp, void *first_plane, void *last_plane);
 /* the same step, also ||recon_new - track_vol||^2 -> scalar `slot` and track_vol = recon_new (sim_ASD.py:86-88) */
 int tomo_tv_update_tracked(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot);
 int tomo_fgp_begin(tomo_engine *e);                                     /* tv_fgp.cu:216-227 */

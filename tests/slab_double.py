@@ -70,6 +70,10 @@ class OracleSlabBackend:
         x = self._field(field)
         return torch.from_numpy(x[0].ravel().copy()), torch.from_numpy(x[-1].ravel().copy())
 
+    def tv_update_planes(self, dPOCS, clamp):
+        self.c_tv_update(dPOCS, clamp)
+        return self.pack_planes(VOL_RECON)
+
     def halo_tensors(self):
         return self.halo_lo, self.halo_hi
 

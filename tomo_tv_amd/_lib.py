@@ -61,6 +61,7 @@ SIGNATURES = {
     "tomo_bind_scalar_buffer": [_p, _p],
     "tomo_bind_halo": [_p, _p, _p],
     "tomo_halo_pack": [_p, _i, _i, _p],
+    "tomo_halo_pack_both": [_p, _i, _p, _p],
     "tomo_halo_local": [_p, _i],
     "tomo_set_slab_edges": [_p, _i, _i],
     "tomo_tv_partial": [_p, _i, _f],
@@ -82,6 +83,7 @@ SIGNATURES = {
     "tomo_sart_data": [_p, _i, _i, _f, _i, _p],
     "tomo_sart_tracked": [_p, _i, _i, _f, _i, _p, _i, _i],
     "tomo_tv_update_tracked": [_p, _f, _i, _i, _i],
+    "tomo_tv_update_planes": [_p, _f, _i, _p, _p],
     "tomo_tv_gd_tracked": [_p, _i, _f, _f, _i, _i],
     "tomo_poisson_residual": [_p, _i, _i, _i],
     "tomo_scale_volume": [_p, _i, _f],

@@ -1289,6 +1289,17 @@ int tomo_halo_pack(tomo_engine *e, int field, int last, void *device_dst)
     return TOMO_OK;
 }
 
+int tomo_halo_pack_both(tomo_engine *e, int field, void *first_plane, void *last_plane)
+{
+    NEED(e);
+    float *x; int rc; if ((rc = field_ptr(e, field, &x))) return rc;
+    if (!first_plane || !last_plane) return fail(TOMO_ERR_ARG, "null destination");
+    // k_halo_wrap(x, lo, hi): lo <- last slice, hi <- slice 0
+    hipLaunchKernelGGL(k_halo_wrap, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, x, (float *)last_plane, (float *)first_plane, (int)e->npix, e->sx, e->nx);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
 int tomo_halo_local(tomo_engine *e, int field)
 {
     NEED(e);
@@ -1393,7 +1404,10 @@ int tomo_tv_grad_tv(tomo_engine *e, float eps)
     return tv_grad_impl(e, eps, true);
 }
 
-static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot, bool wrap = false)
+// wrap: also write the new last / first slice into the engine's halo planes (single slab, periodic); plane_last /
+// plane_first: into caller buffers instead (slab-sharded: the planes the ring exchange sends next)
+static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot, bool wrap = false,
+                          float *plane_last = nullptr, float *plane_first = nullptr)
 {
     NEED(e);
     float *x = e->vol[TOMO_VOL_RECON], *g, *track = nullptr; int rc;
@@ -1410,7 +1424,7 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
     int64_t n4 = e->vol_elems() / 4;
     {
         ProfScope ps(e, TOMO_K_TV_UPDATE);
-        float *wl = wrap ? e->halo_lo : nullptr, *wh = wrap ? e->halo_hi : nullptr;
+        float *wl = wrap ? e->halo_lo : plane_last, *wh = wrap ? e->halo_hi : plane_first;
         if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)track, e->d_part, wl, wh, e->nx, e->sx / 4);
         else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr, wl, wh, e->nx, e->sx / 4);
     }
@@ -1419,6 +1433,12 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
 }
 
 int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp) { return tv_update_impl(e, dPOCS, clamp, -1, 0); }
+
+int tomo_tv_update_planes(tomo_engine *e, float dPOCS, int clamp, void *first_plane, void *last_plane)
+{
+    if (!first_plane || !last_plane) return fail(TOMO_ERR_ARG, "null plane buffer");
+    return tv_update_impl(e, dPOCS, clamp, -1, 0, false, (float *)last_plane, (float *)first_plane);
+}
 
 int tomo_tv_update_tracked(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot)
 {

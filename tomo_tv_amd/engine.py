@@ -86,8 +86,13 @@ class _SlabBackend:
         return self._scal_t[slot:slot + 1]
 
     def pack_planes(self, field):
-        self.c("halo_pack", field, 0, ctypes.c_void_p(self._send_lo.data_ptr()))
-        self.c("halo_pack", field, 1, ctypes.c_void_p(self._send_hi.data_ptr()))
+        self.c("halo_pack_both", field, ctypes.c_void_p(self._send_lo.data_ptr()), ctypes.c_void_p(self._send_hi.data_ptr()))
+        return self._send_lo, self._send_hi
+
+    def tv_update_planes(self, dPOCS, clamp):
+        """TV descent step that also leaves recon's new first / last slice in the send planes (no gather launch)."""
+        self.c("tv_update_planes", float(dPOCS), int(clamp), ctypes.c_void_p(self._send_lo.data_ptr()),
+               ctypes.c_void_p(self._send_hi.data_ptr()))
         return self._send_lo, self._send_hi
 
     def halo_tensors(self):
@@ -158,8 +163,9 @@ class _EngineBase:
         self.comm.allreduce_sum(t)
         return float(t.item())
 
-    def _exchange(self, field):
-        lo, hi = self.be.pack_planes(field)
+    def _exchange(self, field, planes=None):
+        """Ring exchange of the field's boundary planes (``planes``: already packed by the producing kernel)."""
+        lo, hi = planes if planes is not None else self.be.pack_planes(field)
         hlo, hhi = self.be.halo_tensors()
         self.comm.exchange_planes(lo, hi, hlo, hhi)
 
@@ -341,12 +347,16 @@ class _EngineBase:
             tv0 = self._tv_of(VOL_RECON, self.tv_eps)
             self.be.c("positivity", VOL_RECON)
             return tv0
+        planes = None
         for g in range(ng):
-            self._exchange(VOL_RECON)
+            self._exchange(VOL_RECON, planes)
             # the first gradient pass also leaves the slab's share of the TV value "before descent"
             self.be.c("tv_grad_tv" if g == 0 else "tv_grad", self.tv_eps)
             self.comm.allreduce_sum(self.be.scalar_tensor(S_GNORM))   # stays on the device
-            self.be.c("tv_update", float(dPOCS), int(g == ng - 1))
+            if g == ng - 1:
+                self.be.c("tv_update", float(dPOCS), 1)
+            else:                                                     # the step packs the planes the next exchange sends
+                planes = self.be.tv_update_planes(dPOCS, 0)
         return self._scalar(S_TV)
 
     def tv_fgp(self, ng, lam, vol=VOL_RECON):
@@ -496,14 +506,15 @@ class tomoengine(_EngineBase):
             nrm = self.matrix_2norm()
             self.copy_recon()
             return tv0, nrm
+        planes = None
         for g in range(ng):
-            self._exchange(VOL_RECON)
+            self._exchange(VOL_RECON, planes)
             self.be.c("tv_grad_tv" if g == 0 else "tv_grad", self.tv_eps)
             self.comm.allreduce_sum(self.be.scalar_tensor(S_GNORM))   # stays on the device
             if g == ng - 1:
                 self.be.c("tv_update_tracked", float(dPOCS), 1, VOL_TEMP, S_DIFF)
             else:
-                self.be.c("tv_update", float(dPOCS), 0)
+                planes = self.be.tv_update_planes(dPOCS, 0)
         return self._scalar(S_TV), float(np.sqrt(self._scalar(S_DIFF)))
 
     def poisson_ML(self, lam):
