@@ -396,6 +396,10 @@ static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *
 }
 
 // ---- creation ----------------------------------------------------------------------------------------------
+// host tables are released as soon as they are on the device (peak host memory: a few times nnz * 8 bytes per engine,
+// and one process per GPU builds its own)
+template <class V> static void release(V &v) { V().swap(v); }
+
 static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
 {
     Tables t;
@@ -449,6 +453,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_seg_exec, t.seg_exec.data(), t.seg_exec.size() * sizeof(SegItemD), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_row_first, t.row_first.data(), t.row_first.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_row_nseg, t.row_nseg.data(), t.row_nseg.size() * 4, hipMemcpyHostToDevice));
+        release(t.walk_pix); release(t.walk_w); release(t.walk_ptr); release(t.seg_exec); release(t.row_first); release(t.row_nseg);
     }
     {
         build_tiles(m, e->n, e->np, FT_TY, FT_TZ, 256, t);
@@ -467,6 +472,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_ft_tent, tent.data(), tent.size() * sizeof(uint2), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsptr, t.rseg_ptr.data(), t.rseg_ptr.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
+        release(tent); release(t.tile_off); release(t.tile_w); release(t.rseg_idx); release(t.rseg_ptr); release(t.tile_slot_ptr); release(t.tile_slot_seg0);
         build_sart_tiles(m, e->n, e->np, ST_T, ST_MAXR, 256, t);
         static_assert(Tables::ST_MAXSEG == ST_MAXSEG, "segment slots per tile");
         e->st_ok = t.st_ok;
@@ -489,7 +495,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             HIPCHK(hipMemcpy(e->d_st_row_first, t.st_row_first.data(), t.st_row_first.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_st_row_nseg, t.st_row_nseg.data(), t.st_row_nseg.size() * 4, hipMemcpyHostToDevice));
         }
-        { decltype(t.st_cell)().swap(t.st_cell); decltype(t.st_off)().swap(t.st_off); decltype(t.st_w)().swap(t.st_w); }
+        release(t.st_cell); release(t.st_off); release(t.st_w); release(t.st_seg); release(t.st_segid); release(t.st_win);
         build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, 2 * FB_A, t);   // the cell ring prefetches up to angle P + 2*FB_A - 2
         static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
         e->fb_ok = t.bp_tile_ok && e->np <= FB_MAX_PROJ;
