@@ -44,6 +44,8 @@ enum tomo_scalar { TOMO_S_DD = 0,      /* sum (A x - b)^2            data_distan
                    TOMO_S_RMSE = 4,    /* sum (recon - original)^2   rmse           */
                    TOMO_S_COST = 5,    /* Poisson-ML cost            poisson_ML     */
                    TOMO_S_L1 = 6,      /* sum |recon|                l1_norm        */
+                   TOMO_S_DIFF2 = 7,   /* a second step-norm slot: ASD-POCS keeps the SART step norm here until the
+                                          iteration's scalars are read together (one all-reduce, one read-back) */
                    TOMO_S_COUNT = 16 };
 
 const char *tomo_last_error(void);
@@ -87,16 +89,25 @@ int tomo_copy_volume(tomo_engine *e, int dst, int src);                 /* :404 
 /* volume of another engine with the same slab shape (rebuilding the tilt geometry keeps the reconstruction:
  * tomoengine::update_projection_angles, tomoengine.cpp:128-149) */
 int tomo_copy_volume_from(tomo_engine *dst, int dst_vol, tomo_engine *src, int src_vol);
+/* the same rebuild without a copy and with one set of tables in memory: release the old engine's tables and sinograms
+ * (only tomo_adopt_volumes / tomo_destroy remain valid on it), create the new engine, move the volumes over
+ * (ctvlib::update_proj_angles, ctvlib.cpp:317-333, keeps recon across a matrix change as well) */
+int tomo_release_geometry(tomo_engine *e);
+int tomo_adopt_volumes(tomo_engine *dst, tomo_engine *src);
 
 /* ---- projector -------------------------------------------------------------------------------------- */
 int tomo_forward_projection(tomo_engine *e, int vol, int sino);         /* :416-427 forwardProjection; :109-126 create_projections */
 int tomo_back_projection(tomo_engine *e, int sino, int vol);            /* :279-291 back_projection: vol = A^T sino */
 int tomo_lipschitz(tomo_engine *e, float *L);                           /* ctvlib.cpp:194-202 lipschits; tomoengine.cpp:369-371 */
 int tomo_row_inner_product(tomo_engine *e);                             /* ctvlib.cpp:234-242 normalization */
+int tomo_lipschitz_cimmino(tomo_engine *e, float *L);                   /* ctvlib.cpp:198-199: max(A^T M A 1), M = diag(|A_i|^2) */
 
 /* ---- reconstruction steps --------------------------------------------------------------------------- */
 /* ctvlib::SIRT(beta): x = max(0, x + beta A^T (b - A x))   ctvlib.cpp:205-221.  vol = RECON or YK. */
 int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter);
+/* ctvlib::SIRT(beta) after cimminos_method(): x = max(0, x + A^T M (b - A x) beta/Nrow), M_ii = |A_i|^2 -- the
+ * reference multiplies by the row norms (quirk Q10); reproduced as written   ctvlib.cpp:212-216, 245-251 */
+int tomo_sirt_cimmino(tomo_engine *e, int vol, float beta, int niter);
 /* tomoengine::SIRT(nIter) (ASTRA SIRT, min-constraint 0): x = max(0, x + C A^T R (b - A x))  tomoengine.cpp:181-205 */
 int tomo_sirt(tomo_engine *e, int vol, int niter);
 /* the same with the measured data in any sinogram slot: multimodal::SIRT(e, s, nIter)  multimodal.cpp:339-358 */
@@ -155,6 +166,9 @@ enum tomo_field { TOMO_FIELD_FGP_D = 100, TOMO_FIELD_FGP_P1 = 101 };
 /* global-edge flags for the non-periodic FGP stencil (tv_fgp.cu:57,81) */
 int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last);
 
+/* the volume the tv_gd / tv_grad / tv_update forms descend (default RECON): multimodal::tv_gd_4D runs the same descent
+ * on every element's tomogram (multimodal.cpp:494, chemistry/utils/regularizers/tv_gd.cu:208-296) */
+int tomo_tv_set_target(tomo_engine *e, int vol);
 /* step forms (use the halo buffers as they are) */
 int tomo_tv_partial(tomo_engine *e, int vol, float eps);                /* tv_gd.cu:27-47 -> TOMO_S_TV */
 int tomo_tv_grad(tomo_engine *e, float eps);                            /* ctvlib.cpp:415-449 -> TOMO_S_GNORM */
@@ -171,6 +185,16 @@ int tomo_fgp_begin_vol(tomo_engine *e, int vol);                        /* one e
 int tomo_fgp_obj(tomo_engine *e, float lambda);                         /* :44-65 + :143-154 */
 int tomo_fgp_grad(tomo_engine *e, float lambda);                        /* :67-115 */
 int tomo_fgp_end(tomo_engine *e, int iters);                            /* :272 */
+/* Fused FGP iteration, step form: Obj + nonneg + Grad + Proj of tv_fgp.cu:244-268 in one pass (28 instead of 48
+ * bytes per voxel) with ONE ring exchange per iteration when the volume is slab-sharded.  Caller-owned device planes
+ * (Nray*Nray floats each): lo = P1 of the slice below this slab; hi = 4 planes {A, P1, P2, P3} of the slice above;
+ * send_first = the same 4 planes of this slab's first slice and send_last = P1 of its last slice, written by
+ * begin (A) and by every step (P) -- the caller exchanges send_last -> next.lo and send_first -> prev.hi before each
+ * step and before end (tv_fgp.cu:57,81 need exactly these neighbours; mpi_ctvlib.cpp:400-422 is the reference ring). */
+int tomo_bind_fgp_halo(tomo_engine *e, void *lo, void *hi, void *send_first, void *send_last);
+int tomo_fgp_fused_begin(tomo_engine *e, int vol);
+int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration);
+int tomo_fgp_fused_end(tomo_engine *e, float lambda);                   /* the last iteration: D over the input volume */
 
 /* whole-call forms for a single slab (= the reference's single-GPU calls) */
 int tomo_tv(tomo_engine *e, int vol, float eps);                        /* tomoengine.cpp:439-442 tv_3D -> TOMO_S_TV */

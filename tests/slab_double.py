@@ -32,6 +32,7 @@ class OracleSlabBackend:
         self.vol = {VOL_RECON: self.t.recon}
         self.sino = {}
         self.fgp_target = VOL_RECON
+        self.tv_target = VOL_RECON
         self.scal = torch.zeros(S_COUNT, dtype=torch.float64)
         npix = nray * nray
         self.halo_lo, self.halo_hi = torch.zeros(npix), torch.zeros(npix)
@@ -58,10 +59,28 @@ class OracleSlabBackend:
 
     # ---- torch plumbing ------------------------------------------------------------------------------
     def enable_torch(self):
-        pass
+        self.tdev = "cpu"
+        npix = self.nray * self.nray
+        self.fgp_lo, self.fgp_hi = torch.zeros(npix), torch.zeros(4 * npix)
+        self.fgp_send_first, self.fgp_send_last = torch.zeros(4 * npix), torch.zeros(npix)
 
     def scalar_tensor(self, slot):
         return self.scal[slot:slot + 1]
+
+    def scalar_gather(self, slots):
+        return self.scal[list(slots)]
+
+    def tensor(self, values, dtype=None):
+        return torch.tensor(values, dtype=dtype or torch.float64)
+
+    def fgp_planes(self):
+        return self.fgp_send_first, self.fgp_send_last, self.fgp_lo, self.fgp_hi
+
+    def c_async_wait(self):
+        pass
+
+    def c_tv_set_target(self, vid):
+        self.tv_target = vid
 
     def scalars(self):
         return self.scal.numpy().copy()
@@ -72,7 +91,7 @@ class OracleSlabBackend:
 
     def tv_update_planes(self, dPOCS, clamp):
         self.c_tv_update(dPOCS, clamp)
-        return self.pack_planes(VOL_RECON)
+        return self.pack_planes(self.tv_target)
 
     def halo_tensors(self):
         return self.halo_lo, self.halo_hi
@@ -144,7 +163,7 @@ class OracleSlabBackend:
         self.scal[S_TV] = float(t.astype(np.float64).sum())
 
     def c_tv_grad(self, eps):
-        e = self._ext(self.t.recon)
+        e = self._ext(self._v(self.tv_target))
         eps = np.float32(eps)
         c, ip, im = e[1:-1], e[2:], e[:-2]
         jp = lambda v: np.roll(v, -1, 1)  # noqa: E731
@@ -166,14 +185,15 @@ class OracleSlabBackend:
         self.scal[S_GNORM] = float((self.g.astype(np.float64) ** 2).sum())
 
     def c_tv_grad_tv(self, eps):
-        self.c_tv_partial(VOL_RECON, eps)
+        self.c_tv_partial(self.tv_target, eps)
         self.c_tv_grad(eps)
 
     def c_tv_update(self, dPOCS, clamp):
         nrm = np.float32(np.sqrt(float(self.scal[S_GNORM])))
-        self.t.recon -= (np.float32(dPOCS) * self.g) / nrm
+        x = self._v(self.tv_target)
+        x -= (np.float32(dPOCS) * self.g) / nrm
         if clamp:
-            np.maximum(self.t.recon, 0, out=self.t.recon)
+            np.maximum(x, 0, out=x)
 
     def c_fgp_begin(self):
         self.fgp_target = VOL_RECON
@@ -212,6 +232,45 @@ class OracleSlabBackend:
         self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"] = a * sq, b * sq, c * sq
 
     def c_fgp_end(self, iters):
+        self._v(self.fgp_target)[:] = self.fields[FIELD_FGP_D]
+
+    # fused step form (include/tomo_hip.h: tomo_fgp_fused_*): D of the slice above is rebuilt from its A, P planes
+    def c_fgp_fused_begin(self, vid):
+        self.c_fgp_begin_vol(vid)
+        n = self.nray
+        self.fgp_send_first[:n * n] = torch.from_numpy(self._v(vid)[0].ravel().copy())
+
+    def _fgp_obj_with(self, lo_plane):
+        keep = self.halo_lo
+        self.halo_lo = lo_plane
+        self.c_fgp_obj(self._lam)
+        self.halo_lo = keep
+
+    def c_fgp_fused_step(self, lam, first_iteration):
+        n, F = self.nray, np.float32
+        self._lam = lam
+        P1, P2, P3 = self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"]
+        # D of the slab (P1 of the slice below from the lo plane; the first iteration knows P = 0 and reads no plane)
+        self._fgp_obj_with(torch.zeros_like(self.fgp_lo) if first_iteration else self.fgp_lo)
+        hi = self.fgp_hi.numpy().reshape(4, n, n)
+        a, p1, p2, p3 = hi[0], hi[1], hi[2], hi[3]
+        if first_iteration:
+            p1 = p2 = p3 = np.zeros((n, n), F)
+        v2 = np.zeros((n, n), F); v2[1:, :] = p2[:-1, :]
+        v3 = np.zeros((n, n), F); v3[:, 1:] = p3[:, :-1]
+        d_hi = np.maximum(a - F(lam) * (p1 + p2 + p3 - P1[-1] - v2 - v3), 0).astype(F)
+        keep = self.halo_hi
+        self.halo_hi = torch.from_numpy(d_hi.ravel().copy())
+        self.c_fgp_grad(lam)
+        self.halo_hi = keep
+        P1, P2, P3 = self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"]
+        sf = self.fgp_send_first.numpy().reshape(4, n, n)
+        sf[1], sf[2], sf[3] = P1[0], P2[0], P3[0]
+        self.fgp_send_last[:] = torch.from_numpy(P1[-1].ravel().copy())
+
+    def c_fgp_fused_end(self, lam):
+        self._lam = lam
+        self._fgp_obj_with(self.fgp_lo)
         self._v(self.fgp_target)[:] = self.fields[FIELD_FGP_D]
 
     # ---- generic slots + multimodal primitives (tests/test_distributed_gloo.py::test_sharded_multimodal) -----

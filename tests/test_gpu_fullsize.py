@@ -110,3 +110,48 @@ def test_tile_projectors_equal_ray_and_pixel_driven_forms(big):
         out[tile] = t.get_volume()
     t.set_option("fp_tile", 1); t.set_option("bp_tile", 1)
     assert np.array_equal(out[0], out[1])
+
+
+@pytest.fixture(scope="module", params=[(512, 512), (128, 1024)], ids=["config3_512cube", "config4_shard_128x1024sq"])
+def tvbig(request, gpu):
+    """TV / FGP never touch the projector tables: two tilts keep the engine small at the BASELINE volume sizes."""
+    nx, n = request.param
+    rng = np.random.default_rng(17)
+    x = ellipsoids(nx, n) + np.float32(0.05) * rng.random((nx, n, n), dtype=np.float32)
+    t = tomoengine(nx, n, np.deg2rad(np.array([-30.0, 40.0])))
+    return t, np.ascontiguousarray(x, dtype=np.float32)
+
+
+def test_tv_gd_three_kernel_forms_agree_at_full_size(tvbig):
+    """tv_gd(3): the register march (default) == the LDS march bit for bit (same rounding sequence by construction) and
+    == the direct-global stencil (IEEE sqrt + division per term) to 1e-6; the TV value agrees to 1e-6."""
+    t, x = tvbig
+    t.tv_eps = 1e-6
+    res = {}
+    for form in (1, 8, 0):
+        t.set_option("tv_lds", form)
+        t.set_volume(x, VOL_RECON)
+        tv0 = t.tv_gd(3, 1.0)
+        res[form] = (tv0, t.get_volume())
+    t.set_option("tv_lds", 1)
+    assert np.array_equal(res[1][1], res[8][1]) and res[1][0] == res[8][0]
+    assert rel_l2(res[1][1], res[0][1]) < 1e-6 and abs(res[1][0] - res[0][0]) <= 1e-6 * res[0][0]
+    assert res[1][1].min() >= 0 and 0 < rel_l2(res[1][1], x) < 1e-2       # a real step was taken; positivity held
+    assert t.tv() < res[1][0]                                               # and it lowered the TV
+
+
+def test_fgp_fused_equals_two_kernel_form_at_full_size(tvbig):
+    """tv_fgp(4, 0.1): one fused kernel per iteration == the Obj / Grad pair of tv_fgp.cu:244-268 (same arithmetic per
+    voxel, D never written in the fused form); the prox lowers the TV and stays non-negative."""
+    t, x = tvbig
+    res = {}
+    for fused in (1, 0):
+        t.set_option("fgp_fused", fused)
+        t.set_volume(x, VOL_RECON)
+        tv_in = t.tv_fgp(4, 0.1)
+        res[fused] = (tv_in, t.get_volume())
+    t.set_option("fgp_fused", 1)
+    assert res[1][0] == res[0][0]
+    assert np.array_equal(res[1][1], res[0][1]) or rel_l2(res[1][1], res[0][1]) < 1e-7
+    t.tv_eps = 1e-6
+    assert res[1][1].min() >= 0 and t.tv() < res[1][0]

@@ -1,0 +1,165 @@
+"""The slab-sharded TV / FGP / ASD-POCS composition on the REAL kernels: 2 and 3 (uneven) slab engines on one GPU.
+
+``tests/local_ring.py`` plays the process group (threads + device copies), so what runs is the product's own
+composition in ``tomo_tv_amd/engine.py`` -- ``tomo_tv_grad_tv`` -> all-reduce -> ``tomo_tv_update_planes`` with ring
+exchanges, the fused FGP iteration with its single exchange, the Obj / Grad pair with two -- with interior slab faces
+(``tomo_set_slab_edges(0/1)``, halo planes that are NOT the periodic wrap).  Reference semantics:
+mpi_ctvlib.cpp:400-422,502-547 (ring exchange, all-reduced gradient norm), tv_fgp.cu:57,81 (the neighbours FGP needs).
+
+Sharded == one whole-slab engine to 2e-6 and == the oracle to 1e-5 at N = 32; sharded == whole slab at
+2 x 256 x 512^2 and 2 x 64 x 1024^2 (the per-GPU shards of configs 3 and 4).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import rel_l2
+from local_ring import ThreadRing
+from tomo_tv_amd._lib import S_DD, S_DIFF2, VOL_RECON, VOL_TEMP
+from tomo_tv_amd.distributed import slab_partition
+from tomo_tv_amd.engine import tomoengine
+from tomo_tv_amd.phantom import ellipsoids
+
+pytestmark = pytest.mark.gpu
+
+
+def noisy_phantom(nx, n, seed):
+    rng = np.random.default_rng(seed)
+    x = ellipsoids(nx, n, seed=seed) + np.float32(0.05) * rng.random((nx, n, n), dtype=np.float32)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def run_sharded(world, nx, n, ang, x, script, b=None):
+    """Every rank builds its slab engine with the GLOBAL sizes, loads its part of x (and of the tilt series b) and runs
+    ``script(engine)``; returns rank 0's result."""
+    ring = ThreadRing(world)
+
+    def body(comm):
+        t = tomoengine(nx, n, ang, device=0, comm=comm)
+        assert (t.first, t.nloc) == slab_partition(nx, world, comm.rank)
+        if b is not None:
+            t.set_tilt_series(b)
+        t.set_volume(x, VOL_RECON)
+        return script(t)
+    return ring.run(body)[0]
+
+
+def tv_script(eps, fused):
+    def script(t):
+        t.tv_eps = eps
+        t.fgp_fused = fused
+        out = {"tv": t.tv()}
+        out["tv0"] = t.tv_gd(3, 0.3)
+        out["gd"] = t.get_volume()
+        out["fgp_tv"] = t.tv_fgp(4, 0.05)
+        out["fgp"] = t.get_volume()
+        out["fgp1_tv"] = t.tv_fgp(1, 0.05)                 # a single iteration takes the Obj / Grad pair
+        out["fgp1"] = t.get_volume()
+        out["tv_end"] = t.tv()
+        return out
+    return script
+
+
+@pytest.mark.parametrize("world,nx", [(2, 11), (3, 11), (3, 150), (2, 130)])
+@pytest.mark.parametrize("fused", [True, False], ids=["fgp_fused", "fgp_pair"])
+def test_sharded_tv_and_fgp_equal_whole_slab_and_oracle(gpu, world, nx, fused):
+    n = 32
+    ang = np.deg2rad(np.linspace(-60, 60, 5))
+    x = noisy_phantom(nx, n, 3)
+    eps = 1e-6
+    got = run_sharded(world, nx, n, ang, x, tv_script(eps, fused))
+    whole = tomoengine(nx, n, ang)
+    whole.set_volume(x, VOL_RECON)
+    want = tv_script(eps, fused)(whole)
+    for k in ("tv", "tv0", "fgp_tv", "fgp1_tv", "tv_end"):
+        assert abs(got[k] - want[k]) <= 2e-6 * abs(want[k]), (k, got[k], want[k])
+    for k in ("gd", "fgp", "fgp1"):
+        assert rel_l2(got[k], want[k]) < 2e-6, k
+    ref = oracle.ctvlib(nx, n, 5)
+    ref.recon[:] = x
+    ref.tv_eps = eps
+    assert abs(got["tv"] - ref.tv()) <= 1e-5 * ref.tv()
+    tv0 = ref.tv_gd(3, 0.3)
+    assert abs(got["tv0"] - tv0) <= 1e-5 * tv0 and rel_l2(got["gd"], ref.recon) < 1e-5
+    tvf = ref.tv_fgp(4, 0.05)
+    assert abs(got["fgp_tv"] - tvf) <= 1e-5 * tvf and rel_l2(got["fgp"], ref.recon) < 1e-5
+    ref.tv_fgp(1, 0.05)
+    assert rel_l2(got["fgp1"], ref.recon) < 1e-5
+
+
+def asd_script(niter):
+    """The loop of TomoGPU.asd_pocs with its batched scalar read (one all-reduce per iteration)."""
+    def script(t):
+        t.initialize_SART("sequential")
+        t.tv_eps = 1e-6
+        t.restart_recon()
+        t.copy_recon()
+        norm = float(t.Nslice_ * t.Nrow)
+        beta, dPOCS, tr = 0.25, 0.0, []
+        for i in range(niter):
+            if i == 0:
+                dp = t.SART_tracked(beta)
+                dPOCS = dp * 0.2
+            else:
+                t.SART_tracked(beta, defer=True)
+            beta *= 0.9985
+            t.data_distance_begin()
+            if i == 0:
+                tv, dg, dd2 = t.tv_gd_tracked(4, dPOCS, extra=(S_DD,))
+            else:
+                tv, dg, dd2, dp2 = t.tv_gd_tracked(4, dPOCS, extra=(S_DD, S_DIFF2))
+                dp = float(np.sqrt(dp2))
+            dd = float(np.sqrt(dd2)) / norm
+            if dg > dp * 0.95 and dd > 0.0:
+                dPOCS *= 0.95
+            tr.append((dp, dg, dd, tv))
+        return np.array(tr), t.get_volume(), t.get_volume(VOL_TEMP)
+    return script
+
+
+@pytest.mark.parametrize("world,nx", [(2, 10), (3, 70)])
+def test_sharded_asd_pocs_equals_whole_slab(gpu, world, nx):
+    n, p = 32, 7
+    ang = np.deg2rad(np.linspace(-60, 60, p))
+    x = ellipsoids(nx, n, seed=9)
+    whole = tomoengine(nx, n, ang)
+    whole.set_volume(x, 2)
+    whole.create_projections()
+    b = whole.get_projections()
+    tr_w, vol_w, tmp_w = asd_script(4)(whole)
+    tr_s, vol_s, tmp_s = run_sharded(world, nx, n, ang, np.zeros_like(x), asd_script(4), b=b)
+    assert np.allclose(tr_s, tr_w, rtol=5e-6), (tr_s, tr_w)
+    assert rel_l2(vol_s, vol_w) < 5e-6 and np.array_equal(vol_s, tmp_s)
+
+
+@pytest.mark.parametrize("world,nx,n", [(2, 512, 512), (2, 128, 1024)], ids=["2x256x512sq", "2x64x1024sq"])
+def test_sharded_tv_equals_whole_slab_at_full_size(gpu, world, nx, n):
+    """The shards of configs 3 and 4: TV descent and both FGP forms, sharded vs one slab, on real kernels.  (Two tilts
+    only: TV never touches the projector tables.)"""
+    ang = np.deg2rad(np.array([-30.0, 40.0]))
+    x = noisy_phantom(nx, n, 5)
+
+    def script(fused):
+        def run(t):
+            t.tv_eps = 1e-6
+            t.fgp_fused = fused
+            out = {"tv0": t.tv_gd(3, 1.0)}
+            out["gd"] = t.get_volume(dst=0)
+            t.set_volume(x, VOL_RECON)                     # the prox of the SAME input in both layouts
+            out["fgp_tv"] = t.tv_fgp(3, 0.1)
+            out["fgp"] = t.get_volume(dst=0)
+            return out
+        return run
+    got = run_sharded(world, nx, n, ang, x, script(True))
+    whole = tomoengine(nx, n, ang)
+    whole.set_volume(x, VOL_RECON)
+    want = script(True)(whole)
+    del whole
+    assert abs(got["tv0"] - want["tv0"]) <= 2e-6 * want["tv0"] and abs(got["fgp_tv"] - want["fgp_tv"]) <= 2e-6 * want["fgp_tv"]
+    assert rel_l2(got["gd"], want["gd"]) < 2e-6
+    # FGP has no reduction across voxels: same input -> the sharded fields are the whole-slab fields bit for bit
+    assert np.array_equal(got["fgp"], want["fgp"])
+    # the Obj / Grad pair with its two exchanges gives the same prox
+    del want["gd"]
+    got_pair = run_sharded(world, nx, n, ang, x, script(False))
+    assert rel_l2(got_pair["fgp"], want["fgp"]) < 2e-6 and rel_l2(got_pair["gd"], got["gd"]) == 0.0

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libtomo_hip.so")
 VOL_RECON, VOL_TEMP, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD = 0, 1, 2, 3, 4
 SINO_B, SINO_G, SINO_R, SINO_USER0 = 0, 1, 2, 3
 VOL_USER0 = 5
-S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 16
+S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_DIFF2, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 16
 FIELD_FGP_D, FIELD_FGP_P1 = 100, 101
 K_BP_ANGLE, K_FP_ANGLE, K_TV_GRAD, K_TV_UPDATE, K_FGP_OBJ, K_FGP_GRAD, K_SART_FUSED = 0, 1, 2, 3, 4, 5, 6
 
@@ -45,6 +45,10 @@ SIGNATURES = {
     "tomo_row_inner_product": [_p],
     "tomo_sirt_landweber": [_p, _i, _f, _i],
     "tomo_sirt": [_p, _i, _i],
+    "tomo_sirt_cimmino": [_p, _i, _f, _i],
+    "tomo_lipschitz_cimmino": [_p, ctypes.POINTER(_f)],
+    "tomo_release_geometry": [_p],
+    "tomo_adopt_volumes": [_p, _p],
     "tomo_sart": [_p, _i, _f, _i, _p],
     "tomo_art": [_p, _f],
     "tomo_art_order": [_p, _f, _p],
@@ -65,6 +69,7 @@ SIGNATURES = {
     "tomo_halo_local": [_p, _i],
     "tomo_set_slab_edges": [_p, _i, _i],
     "tomo_tv_partial": [_p, _i, _f],
+    "tomo_tv_set_target": [_p, _i],
     "tomo_tv_grad": [_p, _f],
     "tomo_tv_grad_tv": [_p, _f],
     "tomo_tv_update": [_p, _f, _i],
@@ -92,6 +97,10 @@ SIGNATURES = {
     "tomo_sino_proj_scale": [_p, _i, _p, _p],
     "tomo_fgp_begin_vol": [_p, _i],
     "tomo_tv_fgp_vol": [_p, _i, _i, _f],
+    "tomo_bind_fgp_halo": [_p, _p, _p, _p, _p],
+    "tomo_fgp_fused_begin": [_p, _i],
+    "tomo_fgp_fused_step": [_p, _f, _i],
+    "tomo_fgp_fused_end": [_p, _f],
     "tomo_get_stream": [_p, _pp],
     "tomo_mm_model": [_p, _p, _i, _p, _f, _p, _i],
     "tomo_mm_update": [_p, _p, _p, _i, _p, _f, _f, _f, _p, _i, _i],

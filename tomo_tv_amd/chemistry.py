@@ -62,6 +62,7 @@ class multimodal:
         self.he = self._engine_cls(Nslice, Nray, haadfAngles, device=device, comm=comm)
         self.ce = self._engine_cls(Nslice, Nray, chemAngles, device=device, comm=comm)
         self.ce.be.share_stream_with(self.he.be)
+        self.he._stream_peer = self.ce        # a rebuilt HAADF engine (update_projection_angles) rejoins this stream
         self.comm = comm
         self.NprojHaadf, self.NprojChem = self.he.Nproj, self.ce.Nproj
         self.NrowHaadf, self.NrowChem = self.he.Nrow, self.ce.Nrow
@@ -281,23 +282,21 @@ class multimodal:
 
     def tv_fgp_4D(self, ng, lambdaTV):
         """Per-element 3-D FGP prox; returns the summed TV of the inputs (chemistry/.../tv_fgp.cu:192-...)."""
-        tv = 0.0
-        ce = self.ce
-        for e in range(self.Nel):
-            v = int(self._x[e])
-            if ce.comm is None:
-                ce.be.c("tv_fgp_vol", v, int(ng), float(lambdaTV))
-                tv += ce._scalar(S_TV)
-            else:
-                tv += ce._tv_of(v, 1e-6)
-                ce.be.c("fgp_begin_vol", v)
-                for _ in range(int(ng)):
-                    ce._exchange(_lib.FIELD_FGP_P1)
-                    ce.be.c("fgp_obj", float(lambdaTV))
-                    ce._exchange(_lib.FIELD_FGP_D)
-                    ce.be.c("fgp_grad", float(lambdaTV))
-                ce.be.c("fgp_end", int(ng))
-        return tv
+        return sum(self.ce.tv_fgp(int(ng), float(lambdaTV), vol=int(v)) for v in self._x)
+
+    def tv_gd(self, ng, lambdaTV):
+        """``tv_gd`` of the reference's table = ``tv_gd_4D`` (multimodal.cpp:494,548): per element ``ng`` normalised TV
+        descent steps of length ``lambdaTV`` + positivity; returns the summed TV before descent
+        (chemistry/utils/regularizers/tv_gd.cu:208-296)."""
+        return sum(self.ce.tv_gd(int(ng), float(lambdaTV), vol=int(v)) for v in self._x)
+
+    def forward_projection(self, inVol):
+        """HAADF projection of ONE slice image (Ny*Nz values) -> NrowHaadf values (multimodal.cpp:180-192).  Every
+        slice shares the system matrix, so the rank-local slice 0 of a scratch volume carries it; no collective."""
+        img = _f32c(np.asarray(inVol).reshape(self.Ny, self.Nz))
+        self.he.be.c("set_slice", self.UPD, 0, _ptr(img))
+        self.he.be.c("forward_projection", self.UPD, SINO_G)
+        return self.he._sino_local(SINO_G)[0].copy()
 
     def rmse(self):
         out = np.zeros(self.Nel, np.float32)
@@ -305,6 +304,26 @@ class multimodal:
             self.ce.be.c("diff_norm_sq", int(self._x[e]), int(self._gt[e]), S_RMSE)
             out[e] = np.sqrt(self.ce._scalar(S_RMSE) / (self.Nslice_ * self.Ny * self.Nz))
         return out
+
+
+class multigpufusion(multimodal):
+    """``multigpufusion`` (chemistry/utils/multigpufusion.cpp:463-474): the slab-sharded ``multimodal`` -- construct it
+    in every rank of a ``torchrun`` job with the GLOBAL sizes.  Unlike the reference (where only ``poisson_ml`` is really
+    multi-GPU, quirk Q14, and the fusion step drops a factor, quirk Q12) every method runs on the slabs."""
+
+    def __init__(self, Nslice, Nray, Nelements, haadfAngles, chemAngles, group=None):
+        from .distributed import SlabComm
+        super().__init__(Nslice, Nray, Nelements, haadfAngles, chemAngles, device=None, comm=SlabComm(group))
+
+    def get_gpu_ids(self):
+        return self.comm.all_gather_ints(self.ce.gpuID)
+
+    def is_multi_gpu_enabled(self):
+        return self.comm.world > 1
+
+    def print_gpu_usage(self):
+        if self.comm.rank == 0:
+            print(f"{self.comm.world} ranks, one GPU each; slab of rank 0: {self.ce.nloc} of {self.Nslice_} slices")
 
 
 class ChemicalTomo:
@@ -315,7 +334,7 @@ class ChemicalTomo:
         self.elements = list(chem)
         self.nz = len(chem)
         self.tomo = multimodal(self.nx, self.ny, self.nz, np.deg2rad(haadfTiltAngles), np.deg2rad(chemTiltAngles),
-                               device=max(gpu_id, 0), comm=comm)
+                               device=(None if gpu_id < 0 else gpu_id), comm=comm)   # None: the rank's current device
         self.NprojHAADF, self.NprojCHEM = len(haadfTiltAngles), len(chemTiltAngles)
         self.set_haadf_projections(haadf)
         self.set_chemical_projections(chem)

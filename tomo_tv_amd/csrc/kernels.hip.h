@@ -147,7 +147,8 @@ __device__ __forceinline__ void ray_block_map(int bid, int nb, int nrows, int &c
 // ---- forward projector: ray-driven, one workgroup per (ray, slice chunk) ---------------------------
 // g[row][s] = sum_k w_k * x[col_k][s].  The four waves of a workgroup split the ray's entry list; lanes hold
 // VEC consecutive slices each.  Entry (col, w) pairs are wave-uniform: fetched by the scalar unit.
-enum { FP_STORE = 0, FP_RESID = 1, FP_RESID_NORM = 2, FP_DD = 3, FP_POISSON = 4 };
+// FP_RESID_MUL: r = (b - Ax) * m[row] with m passed in the rowsum argument (Cimmino weights, ctvlib.cpp:215)
+enum { FP_STORE = 0, FP_RESID = 1, FP_RESID_NORM = 2, FP_DD = 3, FP_POISSON = 4, FP_RESID_MUL = 5 };
 
 template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void k_fp_rows(const float *__restrict__ x, const uint32_t *__restrict__ rptr,
@@ -191,6 +192,8 @@ __global__ __launch_bounds__(256) void k_fp_rows(const float *__restrict__ x, co
             } else if (MODE == FP_RESID_NORM) {
                 float rs = rowsum[row];
                 r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
+            } else if (MODE == FP_RESID_MUL) {
+                r = (bv - acc) * rowsum[row];
             } else if (MODE == FP_DD) {
                 r = acc;
 #pragma unroll
@@ -276,6 +279,8 @@ __global__ __launch_bounds__(256) void k_fp_rows_g(const float *__restrict__ x, 
             } else if (MODE == FP_RESID_NORM) {
                 float rs = rowsum[row];
                 r = rs > 0.f ? (bv - acc) / rs : vzero<4>();
+            } else if (MODE == FP_RESID_MUL) {
+                r = (bv - acc) * rowsum[row];
             } else if (MODE == FP_DD) {
                 r = acc;
 #pragma unroll
@@ -431,6 +436,8 @@ __global__ __launch_bounds__(256) void k_fp_tile_reduce(const float *__restrict_
             } else if (MODE == FP_RESID_NORM) {
                 float rs = rowsum[row];
                 r = rs > 0.f ? (bv - acc) / rs : vzero<4>();
+            } else if (MODE == FP_RESID_MUL) {
+                r = (bv - acc) * rowsum[row];
             } else if (MODE == FP_DD) {
                 r = acc;
 #pragma unroll
@@ -1686,11 +1693,19 @@ __global__ __launch_bounds__(256) void k_fgp_grad(const float *__restrict__ D, f
 // rebuilds D for the pixel rows y and y+1 in LDS and writes P_new (12 B): 28 B/voxel.  P is ping-ponged because a
 // neighbouring workgroup still needs the old values of this workgroup's border voxels.  Boundaries are the
 // reference's: lower neighbours of the first slice/row/column and upper differences at the last are zero.
+// Slab-sharded use (FgpEdge): an interior slab face is not a boundary.  D of the neighbour's first slice (needed by the
+// slice difference of this slab's last slice) is rebuilt here from that slice's A, P1, P2, P3 planes (hi, 4 planes) and
+// this slab's own last P1; D of this slab's first slice takes P1 of the neighbour's last slice (p1_lo).  The pass also
+// leaves P_new of its first slice (planes 1..3 of send_first; plane 0 = A's first slice, packed once per call) and P1_new
+// of its last slice (send_last): exactly what the ring exchange before the next iteration sends -- one exchange per
+// iteration instead of the two of the Obj / Grad pair (tv_fgp.cu:57,81; mpi_ctvlib.cpp:400-422).
+struct FgpEdge { const float *p1_lo; const float *hi; float *send_first; float *send_last; int first, last; };
+
 __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, const float *__restrict__ P1i,
                                                     const float *__restrict__ P2i, const float *__restrict__ P3i,
                                                     float *__restrict__ P1o, float *__restrict__ P2o,
                                                     float *__restrict__ P3o, float lambda, float multip, int n, int nx,
-                                                    int sx, int yseg, int zero_p)
+                                                    int sx, int yseg, int zero_p, FgpEdge ed)
 {
     // zero_p: first iteration of a call, P = 0 is known and neither zero-filled beforehand nor read here
     __shared__ float pl[3][2][TVL_TZ + 2][TVL_PITCH];     // P1,P2,P3 planes (parity ring); row zi = column z0-1+zi
@@ -1701,9 +1716,13 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
     const int bz = blockIdx.x % nzb, bs = blockIdx.x / nzb;
     const int y0 = blockIdx.y * yseg, y1 = min(y0 + yseg, n);
     const int z0 = bz * TVL_TZ, s0 = bs * 64;
-    auto ld = [&](const float *__restrict__ f, int y, int zi, int si) -> float {
+    const size_t npix = (size_t)n * n;
+    // fid: 0 = A, 1..3 = P1..P3 (the plane order of the hi / send_first buffers)
+    auto ld = [&](const float *__restrict__ f, int fid, int y, int zi, int si) -> float {
         int z = z0 - 1 + zi, s = s0 - 1 + si;
-        if (y < 0 || y >= n || z < 0 || z >= n || s < 0 || s >= nx) return 0.f;
+        if (y < 0 || y >= n || z < 0 || z >= n) return 0.f;
+        if (s < 0) return (fid == 1 && !ed.first && s == -1) ? ed.p1_lo[y * n + z] : 0.f;
+        if (s >= nx) return (!ed.last && s == nx) ? ed.hi[fid * npix + y * n + z] : 0.f;
         return f[(size_t)(y * n + z) * sx + s];
     };
     // a pixel row (A and the three P fields, with halo) travels global -> registers -> LDS; the fetch of row
@@ -1715,15 +1734,15 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
             int r = wave + 4 * t;
             bool ok = r < TVL_TZ + 2;
             const bool okp = ok && !zero_p;
-            rg[0][t] = okp ? ld(P1i, y, r, lane + 1) : 0.f;
-            rg[1][t] = okp ? ld(P2i, y, r, lane + 1) : 0.f;
-            rg[2][t] = okp ? ld(P3i, y, r, lane + 1) : 0.f;
-            rg[3][t] = ok ? ld(A, y, r, lane + 1) : 0.f;
+            rg[0][t] = okp ? ld(P1i, 1, y, r, lane + 1) : 0.f;
+            rg[1][t] = okp ? ld(P2i, 2, y, r, lane + 1) : 0.f;
+            rg[2][t] = okp ? ld(P3i, 3, y, r, lane + 1) : 0.f;
+            rg[3][t] = ok ? ld(A, 0, y, r, lane + 1) : 0.f;
         }
         if (wave == 3 && lane < 2 * (TVL_TZ + 2)) {
             int r = lane >> 1, si = (lane & 1) ? 65 : 0;
-            rh[0] = zero_p ? 0.f : ld(P1i, y, r, si); rh[1] = zero_p ? 0.f : ld(P2i, y, r, si);
-            rh[2] = zero_p ? 0.f : ld(P3i, y, r, si); rh[3] = ld(A, y, r, si);
+            rh[0] = zero_p ? 0.f : ld(P1i, 1, y, r, si); rh[1] = zero_p ? 0.f : ld(P2i, 2, y, r, si);
+            rh[2] = zero_p ? 0.f : ld(P3i, 3, y, r, si); rh[3] = ld(A, 0, y, r, si);
         }
     };
     auto stash = [&](int par) {
@@ -1778,7 +1797,7 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
             int z = z0 + zq, s = s0 + sq;
             if (z < n && s < nx) {
                 float dc = dl[par][zq][sq];
-                float v1 = s + 1 < nx ? dc - dl[par][zq][sq + 1] : 0.f;
+                float v1 = (s + 1 < nx || !ed.last) ? dc - dl[par][zq][sq + 1] : 0.f;
                 float v2 = y + 1 < n ? dc - dl[nxt][zq][sq] : 0.f;
                 float v3 = z + 1 < n ? dc - dl[par][zq + 1][sq] : 0.f;
                 float a = keep[q][0] + multip * v1, b = keep[q][1] + multip * v2, c = keep[q][2] + multip * v3;
@@ -1789,6 +1808,11 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
                 }
                 size_t o = (size_t)(y * n + z) * sx + s;
                 P1o[o] = a; P2o[o] = b; P3o[o] = c;
+                if (ed.send_first) {
+                    const size_t pix = (size_t)y * n + z;
+                    if (s == 0) { ed.send_first[npix + pix] = a; ed.send_first[2 * npix + pix] = b; ed.send_first[3 * npix + pix] = c; }
+                    if (s == nx - 1) ed.send_last[pix] = a;
+                }
             }
         }
         __syncthreads();

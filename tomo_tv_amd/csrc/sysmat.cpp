@@ -198,7 +198,7 @@ void sort_rows(Coo &m)
 //   rowsum[r] = A_r . 1, rowinner[r] = A_r . A_r            (ascending column)
 //   cell[i][p] = up to two (ray-of-angle-i, weight) pairs through pixel p, ascending ray
 //   colsum_all[p] = sum_r A[r,p]                            (ascending row)
-//   lipschitz = max_p (A^T (A 1))_p                          (ctvlib.cpp:194-202)
+//   lipschitz = max_p (A^T (A 1))_p, lipschitz_cimmino = max_p (A^T M (A 1))_p   (ctvlib.cpp:194-202)
 bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err)
 {
     const int64_t npix = (int64_t)N * N;
@@ -211,7 +211,7 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err)
     }
     t.cell.assign((size_t)P * npix, Cell{0u, 0.f, 0u, 0.f});
     t.colsum_all.assign(npix, 0.f);
-    std::vector<float> ata1(npix, 0.f);
+    std::vector<float> ata1(npix, 0.f), atma1(npix, 0.f);
     for (int64_t r = 0; r < m.nrow; ++r) {
         int i = (int)(r / N);
         uint32_t j = (uint32_t)(r % N);
@@ -220,6 +220,7 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err)
             float w = m.val[k];
             t.colsum_all[p] += w;
             ata1[p] += w * t.rowsum[r];
+            atma1[p] += (w * t.rowinner[r]) * t.rowsum[r];   // (A^T M)(A 1), M = diag(|A_i|^2): ctvlib.cpp:198-199
             if (w == 0.f) continue;  // a zero weight carries nothing into a voxel update
             Cell &c = t.cell[(size_t)i * npix + p];
             if (c.w0 == 0.f) { c.r0 = j; c.w0 = w; }
@@ -231,9 +232,10 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err)
             }
         }
     }
-    float L = 0.f;
-    for (int64_t p = 0; p < npix; ++p) L = std::max(L, ata1[p]);
+    float L = 0.f, Lm = 0.f;
+    for (int64_t p = 0; p < npix; ++p) { L = std::max(L, ata1[p]); Lm = std::max(Lm, atma1[p]); }
     t.lipschitz = L;
+    t.lipschitz_cimmino = Lm;
     // inner products of neighbouring rays (fp64 accumulation, ascending pixel) and the neighbour property
     t.rowcross.assign(m.nrow, 0.f);
     t.art_chain_ok = true;

@@ -25,7 +25,7 @@ struct Tables {
     std::vector<float> rowcross;
     bool art_chain_ok = false;
     std::vector<Cell> cell;  // [P][N*N]
-    float lipschitz = 0.f;
+    float lipschitz = 0.f, lipschitz_cimmino = 0.f;
     // "walk" lists for the fused SART step: per ray, its matrix entries plus a share of the angle's
     // un-crossed pixels, so that the rays of one angle visit EVERY pixel and exactly one visit owns it.
     // entry = {pixel | owner << 31, weight bits}

@@ -27,14 +27,14 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(TOMO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));                 \
     } while (0)
 #define LAUNCHCHK() HIPCHK(hipGetLastError())
-#define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); HIPCHK(hipSetDevice((e)->device)); } while (0)
+#define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); if ((e)->geometry_released) return fail(TOMO_ERR_STATE, "engine geometry was released"); HIPCHK(hipSetDevice((e)->device)); } while (0)
 
-enum { PROF_MAX_KERNELS = 8, PROF_MAX_EVENTS = 8192 };
+enum { PROF_MAX_KERNELS = 8, PROF_MAX_EVENTS = 1 << 19 };   // 262144 launches per kernel id between two reads
 
 struct ProfSlot {
     bool on = false;
     std::vector<hipEvent_t> ev;  // pairs
-    size_t used = 0;
+    size_t used = 0, dropped = 0;   // dropped: launches that could not be recorded (tomo_profile_read reports them)
 };
 
 struct tomo_engine {
@@ -51,7 +51,7 @@ struct tomo_engine {
     CellD *d_cell = nullptr;
     uint32_t *d_wptr = nullptr;                   // walk lists of the fused SART step
     uint2 *d_went = nullptr;
-    float lipschitz = 0.f;
+    float lipschitz = 0.f, lipschitz_cimmino = 0.f;
     int sart_fused = 1;                      // 1: SART sweep as a chain of fused BP+FP steps; 0: separate FP and BP per angle
     int tv_lds = 1, fp_all_lpr = 16;
     // fp_all_lpr: all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
@@ -86,6 +86,7 @@ struct tomo_engine {
     float *vol[TOMO_VOL_SLOTS] = {};
     float *sino[TOMO_SINO_SLOTS] = {};
     int fgp_target = TOMO_VOL_RECON;
+    int tv_target = TOMO_VOL_RECON;               // volume the tv_gd / tv_grad / tv_update forms act on (tomo_tv_set_target)
     float *cur_b = nullptr;
     float *cg_p = nullptr, *cg_z = nullptr, *cg_w = nullptr, *fbp_h = nullptr;   // CGLS direction / A^T r / A p; WBP kernel
     double *cg_sums = nullptr;                    // 2*sx per-slice sums
@@ -101,8 +102,11 @@ struct tomo_engine {
     hipStream_t aux = nullptr;                    // second stream for work that is independent of the main sequence
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool async_pending = false;
+    bool geometry_released = false;               // tomo_release_geometry: only tomo_adopt_volumes / tomo_destroy remain valid
     // halos
     float *halo_lo = nullptr, *halo_hi = nullptr, *halo_lo_own = nullptr, *halo_hi_own = nullptr;
+    // planes of the fused slab-sharded FGP iteration (caller-owned device buffers, tomo_bind_fgp_halo)
+    float *fgp_lo = nullptr, *fgp_hi = nullptr, *fgp_send_first = nullptr, *fgp_send_last = nullptr;
     int is_first = 1, is_last = 1;
     ProfSlot prof[PROF_MAX_KERNELS];
     size_t vol_elems() const { return (size_t)npix * sx; }
@@ -153,6 +157,14 @@ static int get_scratch(tomo_engine *e, float **slot, float **out)
     return TOMO_OK;
 }
 
+// A write to a volume or to the re-projection G on the main stream must not overtake an evaluation still reading them
+// on the second stream (tomo_data_distance_sq_async): order the main stream behind it.  No-op when nothing is pending.
+static int order_after_async(tomo_engine *e)
+{
+    if (e->async_pending) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    return TOMO_OK;
+}
+
 static int ensure_stage(tomo_engine *e, size_t bytes)
 {
     if (e->stage_bytes >= bytes) return TOMO_OK;
@@ -170,9 +182,9 @@ struct ProfScope {
         ProfSlot &p = e->prof[k];
         if (!p.on) return;
         if (p.used + 2 > p.ev.size()) {
-            if (p.ev.size() >= PROF_MAX_EVENTS) return;
+            if (p.ev.size() >= PROF_MAX_EVENTS) { ++p.dropped; return; }
             hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ++p.dropped; return; }
             p.ev.push_back(a); p.ev.push_back(b);
         }
         (void)hipEventRecord(p.ev[p.used], e->stream);
@@ -409,6 +421,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
     e->nnz = m.ptr[m.nrow];
     if (e->nnz >= (int64_t)0xFFFFFFFFu) return fail(TOMO_ERR_ARG, "matrix too large for 32-bit entry offsets");
     e->lipschitz = t.lipschitz;
+    e->lipschitz_cimmino = t.lipschitz_cimmino;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
@@ -610,20 +623,64 @@ int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const 
     return finish_create(e, m, out);
 }
 
+// every device buffer that depends on the tilt geometry (tables, sinograms, scratch sized by it); volumes stay
+static void free_geometry(tomo_engine *e)
+{
+    void **ptrs[] = {(void **)&e->d_st_cell, (void **)&e->d_st_win, (void **)&e->d_st_segid, (void **)&e->d_st_seg, (void **)&e->d_st_ent,
+                     (void **)&e->d_st_row_first, (void **)&e->d_st_row_nseg, (void **)&e->st_partial, (void **)&e->d_fb_cell, (void **)&e->d_fb_win,
+                     (void **)&e->d_ft_slot_ptr, (void **)&e->d_ft_slot_seg0, (void **)&e->d_ft_tent, (void **)&e->d_ft_rsptr, (void **)&e->d_ft_rsidx,
+                     (void **)&e->ft_part, (void **)&e->ft_part_aux, (void **)&e->cg_w, (void **)&e->fbp_h, (void **)&e->d_seg_exec,
+                     (void **)&e->d_row_first, (void **)&e->d_row_nseg, (void **)&e->seg_partial, (void **)&e->d_wptr, (void **)&e->d_went,
+                     (void **)&e->d_rptr, (void **)&e->d_rent, (void **)&e->d_rowsum, (void **)&e->d_rowinner, (void **)&e->d_colsum_all,
+                     (void **)&e->d_rowcross, (void **)&e->d_cell};
+    for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
+    e->geometry_released = true;
+}
+
 int tomo_destroy(tomo_engine *e)
 {
     if (!e) return TOMO_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
-    void *ptrs[] = {e->d_st_cell, e->d_st_win, e->d_st_segid, e->d_st_seg, e->d_st_ent, e->d_st_row_first, e->d_st_row_nseg, e->st_partial, e->d_fb_cell, e->d_fb_win, e->d_ft_slot_ptr, e->d_ft_slot_seg0, e->d_ft_tent, e->d_ft_rsptr, e->d_ft_rsidx, e->ft_part, e->ft_part_aux, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_w, e->fbp_h, e->cg_sums, e->cg_coef, e->d_seg_exec, e->d_row_first, e->d_row_nseg, e->seg_partial, e->d_wptr, e->d_went, e->sart_alt, e->d_rptr, e->d_rent, e->d_rowsum, e->d_rowinner, e->d_colsum_all, e->d_rowcross, e->d_cell, e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part,
-                    e->halo_lo_own, e->halo_hi_own};
+    free_geometry(e);
+    void *ptrs[] = {e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_coef, e->sart_alt,
+                    e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
-    for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) (void)hipFree(e->sino[i]);
     for (auto &p : e->prof) for (auto ev : p.ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+    return TOMO_OK;
+}
+
+// Rebuilding the tilt geometry with the reconstruction kept (tomoengine::update_projection_angles, tomoengine.cpp:128-149;
+// ctvlib::update_proj_angles, ctvlib.cpp:317-333): release the old engine's tables and sinograms, create the new engine,
+// let it adopt the old engine's volumes (pointers move, nothing is copied), destroy the old engine.
+int tomo_release_geometry(tomo_engine *e)
+{
+    NEED(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->aux) HIPCHK(hipStreamSynchronize(e->aux));
+    e->async_pending = false;
+    free_geometry(e);
+    return TOMO_OK;
+}
+
+int tomo_adopt_volumes(tomo_engine *dst, tomo_engine *src)
+{
+    if (!dst || !src) return fail(TOMO_ERR_ARG, "null engine");
+    if (dst->nx != src->nx || dst->n != src->n || dst->sx != src->sx || dst->device != src->device) return fail(TOMO_ERR_ARG, "engines differ in slab shape or device");
+    HIPCHK(hipSetDevice(dst->device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    for (int i = 0; i < TOMO_VOL_SLOTS; ++i) {
+        if (!src->vol[i]) continue;
+        if (dst->vol[i]) HIPCHK(hipFree(dst->vol[i]));
+        dst->vol[i] = src->vol[i];
+        src->vol[i] = nullptr;
+    }
     return TOMO_OK;
 }
 
@@ -698,6 +755,7 @@ int tomo_get_sinogram(tomo_engine *e, int which, float *out)
 int tomo_set_volume(tomo_engine *e, int vol, const float *data)
 {
     NEED(e);
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *dst; int rc = get_vol(e, vol, &dst); if (rc) return rc;
     if (!data) return fail(TOMO_ERR_ARG, "null volume");
     return upload(e, data, dst, e->npix);
@@ -714,6 +772,7 @@ int tomo_get_volume(tomo_engine *e, int vol, float *data)
 int tomo_set_slice(tomo_engine *e, int vol, int s, const float *img)
 {
     NEED(e);
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *dst; int rc = get_vol(e, vol, &dst); if (rc) return rc;
     if (s < 0 || s >= e->nx || !img) return fail(TOMO_ERR_ARG, "slice index out of range");
     if ((rc = ensure_stage(e, e->npix * sizeof(float)))) return rc;
@@ -740,6 +799,7 @@ int tomo_get_slice(tomo_engine *e, int vol, int s, float *img)
 int tomo_restart_recon(tomo_engine *e)
 {
     NEED(e);
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_RECON], 0, e->vol_elems() * sizeof(float), e->stream));
     if (e->vol[TOMO_VOL_YK]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_YK], 0, e->vol_elems() * sizeof(float), e->stream));
     if (e->vol[TOMO_VOL_RECON_OLD]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_RECON_OLD], 0, e->vol_elems() * sizeof(float), e->stream));
@@ -749,6 +809,7 @@ int tomo_restart_recon(tomo_engine *e)
 int tomo_copy_volume(tomo_engine *e, int dst, int src)
 {
     NEED(e);
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *d, *s; int rc;
     if ((rc = get_vol(e, dst, &d)) || (rc = get_vol(e, src, &s))) return rc;
     if (d != s) HIPCHK(hipMemcpyAsync(d, s, e->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -759,6 +820,7 @@ int tomo_copy_volume(tomo_engine *e, int dst, int src)
 int tomo_forward_projection(tomo_engine *e, int vol, int sino)
 {
     NEED(e);
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *x, *g; int rc;
     if ((rc = get_vol(e, vol, &x))) return rc;
     if ((rc = sino_slot(e, sino, &g))) return rc;
@@ -775,6 +837,7 @@ int tomo_back_projection(tomo_engine *e, int sino, int vol)
 }
 
 int tomo_lipschitz(tomo_engine *e, float *L) { if (!e || !L) return fail(TOMO_ERR_ARG, "null"); *L = e->lipschitz; return TOMO_OK; }
+int tomo_lipschitz_cimmino(tomo_engine *e, float *L) { if (!e || !L) return fail(TOMO_ERR_ARG, "null"); *L = e->lipschitz_cimmino; return TOMO_OK; }
 int tomo_row_inner_product(tomo_engine *e) { if (!e) return fail(TOMO_ERR_ARG, "null engine"); return TOMO_OK; /* built with the tables */ }
 
 // ---- reconstruction steps -----------------------------------------------------------------------------------------
@@ -786,6 +849,24 @@ int tomo_sirt_landweber(tomo_engine *e, int vol, float beta, int niter)
     for (int it = 0; it < niter; ++it) {
         if ((rc = launch_fp_all<FP_RESID>(e, x, e->sino[TOMO_SINO_B], r))) return rc;
         if ((rc = launch_bp_all(e, x, r, nullptr, 1.f, beta, 1))) return rc;
+    }
+    return TOMO_OK;
+}
+
+// ctvlib::SIRT(beta) with cimminos_method() active: x += A^T M (b - A x) * beta/Nrow, M = diag(|A_i|^2) (sic: the
+// reference multiplies by the row norms, quirk Q10), then positivity   ctvlib.cpp:212-216, 245-251
+int tomo_sirt_cimmino(tomo_engine *e, int vol, float beta, int niter)
+{
+    NEED(e);
+    float *x, *r; int rc;
+    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r))) return rc;
+    const float *rs = e->d_rowsum;
+    for (int it = 0; it < niter; ++it) {
+        e->d_rowsum = e->d_rowinner;                     // the FP epilogue reads its per-row factor from this argument
+        rc = launch_fp_all<FP_RESID_MUL>(e, x, e->sino[TOMO_SINO_B], r);
+        e->d_rowsum = const_cast<float *>(rs);
+        if (rc) return rc;
+        if ((rc = launch_bp_all(e, x, r, nullptr, 1.f, beta / (float)e->nrows, 1))) return rc;
     }
     return TOMO_OK;
 }
@@ -1035,6 +1116,7 @@ int tomo_fbp(tomo_engine *e, const float *taps_host, float scale, int apply_posi
 int tomo_scale_volume(tomo_engine *e, int vol, float factor)
 {
     NEED(e);
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
     int64_t n4 = e->vol_elems() / 4;
     hipLaunchKernelGGL(k_scale, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, factor, n4);
@@ -1149,6 +1231,7 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
 int tomo_positivity(tomo_engine *e, int vol)
 {
     NEED(e);
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
     int64_t n4 = e->vol_elems() / 4;
     hipLaunchKernelGGL(k_clamp, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, n4);
@@ -1361,7 +1444,8 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
 static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
 {
     NEED(e);
-    float *x = e->vol[TOMO_VOL_RECON], *g; int rc;
+    float *x, *g; int rc;
+    if ((rc = get_vol(e, e->tv_target, &x))) return rc;
     if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     Halo h{e->halo_lo, e->halo_hi};
@@ -1400,11 +1484,21 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
     return reduce_end(e, TOMO_S_GNORM);
 }
 
+int tomo_tv_set_target(tomo_engine *e, int vol)
+{
+    NEED(e);
+    float *x;
+    int rc = get_vol(e, vol, &x);
+    if (rc) return rc;
+    e->tv_target = vol;
+    return TOMO_OK;
+}
+
 int tomo_tv_grad(tomo_engine *e, float eps) { return tv_grad_impl(e, eps, false); }
 int tomo_tv_grad_tv(tomo_engine *e, float eps)
 {
     if (e && e->tv_lds != 8 && e->tv_lds != 1) {   // kernels without the folded value: a separate pass
-        int rc = tomo_tv_partial(e, TOMO_VOL_RECON, eps);
+        int rc = tomo_tv_partial(e, e->tv_target, eps);
         return rc ? rc : tv_grad_impl(e, eps, false);
     }
     return tv_grad_impl(e, eps, true);
@@ -1416,15 +1510,16 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
                           float *plane_last = nullptr, float *plane_first = nullptr)
 {
     NEED(e);
-    float *x = e->vol[TOMO_VOL_RECON], *g, *track = nullptr; int rc;
+    float *x, *g, *track = nullptr; int rc;
+    if ((rc = get_vol(e, e->tv_target, &x))) return rc;
     if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
     if (track_vol >= 0) {
-        if (track_vol == TOMO_VOL_RECON) return fail(TOMO_ERR_ARG, "the tracked volume must differ from the reconstruction");
+        if (track_vol == e->tv_target) return fail(TOMO_ERR_ARG, "the tracked volume must differ from the one descended");
         if (slot < 0 || slot >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
         if ((rc = get_vol(e, track_vol, &track))) return rc;
         // an evaluation in flight on the second stream may still read the tracked volume (ASD-POCS: the data distance
         // of the snapshot): order this write behind it on the device; tomo_async_wait later is still valid
-        if (e->async_pending) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        if ((rc = order_after_async(e))) return rc;
         if ((rc = reduce_begin(e))) return rc;
     }
     int64_t n4 = e->vol_elems() / 4;
@@ -1512,20 +1607,21 @@ int tomo_tv(tomo_engine *e, int vol, float eps)
 static int tv_gd_impl(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot)
 {
     int rc;
+    if (!e) return fail(TOMO_ERR_ARG, "null engine");
     // the TV value before descent comes out of the first gradient pass (its denominators are the TV integrand)
     const bool fold_tv = ng > 0 && e && (e->tv_lds == 8 || e->tv_lds == 1);
-    if (fold_tv) { if ((rc = tomo_halo_local(e, TOMO_VOL_RECON))) return rc; }
-    else if ((rc = tomo_tv(e, TOMO_VOL_RECON, eps))) return rc;
+    if (fold_tv) { if ((rc = tomo_halo_local(e, e->tv_target))) return rc; }
+    else if ((rc = tomo_tv(e, e->tv_target, eps))) return rc;
     for (int g = 0; g < ng; ++g) {
         // single slab: every descent step but the last also writes the wrapped halo planes of its result
         if ((rc = tv_grad_impl(e, eps, fold_tv && g == 0))) return rc;
         if ((rc = tv_update_impl(e, dPOCS, g == ng - 1, g == ng - 1 ? track_vol : -1, slot, g < ng - 1))) return rc;
     }
     if (ng <= 0) {
-        if ((rc = tomo_positivity(e, TOMO_VOL_RECON))) return rc;
+        if ((rc = tomo_positivity(e, e->tv_target))) return rc;
         if (track_vol >= 0) {
-            if ((rc = tomo_diff_norm_sq(e, TOMO_VOL_RECON, track_vol, slot))) return rc;
-            return tomo_copy_volume(e, track_vol, TOMO_VOL_RECON);
+            if ((rc = tomo_diff_norm_sq(e, e->tv_target, track_vol, slot))) return rc;
+            return tomo_copy_volume(e, track_vol, e->tv_target);
         }
     }
     return TOMO_OK;
@@ -1541,43 +1637,86 @@ int tomo_tv_gd_tracked(tomo_engine *e, int ng, float dPOCS, float eps, int track
 
 int tomo_tv_fgp(tomo_engine *e, int iters, float lambda) { return tomo_tv_fgp_vol(e, TOMO_VOL_RECON, iters, lambda); }
 
+// ---- fused FGP iteration, step form (single slab and slab-sharded) ------------------------------------------------------
+int tomo_bind_fgp_halo(tomo_engine *e, void *lo, void *hi, void *send_first, void *send_last)
+{
+    NEED(e);
+    if (!lo || !hi || !send_first || !send_last) return fail(TOMO_ERR_ARG, "null plane buffer");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->fgp_lo = (float *)lo; e->fgp_hi = (float *)hi; e->fgp_send_first = (float *)send_first; e->fgp_send_last = (float *)send_last;
+    return TOMO_OK;
+}
+
+// sharded: slab faces that are not global edges read / write the bound planes
+static bool fgp_sharded(const tomo_engine *e) { return !(e->is_first && e->is_last); }
+
+int tomo_fgp_fused_begin(tomo_engine *e, int vol)
+{
+    int rc;
+    if ((rc = fgp_begin_impl(e, vol, false))) return rc;     // the first iteration takes P = 0 as known
+    float *q;
+    for (int i = 0; i < 3; ++i) if ((rc = get_scratch(e, &e->fgp_q[i], &q))) return rc;
+    if (fgp_sharded(e)) {
+        if (!e->fgp_lo) return fail(TOMO_ERR_STATE, "slab-sharded fused FGP needs tomo_bind_fgp_halo");
+        // plane 0 of send_first: the first slice of the prox input (constant over the call)
+        hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, e->vol[vol], e->fgp_send_first, (int)e->npix, e->sx, 0);
+        LAUNCHCHK();
+    }
+    return TOMO_OK;
+}
+
+int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration)
+{
+    NEED(e);
+    if (!e->fgp_q[2] || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
+    const int yseg = 32;
+    const int nzb = (e->n + TVL_TZ - 1) / TVL_TZ;
+    dim3 grid((unsigned)(nzb * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+    const float multip = 1.0f / (26.0f * lambda);
+    FgpEdge ed{};
+    ed.first = e->is_first; ed.last = e->is_last;
+    if (fgp_sharded(e)) { ed.p1_lo = e->fgp_lo; ed.hi = e->fgp_hi; ed.send_first = e->fgp_send_first; ed.send_last = e->fgp_send_last; }
+    {
+        ProfScope ps(e, TOMO_K_FGP_GRAD);
+        hipLaunchKernelGGL(k_fgp_fused, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0, ed);
+    }
+    LAUNCHCHK();
+    for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
+    return TOMO_OK;
+}
+
+// the last iteration only needs D (tv_fgp.cu:272), written straight over the target volume
+int tomo_fgp_fused_end(tomo_engine *e, float lambda)
+{
+    NEED(e);
+    if (!e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
+    ProfScope ps(e, TOMO_K_FGP_OBJ);
+    float *a = e->vol[e->fgp_target];
+    hipLaunchKernelGGL(k_fgp_obj, dim3(tv_grid(e)), dim3(256), 0, e->stream, a, a, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                       fgp_sharded(e) ? e->fgp_lo : e->halo_lo, e->is_first, lambda, e->n, e->nx, e->sx);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
 int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
 {
     int rc;
     if ((rc = tomo_tv(e, vol, 1e-6f))) return rc;    // tv_fgp.cu:170-189,231-238
     const bool fused = e && e->fgp_fused && iters > 1;
-    if ((rc = fgp_begin_impl(e, vol, !fused))) return rc;    // the fused form's first iteration takes P = 0 as known
     int f = e->is_first, l = e->is_last;
     e->is_first = e->is_last = 1;
     if (fused) {
-        // iterations 0..iters-2: one fused kernel each (D stays on chip); the last iteration only needs D (tv_fgp.cu:272)
-        float *q;
-        for (int i = 0; i < 3 && !rc; ++i) rc = get_scratch(e, &e->fgp_q[i], &q);
-        int yseg = 32;
-        int nzb = (e->n + TVL_TZ - 1) / TVL_TZ;
-        dim3 grid((unsigned)(nzb * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
-        float multip = 1.0f / (26.0f * lambda);
-        for (int i = 0; i + 1 < iters && !rc; ++i) {
-            {
-                ProfScope ps(e, TOMO_K_FGP_GRAD);
-                hipLaunchKernelGGL(k_fgp_fused, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
-                                   e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, i == 0 ? 1 : 0);
-            }
-            if (hipGetLastError() != hipSuccess) rc = fail(TOMO_ERR_HIP, "k_fgp_fused launch failed");
-            for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
-        }
-        if (!rc) {   // the last iteration only needs D (tv_fgp.cu:272), written straight over the target volume
-            ProfScope ps(e, TOMO_K_FGP_OBJ);
-            float *a = e->vol[e->fgp_target];
-            hipLaunchKernelGGL(k_fgp_obj, dim3(tv_grid(e)), dim3(256), 0, e->stream, a, a, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->halo_lo, e->is_first, lambda, e->n, e->nx, e->sx);
-            if (hipGetLastError() != hipSuccess) rc = fail(TOMO_ERR_HIP, "k_fgp_obj launch failed");
-        }
+        // iterations 0..iters-2: one fused kernel each (D stays on chip); the last iteration only needs D
+        rc = tomo_fgp_fused_begin(e, vol);
+        for (int i = 0; i + 1 < iters && !rc; ++i) rc = tomo_fgp_fused_step(e, lambda, i == 0);
+        if (!rc) rc = tomo_fgp_fused_end(e, lambda);
         e->is_first = f; e->is_last = l;
         return rc;
-    } else {
-        for (int i = 0; i < iters; ++i) {
-            if ((rc = tomo_fgp_obj(e, lambda)) || (rc = tomo_fgp_grad(e, lambda))) break;
-        }
+    }
+    rc = fgp_begin_impl(e, vol, true);
+    for (int i = 0; i < iters && !rc; ++i) {
+        if ((rc = tomo_fgp_obj(e, lambda)) || (rc = tomo_fgp_grad(e, lambda))) break;
     }
     e->is_first = f; e->is_last = l;
     if (rc) return rc;
@@ -1614,6 +1753,7 @@ int tomo_profile_enable(tomo_engine *e, int kernel, int on)
     HIPCHK(hipStreamSynchronize(e->stream));
     e->prof[kernel].on = on != 0;
     e->prof[kernel].used = 0;
+    e->prof[kernel].dropped = 0;
     return TOMO_OK;
 }
 
@@ -1632,6 +1772,11 @@ int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *tot
     *launches = (int64_t)(p.used / 2);
     *total_ms = tot;
     p.used = 0;
+    if (p.dropped) {   // never report an average over a silently truncated log
+        std::string msg = std::to_string(p.dropped) + " launches were not recorded (event log full)";
+        p.dropped = 0;
+        return fail(TOMO_ERR_STATE, msg);
+    }
     return TOMO_OK;
 }
 

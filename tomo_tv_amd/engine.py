@@ -15,7 +15,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COST, S_COUNT, S_DD, S_DIFF, S_GNORM, S_L1, S_RMSE, S_TV, SINO_B,
+from ._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COST, S_COUNT, S_DD, S_DIFF, S_DIFF2, S_GNORM, S_L1, S_RMSE, S_TV, SINO_B,
                    SINO_G, VOL_ORIGINAL, VOL_RECON, VOL_RECON_OLD, VOL_TEMP, VOL_YK, check)
 from .distributed import SlabComm, slab_partition
 
@@ -69,21 +69,33 @@ class _SlabBackend:
 
     # ---- torch plumbing for the distributed path (device tensors the collectives operate on) ----------
     def enable_torch(self):
+        """Device tensors the collectives operate on, bound into the engine; the engine runs on torch's current stream
+        of ITS device (the caller's device selection is left alone)."""
         import torch
-        torch.cuda.set_device(self.device)
         dev = torch.device("cuda", self.device)
+        self.tdev = dev
         self.c("set_stream", ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         self._scal_t = torch.zeros(S_COUNT, dtype=torch.float64, device=dev)
         npix = self.nray * self.nray
-        self._halo_lo = torch.zeros(npix, dtype=torch.float32, device=dev)
-        self._halo_hi = torch.zeros(npix, dtype=torch.float32, device=dev)
-        self._send_lo = torch.zeros(npix, dtype=torch.float32, device=dev)
-        self._send_hi = torch.zeros(npix, dtype=torch.float32, device=dev)
+        z = lambda k=1: torch.zeros(k * npix, dtype=torch.float32, device=dev)  # noqa: E731
+        self._halo_lo, self._halo_hi, self._send_lo, self._send_hi = z(), z(), z(), z()
+        # planes of the fused FGP iteration: lo = P1 below, hi = {A, P1, P2, P3} above, and what this slab sends
+        self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last = z(), z(4), z(4), z()
         self.c("bind_scalar_buffer", ctypes.c_void_p(self._scal_t.data_ptr()))
         self.c("bind_halo", ctypes.c_void_p(self._halo_lo.data_ptr()), ctypes.c_void_p(self._halo_hi.data_ptr()))
+        self.c("bind_fgp_halo", *(ctypes.c_void_p(t.data_ptr()) for t in
+                                  (self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last)))
 
     def scalar_tensor(self, slot):
         return self._scal_t[slot:slot + 1]
+
+    def scalar_gather(self, slots):
+        """The listed slots of the device scalar buffer as one new tensor (one all-reduce, one read-back)."""
+        return self._scal_t[list(slots)]
+
+    def tensor(self, values, dtype=None):
+        import torch
+        return torch.tensor(values, dtype=dtype or torch.float64, device=self.tdev)
 
     def pack_planes(self, field):
         self.c("halo_pack_both", field, ctypes.c_void_p(self._send_lo.data_ptr()), ctypes.c_void_p(self._send_hi.data_ptr()))
@@ -98,15 +110,19 @@ class _SlabBackend:
     def halo_tensors(self):
         return self._halo_lo, self._halo_hi
 
+    def fgp_planes(self):
+        """(send_first, send_last, lo, hi) of the fused FGP iteration."""
+        return self._fgp_send_first, self._fgp_send_last, self._fgp_lo, self._fgp_hi
+
     def new_plane(self):
         import torch
-        return torch.zeros(self.nray * self.nray, dtype=torch.float32, device=self._halo_lo.device)
+        return torch.zeros(self.nray * self.nray, dtype=torch.float32, device=self.tdev)
 
     def slice_to_tensor(self, vol, s):
         import torch
         img = np.empty((self.nray, self.nray), np.float32)
         self.c("get_slice", vol, s, _ptr(img))
-        return torch.from_numpy(img).to(self._halo_lo.device)
+        return torch.from_numpy(img).to(self.tdev)
 
     def lipschitz(self):
         L = ctypes.c_float(0)
@@ -142,11 +158,14 @@ class _EngineBase:
                 raise ValueError("more ranks than slices")
         else:
             self.first, self.nloc = 0, self.Nslice_
-        self.gpuID = 0 if device is None else int(device)
-        self.be = self._backend_cls(self.nloc, self.Ny, self.Nproj, angles_rad=angles_rad, A=A, device=self.gpuID)
-        if comm is not None:
-            self.be.enable_torch()
-            self.be.c("set_slab_edges", int(comm.rank == 0), int(comm.rank == comm.world - 1))
+        if device is None:
+            # with a process group the slab lives on the device the rank selected (torch.cuda.set_device(LOCAL_RANK))
+            device = self._current_device() if comm is not None else 0
+        self.gpuID = int(device)
+        self._ctor_kw = dict(angles_rad=angles_rad, A=A)
+        self._options = {}
+        self._stream_peer = None
+        self._make_backend(angles_rad=angles_rad, A=A)
         self.momentum = False
         self.tv_eps = 1e-6          # tv_gd.cu:29,54 (GPU path); ctvlib facade overrides to 1e-8
         self.projOrder = "sequential"
@@ -154,14 +173,33 @@ class _EngineBase:
         self.L_A = None
         self.L_Aml = None
 
+    @staticmethod
+    def _current_device():
+        try:
+            import torch
+            return torch.cuda.current_device() if torch.cuda.is_available() else 0
+        except ImportError:
+            return 0
+
+    def _make_backend(self, angles_rad=None, A=None):
+        self.be = self._backend_cls(self.nloc, self.Ny, self.Nproj, angles_rad=angles_rad, A=A, device=self.gpuID)
+        if self.comm is not None:
+            self.be.enable_torch()
+            self.be.c("set_slab_edges", int(self.comm.rank == 0), int(self.comm.rank == self.comm.world - 1))
+
     # ---- helpers -------------------------------------------------------------------------------------
     def _scalar(self, slot):
         """Global value of a partial-sum slot."""
+        return self._scalars((slot,))[0]
+
+    def _scalars(self, slots):
+        """Global values of several partial-sum slots: one all-reduce and one read-back for all of them."""
         if self.comm is None:
-            return float(self.be.scalars()[slot])
-        t = self.be.scalar_tensor(slot)
+            v = self.be.scalars()
+            return [float(v[k]) for k in slots]
+        t = self.be.scalar_gather(slots)
         self.comm.allreduce_sum(t)
-        return float(t.item())
+        return [float(v) for v in t.tolist()]
 
     def _exchange(self, field, planes=None):
         """Ring exchange of the field's boundary planes (``planes``: already packed by the producing kernel)."""
@@ -250,23 +288,31 @@ class _EngineBase:
         self.be.c("get_volume", which, _ptr(out))
         return out
 
-    def get_volume(self, which=VOL_RECON):
+    def _counts(self):
+        return [slab_partition(self.Nslice_, self.comm.world, r)[1] for r in range(self.comm.world)]
+
+    def get_volume(self, which=VOL_RECON, dst=None):
+        """(Nslice, Ny, Nz).  Sharded: a collective; ``dst=None`` assembles the volume on every rank, ``dst=r`` on
+        rank r only (the others return None)."""
         loc = self.get_volume_local(which)
         if self.comm is None or self.comm.world == 1:
             return loc
-        import torch
-        parts = [None] * self.comm.world
-        self.comm.dist.all_gather_object(parts, loc, group=self.comm.group)
-        return np.concatenate(parts, axis=0)
+        return self.comm.gather_slabs(loc, self._counts(), device=getattr(self.be, "tdev", None), dst=dst)
 
-    def _sino(self, which):
+    def _sino(self, which, dst=None):
         out = np.empty((self.nloc, self.Nrow), np.float32)
         self.be.c("get_sinogram", which, _ptr(out))
         if self.comm is None or self.comm.world == 1:
             return out
-        parts = [None] * self.comm.world
-        self.comm.dist.all_gather_object(parts, out, group=self.comm.group)
-        return np.concatenate(parts, axis=0)
+        return self.comm.gather_slabs(out, self._counts(), device=getattr(self.be, "tdev", None), dst=dst)
+
+    def _sino_local(self, which):
+        out = np.empty((self.nloc, self.Nrow), np.float32)
+        self.be.c("get_sinogram", which, _ptr(out))
+        return out
+
+    def _set_sino_local(self, loc):
+        self.be.c("set_tilt_series", _ptr(_f32c(loc)))
 
     def get_projections(self):
         return self._sino(SINO_B)
@@ -337,19 +383,29 @@ class _EngineBase:
     def original_tv(self):
         return self._tv_of(VOL_ORIGINAL, self.tv_eps)
 
-    def tv_gd(self, ng, dPOCS):
-        """ng steps of x -= dPOCS * g/||g|| then clamp; returns TV before descent (tv_gd.cu:141-218)."""
+    def tv_gd(self, ng, dPOCS, vol=VOL_RECON):
+        """ng steps of x -= dPOCS * g/||g|| then clamp on recon (or another volume slot); returns TV before descent
+        (tv_gd.cu:141-218)."""
         ng = int(ng)
+        if vol != VOL_RECON:
+            self.be.c("tv_set_target", int(vol))
+            try:
+                return self._tv_gd(ng, dPOCS, int(vol))
+            finally:
+                self.be.c("tv_set_target", VOL_RECON)
+        return self._tv_gd(ng, dPOCS, VOL_RECON)
+
+    def _tv_gd(self, ng, dPOCS, vol):
         if self.comm is None:
             self.be.c("tv_gd", ng, float(dPOCS), self.tv_eps)
             return self._scalar(S_TV)
         if ng <= 0:
-            tv0 = self._tv_of(VOL_RECON, self.tv_eps)
-            self.be.c("positivity", VOL_RECON)
+            tv0 = self._tv_of(vol, self.tv_eps)
+            self.be.c("positivity", vol)
             return tv0
         planes = None
         for g in range(ng):
-            self._exchange(VOL_RECON, planes)
+            self._exchange(vol, planes)
             # the first gradient pass also leaves the slab's share of the TV value "before descent"
             self.be.c("tv_grad_tv" if g == 0 else "tv_grad", self.tv_eps)
             self.comm.allreduce_sum(self.be.scalar_tensor(S_GNORM))   # stays on the device
@@ -359,6 +415,8 @@ class _EngineBase:
                 planes = self.be.tv_update_planes(dPOCS, 0)
         return self._scalar(S_TV)
 
+    fgp_fused = True   # sharded FGP: one fused kernel + one ring exchange per iteration (False: Obj / Grad pair, two)
+
     def tv_fgp(self, ng, lam, vol=VOL_RECON):
         """FGP-TV prox on recon (tv_fgp.cu:192-281), or on another volume slot; returns TV of the input."""
         ng, lam = int(ng), float(lam)
@@ -366,6 +424,17 @@ class _EngineBase:
             self.be.c("tv_fgp_vol", vol, ng, lam)
             return self._scalar(S_TV)
         tv0 = self._tv_of(vol, 1e-6)
+        if self.fgp_fused and ng > 1:
+            # iterations 0..ng-2: one fused pass each, which also leaves the planes the next exchange sends; the last
+            # iteration only needs D (tv_fgp.cu:272) and P1 of the slice below
+            self.be.c("fgp_fused_begin", vol)
+            first, last, lo, hi = self.be.fgp_planes()
+            for i in range(ng - 1):
+                self.comm.exchange_planes(first, last, lo, hi)
+                self.be.c("fgp_fused_step", lam, int(i == 0))
+            self.comm.exchange_planes(first, last, lo, hi)
+            self.be.c("fgp_fused_end", lam)
+            return tv0
         self.be.c("fgp_begin_vol", vol)
         for _ in range(ng):
             self._exchange(FIELD_FGP_P1)
@@ -401,6 +470,46 @@ class _EngineBase:
     def set_option(self, name, value):
         """Engine switches (include/tomo_hip.h: tomo_set_option), e.g. ``set_option("sart_fused", 0)``."""
         self.be.c("set_option", name.encode(), int(value))
+        self._options[name] = int(value)
+
+    # ---- simulation edges shared by every engine class ---------------------------------------------------------
+    def poisson_noise(self, Nc, seed=4321):
+        """Poisson noise on the tilt series at a mean of ``Nc`` counts per sample, total intensity preserved
+        (tomoengine.cpp:471-484, ctvlib.cpp:118-134; the reference draws from an unseeded std::default_random_engine,
+        quirk Q13: here a seeded numpy generator on the host -- a simulation edge, not part of the hot path).
+        Sharded: every rank draws for its own slab (seed + rank); only the total crosses ranks."""
+        b = self._sino_local(SINO_B).astype(np.float64)
+        total, count = float(b.sum()), float(b.size)
+        if self.comm is not None and self.comm.world > 1:
+            t = self.be.tensor([total, count])
+            self.comm.allreduce_sum(t)
+            total, count = (float(v) for v in t.tolist())
+            seed = seed + self.comm.rank
+        if total <= 0:
+            return
+        scaled = b / total * Nc * count
+        noisy = np.random.default_rng(seed).poisson(scaled).astype(np.float64)
+        self._set_sino_local(noisy / (Nc * count) * total)
+
+    def _rebuild(self, Nproj, angles_rad=None, A=None):
+        """New tilt geometry with the reconstruction kept (tomoengine.cpp:128-149, ctvlib.cpp:317-333): the old tables
+        are released BEFORE the new ones are built (one set in memory), the new engine adopts the volumes (no copy),
+        the stored options and the shared stream are re-applied, the Lipschitz constants refreshed."""
+        old = self.be
+        old.c("release_geometry")          # tables and sinograms go, the volumes stay on the device
+        self.Nproj = int(Nproj)
+        self.Nrow = self.Ny * self.Nproj
+        self._make_backend(angles_rad=angles_rad, A=A)
+        for name, value in self._options.items():
+            self.be.c("set_option", name.encode(), value)
+        if self._stream_peer is not None:
+            self._stream_peer.be.share_stream_with(self.be)
+        check(self.be.L.tomo_adopt_volumes(self.be.h, old.h))
+        old.close()
+        if self.L_A is not None:
+            self.L_A = self.get_lipschitz()
+        if self.L_Aml is not None:
+            self.L_Aml = self.get_lipschitz()
 
 
 class tomoengine(_EngineBase):
@@ -456,10 +565,14 @@ class tomoengine(_EngineBase):
     def initialize_poisson_ML(self):
         """tomoengine.cpp:231-246: L = max(A^T A 1); normalise the tilt series by its maximum if > 1."""
         self.L_Aml = self.get_lipschitz()
-        b = self.get_projections()
+        b = self._sino_local(SINO_B)
         m = float(b.max())
+        if self.comm is not None and self.comm.world > 1:
+            t = self.be.tensor([m])
+            self.comm.allreduce_max(t)
+            m = float(t.item())
         if m > 1:
-            self.set_tilt_series(b / m)
+            self._set_sino_local(b / np.float32(m))
 
     def SIRT(self, nIter=1):
         """ASTRA SIRT with min-constraint 0 on recon, or on yk under momentum (tomoengine.cpp:189-205)."""
@@ -467,45 +580,52 @@ class tomoengine(_EngineBase):
 
     def SART(self, beta=1.0, nIter=1):
         """Nproj*nIter single-angle updates, relaxation beta, min-constraint 0 (tomoengine.cpp:162-179)."""
-        if self.projOrder == "random":
-            order = np.ascontiguousarray(self._order_rng.permutation(self.Nproj), dtype=np.int32)
-            if self.comm is not None and self.comm.world > 1:   # every rank must sweep the same order
-                import torch
-                t = torch.from_numpy(order.astype(np.int64)).to(self.be.halo_tensors()[0].device)
-                self.comm.broadcast(t, 0)
-                order = np.ascontiguousarray(t.cpu().numpy(), dtype=np.int32)
-            self.be.c("sart", VOL_RECON, float(beta), int(nIter), _ptr(order))
-        else:
-            self.be.c("sart", VOL_RECON, float(beta), int(nIter), None)
+        order = self._sart_order()
+        self.be.c("sart", VOL_RECON, float(beta), int(nIter), _ptr(order) if order is not None else None)
 
-    def SART_tracked(self, beta=1.0, nIter=1):
+    def _sart_order(self):
+        if self.projOrder != "random":
+            return None
+        order = np.ascontiguousarray(self._order_rng.permutation(self.Nproj), dtype=np.int32)
+        if self.comm is not None and self.comm.world > 1:   # every rank must sweep the same order
+            import torch
+            t = self.be.tensor(order.astype(np.int64), dtype=torch.int64)
+            self.comm.broadcast(t, 0)
+            order = np.ascontiguousarray(t.cpu().numpy(), dtype=np.int32)
+        return order
+
+    def SART_tracked(self, beta=1.0, nIter=1, defer=False):
         """``SART(beta, nIter)`` followed by ``matrix_2norm()`` and ``copy_recon()`` (the three calls after which the
         ASD-POCS loop continues, examples/sim_ASD.py:70-78) with the norm and the snapshot produced by the sweep's last
-        back-projection pass.  The snapshot (TEMP) must equal recon's state before the sweep.  Returns the step norm."""
-        order = None
-        if self.projOrder == "random":
-            order = np.ascontiguousarray(self._order_rng.permutation(self.Nproj), dtype=np.int32)
-            if self.comm is not None and self.comm.world > 1:
-                import torch
-                t = torch.from_numpy(order.astype(np.int64)).to(self.be.halo_tensors()[0].device)
-                self.comm.broadcast(t, 0)
-                order = np.ascontiguousarray(t.cpu().numpy(), dtype=np.int32)
+        back-projection pass.  The snapshot (TEMP) must equal recon's state before the sweep.  Returns the step norm;
+        ``defer=True`` leaves its square in scalar slot ``S_DIFF2`` instead (no host synchronisation: read it later
+        together with the other scalars of the iteration, ``tv_gd_tracked(..., extra=(S_DIFF2,))``)."""
+        order = self._sart_order()
         self.be.c("sart_tracked", VOL_RECON, SINO_B, float(beta), int(nIter), _ptr(order) if order is not None else None,
-                  VOL_TEMP, S_DIFF)
-        return float(np.sqrt(self._scalar(S_DIFF)))
+                  VOL_TEMP, S_DIFF2 if defer else S_DIFF)
+        return None if defer else float(np.sqrt(self._scalar(S_DIFF)))
 
-    def tv_gd_tracked(self, ng, dPOCS):
+    def tv_gd_tracked(self, ng, dPOCS, extra=()):
         """``tv_gd(ng, dPOCS)`` followed by ``matrix_2norm()`` and ``copy_recon()`` in one call (the last descent step
-        also forms the norm and refreshes the snapshot).  Returns (TV before descent, step norm)."""
+        also forms the norm and refreshes the snapshot).  Returns (TV before descent, step norm) + the raw values of
+        the ``extra`` scalar slots, all from ONE all-reduce / read-back (``S_DD`` waits for the asynchronous data
+        distance first)."""
         ng = int(ng)
+        extra = tuple(extra)
+
+        def read():
+            if S_DD in extra:
+                self.be.c("async_wait")
+            v = self._scalars((S_TV, S_DIFF) + extra)
+            return (v[0], float(np.sqrt(v[1]))) + tuple(v[2:])
         if self.comm is None:
             self.be.c("tv_gd_tracked", ng, float(dPOCS), self.tv_eps, VOL_TEMP, S_DIFF)
-            return self._scalar(S_TV), float(np.sqrt(self._scalar(S_DIFF)))
+            return read()
         if ng <= 0:
             tv0 = self.tv_gd(ng, dPOCS)
             nrm = self.matrix_2norm()
             self.copy_recon()
-            return tv0, nrm
+            return (tv0, nrm) + tuple(self._scalars(extra)) if extra else (tv0, nrm)
         planes = None
         for g in range(ng):
             self._exchange(VOL_RECON, planes)
@@ -515,38 +635,17 @@ class tomoengine(_EngineBase):
                 self.be.c("tv_update_tracked", float(dPOCS), 1, VOL_TEMP, S_DIFF)
             else:
                 planes = self.be.tv_update_planes(dPOCS, 0)
-        return self._scalar(S_TV), float(np.sqrt(self._scalar(S_DIFF)))
+        return read()
 
     def poisson_ML(self, lam):
         self.be.c("poisson_ml", float(lam))
         return self._scalar(S_COST)
 
-    def poisson_noise(self, Nc, seed=4321):
-        """Poisson noise on the tilt series at a mean of ``Nc`` counts per sample, total intensity preserved
-        (tomoengine.cpp:471-484; the reference draws from an unseeded std::default_random_engine, quirk Q13: here a
-        seeded numpy generator on the host -- a simulation edge, not part of the hot path)."""
-        b = self.get_projections().astype(np.float64)
-        total = b.sum()
-        if total <= 0:
-            return
-        scaled = b / total * Nc * b.size
-        noisy = np.random.default_rng(seed).poisson(scaled).astype(np.float64)
-        self.set_tilt_series(noisy / (Nc * b.size) * total)
-
     def update_projection_angles(self, pyAngles):
-        """New tilt geometry, reconstruction kept (tomoengine.cpp:128-149): tables are rebuilt in a fresh engine and
-        the volumes that exist are moved over on the device.  The tilt series must be set again (its shape changed)."""
+        """New tilt geometry, reconstruction kept (tomoengine.cpp:128-149).  The tilt series must be set again (its
+        shape changed)."""
         ang = np.ascontiguousarray(pyAngles, dtype=np.float64).ravel()
-        old = self.be
-        self.Nproj = ang.size
-        self.Nrow = self.Ny * self.Nproj
-        self.be = self._backend_cls(self.nloc, self.Ny, self.Nproj, angles_rad=ang, device=self.gpuID)
-        if self.comm is not None:
-            self.be.enable_torch()
-            self.be.c("set_slab_edges", int(self.comm.rank == 0), int(self.comm.rank == self.comm.world - 1))
-        for v in (VOL_RECON, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD):
-            check(self.be.L.tomo_copy_volume_from(self.be.h, v, old.h, v))
-        old.close()
+        self._rebuild(ang.size, angles_rad=ang)
 
     def data_distance(self):
         """||A recon - b||_2, un-normalised (tomoengine.cpp:410-413)."""
@@ -560,16 +659,10 @@ class multigpuengine(tomoengine):
     dynamic per-slice scheduling, TV on one GPU) by static device-resident slabs + RCCL."""
 
     def __init__(self, Nslice, Nray, pyAngles=None, group=None):
-        import torch
-        comm = SlabComm(group)
-        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        super().__init__(Nslice, Nray, pyAngles, device=dev, comm=comm)
+        super().__init__(Nslice, Nray, pyAngles, device=None, comm=SlabComm(group))
 
     def get_gpu_ids(self):
-        import torch
-        ids = [None] * self.comm.world
-        self.comm.dist.all_gather_object(ids, self.gpuID, group=self.comm.group)
-        return ids
+        return self.comm.all_gather_ints(self.gpuID)
 
     def is_multi_gpu_enabled(self):
         return self.comm.world > 1
@@ -593,15 +686,36 @@ class ctvlib(_EngineBase):
         self._setup(Nslice, Nray, Nproj, A=A, device=device, comm=comm)
         self.tv_eps = 1e-8  # ctvlib.cpp:339,408
 
+    def update_proj_angles(self, A, Nproj):
+        """New measurement matrix for ``Nproj`` projections, reconstruction kept (ctvlib.cpp:317-333; the dynamic
+        harness appends tilts this way, cpu/utils/pytvlib.py:183-184).  The tilt series must be set again."""
+        if self.be is None:
+            raise _lib.TomoError("update_proj_angles before load_A")
+        self._ctor = (self._ctor[0], self._ctor[1], int(Nproj)) + self._ctor[3:]
+        self._rebuild(int(Nproj), A=A)
+
     def row_inner_product(self):
         self.be.c("row_inner_product")
 
+    def cimminos_method(self):
+        """Cimmino weights M = diag(|A_i|^2) (ctvlib.cpp:245-251): from now on ``SIRT`` and ``lipschits`` take the
+        Cimmino branch.  The reference multiplies by the row norms where Cimmino's method divides (quirk Q10); the
+        branch is reproduced as written."""
+        self._cimmino = True
+
     def lipschits(self):
+        if getattr(self, "_cimmino", False):
+            L = ctypes.c_float(0)
+            check(self.be.L.tomo_lipschitz_cimmino(self.be.h, ctypes.byref(L)))
+            return float(L.value)
         return self.get_lipschitz()
 
     def SIRT(self, beta):
-        """Landweber step + positivity (ctvlib.cpp:205-221)."""
-        self.be.c("sirt_landweber", VOL_RECON, float(beta), 1)
+        """Landweber (or, after ``cimminos_method``, Cimmino) step + positivity (ctvlib.cpp:205-221)."""
+        if getattr(self, "_cimmino", False):
+            self.be.c("sirt_cimmino", VOL_RECON, float(beta), 1)
+        else:
+            self.be.c("sirt_landweber", VOL_RECON, float(beta), 1)
 
     def ART(self, beta):
         self.be.c("art", float(beta))

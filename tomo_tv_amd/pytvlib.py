@@ -62,31 +62,41 @@ def parallelRay(Nside, angles):
     return system_matrix(Nside, angles)
 
 
-def initialize_ctvlib(tomo, alg, Nray, tiltAngles):
-    """cpu/utils/pytvlib.py:178-189 (angleStart == 0 branch)."""
-    tomo.load_A(parallelRay(Nray, np.asarray(tiltAngles)))
+def initialize_ctvlib(tomo, alg, Nray, tiltAngles, angleStart=0):
+    """cpu/utils/pytvlib.py:178-189: build A; first call loads it, later calls (``angleStart != 0``: tilts were
+    appended) swap it in with the reconstruction kept; then the row weights the algorithm needs."""
+    A = parallelRay(Nray, np.asarray(tiltAngles))
+    if angleStart == 0:
+        tomo.load_A(A)
+    else:
+        tomo.update_proj_angles(A, np.asarray(tiltAngles).shape[0])
     if alg in ("ART", "randART"):
         tomo.row_inner_product()
+    elif alg == "cimminoSIRT" and angleStart == 0:
+        tomo.cimminos_method()
 
 
 def run_ctvlib(tomo, alg, beta=1):
     """cpu/utils/pytvlib.py:171-176."""
-    if alg == "SIRT":
+    if alg in ("SIRT", "cimminoSIRT"):
         tomo.SIRT(beta)
-    elif alg == "ART":
-        tomo.ART(beta)
     elif alg == "randART":
         tomo.randART(beta)
-    else:
-        raise NotImplementedError(f"{alg}: the Cimmino branch multiplies by the row norms instead of dividing (quirk Q10) and is not built")
+    elif alg == "ART":
+        tomo.ART(beta)
 
 
-def create_projections(tomo, original_volume):
-    """cpu/utils/pytvlib.py:191-206 without the noise branch."""
+def create_projections(tomo, original_volume, SNR=0):
+    """cpu/utils/pytvlib.py:191-206: with ``SNR != 0`` the background is lifted to 1 (in place, like the reference)
+    and Poisson noise at ``SNR`` counts per sample is applied to the projections."""
+    if SNR != 0:
+        original_volume[original_volume == 0] = 1
     tomo.initialize_original_volume()
     for s in range(original_volume.shape[0]):
         tomo.set_original_volume(original_volume[s], s)
     tomo.create_projections()
+    if SNR != 0:
+        tomo.poisson_noise(SNR)
 
 
 def pack_tilt_series(tiltSeries):
