@@ -32,13 +32,18 @@ def asd_pocs_step(t, st):
         # descent pass; the residual of the SART result runs on the second stream under the TV steps
         if st["i"] == 0:
             t.copy_recon()
-        dp = t.SART_tracked(st["beta"], 1)
-        st["beta"] *= 0.9985
-        if st["i"] == 0:
+            dp = t.SART_tracked(st["beta"], 1)
             st["dPOCS"] = dp * 0.2
+        else:
+            t.SART_tracked(st["beta"], 1, defer=True)       # its step norm is read with the other scalars below
+        st["beta"] *= 0.9985
         t.data_distance_begin()
-        tv, dg = t.tv_gd_tracked(10, st["dPOCS"])
-        dd = t.data_distance_end() / st["norm"]
+        if st["i"] == 0:
+            tv, dg, dd2 = t.tv_gd_tracked(10, st["dPOCS"], extra=(S_DD,))
+        else:
+            tv, dg, dd2, dp2 = t.tv_gd_tracked(10, st["dPOCS"], extra=(S_DD, S_DIFF2))
+            dp = dp2 ** 0.5
+        dd = dd2 ** 0.5 / st["norm"]
     else:                                      # oracle (cpu_baseline): the same work as separate calls
         t.copy_recon()
         t.SART(st["beta"], 1)

@@ -55,6 +55,10 @@ def lib():
         L.orc_positivity.argtypes = [i64, P]
         L.orc_sirt.restype = None
         L.orc_sirt.argtypes = [i32, i64, i64, P, P, P, P, P, f32, i32]
+        L.orc_sirt_cimmino.restype = None
+        L.orc_sirt_cimmino.argtypes = [i32, i64, i64, P, P, P, P, P, P, f32, i32]
+        L.orc_lipschitz_cimmino.restype = f32
+        L.orc_lipschitz_cimmino.argtypes = [i64, i64, P, P, P, P]
         L.orc_row_inner.restype = None
         L.orc_row_inner.argtypes = [i64, P, P, P]
         L.orc_art.restype = None
@@ -201,8 +205,25 @@ class ctvlib:
         self.innerProduct = np.empty(self.Nrow, np.float32)
         lib().orc_row_inner(self.Nrow, _p(self.A.ptr), _p(self.A.val), _p(self.innerProduct))
 
+    def cimminos_method(self):
+        """M = diag(A.row(i).dot(A.row(i)))  (ctvlib.cpp:245-251): SIRT and lipschits take the Cimmino branch."""
+        self.M = np.empty(self.Nrow, np.float32)
+        lib().orc_row_inner(self.Nrow, _p(self.A.ptr), _p(self.A.val), _p(self.M))
+
     def lipschits(self):
+        if getattr(self, "M", None) is not None:
+            return float(lib().orc_lipschitz_cimmino(self.Nrow, self.Ncol, *self._a(), _p(self.M)))
         return float(lib().orc_lipschitz(self.Nrow, self.Ncol, *self._a()))
+
+    def poisson_noise(self, Nc, seed=4321):
+        """ctvlib.cpp:118-134 with a seeded numpy generator in place of the unseeded std::default_random_engine
+        (quirk Q13); the same formula as the product's ``poisson_noise``."""
+        b = self.b.astype(np.float64)
+        total = b.sum()
+        if total <= 0:
+            return
+        noisy = np.random.default_rng(seed).poisson(b / total * Nc * b.size).astype(np.float64)
+        self.b = (noisy / (Nc * b.size) * total).astype(np.float32)
 
     # -- data --------------------------------------------------------------------------------
     def set_tilt_series(self, b):
@@ -249,6 +270,10 @@ class ctvlib:
 
     # -- reconstruction ----------------------------------------------------------------------
     def SIRT(self, beta, niter=1):
+        if getattr(self, "M", None) is not None:
+            lib().orc_sirt_cimmino(self.Nslice_, self.Nrow, self.Ncol, *self._a(), _p(self.M), _p(self.b),
+                                   _p(self.recon), beta, niter)
+            return
         lib().orc_sirt(self.Nslice_, self.Nrow, self.Ncol, *self._a(), _p(self.b), _p(self.recon), beta, niter)
 
     def ART(self, beta, order=None):

@@ -12,6 +12,7 @@
  *   tomofusion/cpu/utils/ctvlib.cpp:101-115,279-293 create/forward proj.   -> orc_forward
  *   tomofusion/cpu/utils/ctvlib.cpp:194-202 lipschits                      -> orc_lipschitz
  *   tomofusion/cpu/utils/ctvlib.cpp:205-231 SIRT (Landweber) + positivity  -> orc_sirt
+ *   tomofusion/cpu/utils/ctvlib.cpp:198-199,212-216,245-251 Cimmino branch  -> orc_sirt_cimmino, orc_lipschitz_cimmino
  *   tomofusion/cpu/utils/ctvlib.cpp:137-155,234-242 ART + normalization    -> orc_art, orc_row_inner
  *   tomofusion/cpu/utils/ctvlib.cpp:260-306 matrix_2norm/data_distance/rmse-> orc_sqdiff (+ callers)
  *   tomofusion/cpu/utils/ctvlib.cpp:336-367 tv_3D                          -> orc_tv
@@ -299,6 +300,53 @@ void orc_sirt(int nslice, int64_t nrow, int64_t ncol, const int64_t *ptr, const 
         }
         orc_positivity((int64_t)nslice * ncol, vol);
     }
+}
+
+/* SIRT(beta), Cimmino branch + positivity: ctvlib.cpp:212-216 with M = diag(A.row(i).dot(A.row(i))) from
+ * cimminos_method() (ctvlib.cpp:245-251).  Eigen evaluates  A^T * M * r * (beta/Nrow)  left to right: the sparse
+ * product (A^T M) has entries a_ij * m_i (rounded to fp32), applied to r, the result scaled by beta/Nrow.
+ * (M multiplies by the row norms where Cimmino's method divides: quirk Q10, reproduced as written.) */
+void orc_sirt_cimmino(int nslice, int64_t nrow, int64_t ncol, const int64_t *ptr, const int32_t *idx,
+                      const float *val, const float *inner, const float *b, float *vol, float beta, int niter)
+{
+    const float scale = beta / (float)nrow;
+    for (int it = 0; it < niter; it++) {
+#pragma omp parallel
+        {
+            float *t = (float *)malloc(sizeof(float) * (size_t)nrow);
+            float *u = (float *)malloc(sizeof(float) * (size_t)ncol);
+#pragma omp for
+            for (int s = 0; s < nslice; s++) {
+                float *x = vol + (size_t)s * ncol;
+                const float *bs = b + (size_t)s * nrow;
+                spmv(nrow, ptr, idx, val, x, t);
+                for (int64_t r = 0; r < nrow; r++) t[r] = bs[r] - t[r];
+                for (int64_t c = 0; c < ncol; c++) u[c] = 0.0f;
+                for (int64_t r = 0; r < nrow; r++)
+                    for (int64_t k = ptr[r]; k < ptr[r + 1]; k++) u[idx[k]] += (val[k] * inner[r]) * t[r];
+                for (int64_t c = 0; c < ncol; c++) x[c] += u[c] * scale;
+            }
+            free(t); free(u);
+        }
+        orc_positivity((int64_t)nslice * ncol, vol);
+    }
+}
+
+/* lipschits(), Cimmino branch: (A^T * M * (A 1)).maxCoeff()   ctvlib.cpp:198-199 */
+float orc_lipschitz_cimmino(int64_t nrow, int64_t ncol, const int64_t *ptr, const int32_t *idx, const float *val,
+                            const float *inner)
+{
+    float *one = (float *)malloc(sizeof(float) * (size_t)ncol);
+    float *t = (float *)malloc(sizeof(float) * (size_t)nrow);
+    float *u = (float *)calloc((size_t)ncol, sizeof(float));
+    for (int64_t c = 0; c < ncol; c++) one[c] = 1.0f;
+    spmv(nrow, ptr, idx, val, one, t);
+    for (int64_t r = 0; r < nrow; r++)
+        for (int64_t k = ptr[r]; k < ptr[r + 1]; k++) u[idx[k]] += (val[k] * inner[r]) * t[r];
+    float m = u[0];
+    for (int64_t c = 1; c < ncol; c++) if (u[c] > m) m = u[c];
+    free(one); free(t); free(u);
+    return m;
 }
 
 /* normalization(): innerProduct(i) = A.row(i).dot(A.row(i))  ctvlib.cpp:234-242 */

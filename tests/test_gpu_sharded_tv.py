@@ -129,7 +129,9 @@ def test_sharded_asd_pocs_equals_whole_slab(gpu, world, nx):
     tr_w, vol_w, tmp_w = asd_script(4)(whole)
     tr_s, vol_s, tmp_s = run_sharded(world, nx, n, ang, np.zeros_like(x), asd_script(4), b=b)
     assert np.allclose(tr_s, tr_w, rtol=5e-6), (tr_s, tr_w)
-    assert rel_l2(vol_s, vol_w) < 5e-6 and np.array_equal(vol_s, tmp_s)
+    # free-running loop: the all-reduced ||grad TV||^2 is summed slab by slab, so the step lengths differ in the last
+    # bits and the TV descent amplifies that (measured 1.2e-5 after 4 iterations on 3 slabs; single steps: 2e-6 above)
+    assert rel_l2(vol_s, vol_w) < 5e-5 and np.array_equal(vol_s, tmp_s)
 
 
 @pytest.mark.parametrize("world,nx,n", [(2, 512, 512), (2, 128, 1024)], ids=["2x256x512sq", "2x64x1024sq"])

@@ -8,7 +8,7 @@ to the semantics of their canonical loops:
 import numpy as np
 
 from . import _lib, pytvlib
-from ._lib import VOL_RECON, VOL_YK
+from ._lib import S_DD, S_DIFF2, VOL_RECON, VOL_YK
 from .engine import multigpuengine, tomoengine
 
 
@@ -130,17 +130,25 @@ class TomoGPU:
         t.copy_recon()
         for i in range(Niter):
             # sim_ASD.py:68-78: copy_recon; SART; dp = matrix_2norm; copy_recon -- the step norm and the new snapshot
-            # (TEMP) come out of the sweep's last back-projection pass; TEMP == recon holds on entry
-            dp = t.SART_tracked(beta)
-            beta *= beta_reduce
+            # (TEMP) come out of the sweep's last back-projection pass; TEMP == recon holds on entry.  Only the first
+            # iteration needs dp at once (it sets the TV step length); later ones leave it on the device until the
+            # iteration's scalars are read together: one all-reduce and one host synchronisation per iteration.
             if i == 0:
+                dp = t.SART_tracked(beta)
                 dPOCS = dp * alpha
+            else:
+                t.SART_tracked(beta, defer=True)
+            beta *= beta_reduce
             # the residual of the SART result is independent of the TV descent: evaluate it on the snapshot (TEMP)
             # on the engine's second stream while the TV steps run
             t.data_distance_begin()
             # sim_ASD.py:84-88: tv_gd; dg = matrix_2norm (and the copy_recon that opens the next iteration)
-            self.tv_vec[i], dg = t.tv_gd_tracked(nTViter, dPOCS)
-            self.dd_vec[i] = t.data_distance_end() / norm
+            if i == 0:
+                self.tv_vec[i], dg, dd2 = t.tv_gd_tracked(nTViter, dPOCS, extra=(S_DD,))
+            else:
+                self.tv_vec[i], dg, dd2, dp2 = t.tv_gd_tracked(nTViter, dPOCS, extra=(S_DD, S_DIFF2))
+                dp = float(np.sqrt(dp2))
+            self.dd_vec[i] = float(np.sqrt(dd2)) / norm
             if dg > dp * r_max and self.dd_vec[i] > eps:
                 dPOCS *= alpha_reduce
         return self.dd_vec, self.tv_vec

@@ -51,8 +51,90 @@ def phantom(nx, n, seed=1234, k=20):
     return ellipsoids(nx, n, seed=seed, k=k)
 
 
+SIM_ASD = dict(alg="ART", beta0=0.5, beta_red=0.985, eps=0.02, alpha=0.2, alpha_red=0.95, r_max=0.95, ng=10, SNR=100)
+"""The parameter block of tomofusion/cpu/sim_ASD.py:14-31 (its own defaults)."""
+
+
+def sim_asd_loop(tomo, Niter, p=SIM_ASD, on_iter=None):
+    """The main loop of tomofusion/cpu/sim_ASD.py:64-96 on any object with the ``ctvlib`` method table (the oracle
+    here, the GPU facade in tests/test_gpu_cpu_harness.py).  Returns the per-iteration traces."""
+    beta = p["beta0"]
+    tr = {k: np.zeros(Niter) for k in ("dd", "tv", "rmse", "dp", "dg", "dPOCS")}
+    dPOCS = 0.0
+    for i in range(Niter):
+        tomo.copy_recon()
+        tomo.ART(beta)                                   # run(tomo, 'ART', beta)
+        beta *= p["beta_red"]
+        if i == 0:
+            dPOCS = tomo.matrix_2norm() * p["alpha"]
+            dp = dPOCS / p["alpha"]
+        else:
+            dp = tomo.matrix_2norm()
+        tr["dd"][i] = tomo.data_distance()
+        tr["rmse"][i] = tomo.rmse()
+        tomo.copy_recon()
+        tr["tv"][i] = tomo.tv()
+        tomo.tv_gd(p["ng"], dPOCS)
+        dg = tomo.matrix_2norm()
+        if dg > dp * p["r_max"] and tr["dd"][i] > p["eps"]:
+            dPOCS *= p["alpha_red"]
+        tr["dp"][i], tr["dg"][i], tr["dPOCS"][i] = dp, dg, dPOCS
+        if on_iter is not None:
+            on_iter(i, tomo)
+    return tr
+
+
+def asd_art_traces(shapes, Niter=20):
+    """ASD-POCS in the CPU reference's own form: alg = 'ART', the defaults of cpu/sim_ASD.py:14-31, SNR = 100 (background
+    lifted to 1, Poisson noise -- drawn from a seeded numpy generator, the reference's engine is unseedable: Q13).
+    Every line of the loop is arithmetic of ctvlib.cpp restated in oracle/: ART :137-155, true-copy matrix_2norm
+    :254-269 (Q1), data_distance :272-276, rmse :296-306, tv_3D :336-367, tv_gd_3D :406-462."""
+    import oracle
+    for N, P, Nx in shapes:
+        A = np.load(os.path.join(GOLD, f"A_N{N}_P{P}.npz"))["A"]
+        x0 = phantom(Nx, N).copy()
+        x0[x0 == 0] = 1                                   # cpu/utils/pytvlib.py:194-195 (SNR != 0)
+        out = {"x0": x0, "params": json.dumps(SIM_ASD)}
+        for eps in (1e-8, 1e-6):
+            t = oracle.ctvlib(Nx, N, P)
+            t.load_A(A)
+            t.row_inner_product()
+            t.initialize_recon_copy()
+            t.initialize_original_volume()
+            for s in range(Nx):
+                t.set_original_volume(x0[s], s)
+            t.create_projections()
+            t.poisson_noise(SIM_ASD["SNR"], seed=4321)
+            out["b"] = t.b.copy()
+            t.tv_eps = eps
+            out[f"tv0_eps{eps:g}"] = np.float64(t.original_tv())
+            snaps = {}
+            tr = sim_asd_loop(t, Niter, on_iter=lambda i, tt: snaps.__setitem__(i, tt.recon.copy()) if i in (0, 4) else None)
+            for k, v in tr.items():
+                out[f"{k}_eps{eps:g}"] = v
+            out[f"final_eps{eps:g}"] = t.recon.copy()
+            out[f"iter1_eps{eps:g}"], out[f"iter5_eps{eps:g}"] = snaps[0], snaps[4]
+        out["provenance"] = ("oracle/ restatement driven by the loop of tomofusion/cpu/sim_ASD.py:64-96 with its own "
+                             "defaults (alg ART); noise from numpy default_rng(4321) (not reference output)")
+        np.savez_compressed(os.path.join(GOLD, f"trace_asd_art_N{N}_P{P}_Nx{Nx}.npz"), **out)
+        # Cimmino branch of ctvlib::SIRT (ctvlib.cpp:212-216, 245-251) on the same data: 10 iterations at 1/L
+        t = oracle.ctvlib(Nx, N, P)
+        t.load_A(A)
+        t.cimminos_method()
+        t.set_tilt_series(out["b"])
+        L = t.lipschits()
+        for _ in range(10):
+            t.SIRT(t.Nrow / L)
+        np.savez_compressed(os.path.join(GOLD, f"trace_cimmino_N{N}_P{P}_Nx{Nx}.npz"), b=out["b"], lipschitz=np.float32(L),
+                            recon10=t.recon.copy(),
+                            provenance="oracle/ restatement of the Cimmino branch (ctvlib.cpp:198-199,212-216,245-251)")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-asd-art" in sys.argv:       # the traces added in round 2; everything else stays byte-identical
+        asd_art_traces([(16, 5, 2), (32, 9, 4), (64, 16, 8)])
+        return
     ref, ref_fusion = import_reference()
     import oracle
 
@@ -211,6 +293,7 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "trace_config1_sirt50.npz"), recon=t.recon.astype(np.float32),
                         dd=np.array(dd), rmse=np.array(rm), lipschitz=np.float32(t.lipschits()),
                         provenance="oracle/ restatement, config 1 (256x256 Shepp-Logan, 50 tilts, SIRT x50)")
+    asd_art_traces(shapes)
     print("golden written to", GOLD)
 
 
