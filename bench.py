@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: SART+TV (one ASD-POCS outer iteration) at 512^3 x 90 tilts per GPU.
+"""Headline benchmark: SART+TV (one ASD-POCS outer iteration) at 512^3 x 90 tilts.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--n 1024 --nslice 1024 --nproj 120]
 
-A step = one ASD-POCS outer iteration (examples/sim_ASD.py:66-94): copy_recon, one SART sweep over all
-tilts, step norm, data distance (a full forward projection), copy_recon, 10 TV gradient-descent steps, step
-norm (the engine forms the two norms and snapshot copies inside the sweep's last back-projection and the last
-descent step: tomo_sart_tracked / tomo_tv_gd_tracked).  Synthetic phantom + tilt series are resident in HBM before the timed region.  N > 1: one rank per GPU,
-each owns a 512-slice slab (weak scaling); the only cross-rank traffic is scalar all-reduces and TV halo planes.
-Prints ONE JSON line (rank 0).
+A step = one ASD-POCS outer iteration (examples/sim_ASD.py:66-94): copy_recon, one SART sweep over all tilts, step
+norm, data distance (a full forward projection), copy_recon, 10 TV gradient-descent steps, step norm (the engine forms
+the two norms and snapshot copies inside the sweep's last back-projection and the last descent step; the iteration's
+scalars are read back together).  Synthetic phantom + tilt series are resident in HBM before the timed region.
+
+N > 1: one rank per GPU over RCCL.  Launched by ``torch.distributed.run`` the ranks come from the environment; launched
+plainly (``python bench.py --gpus 4``) this process starts the N ranks itself as fresh child processes before anything
+touches the GPU (the role of multigpuengine.cpp:140-193, which starts its own workers).  ``--scaling strong`` (default,
+BASELINE's metric: ONE 512^3 x 90 volume on 1/2/4/8 GPUs) shards the --nslice slices of the volume over the ranks;
+``--scaling weak`` gives every rank its own --nslice slices.  The only cross-rank traffic is one scalar all-reduce per
+iteration + one per TV step, and the TV halo planes.  Rank 0 prints ONE JSON line.
+
+At N = 1 the same process then times, as sub-objects of that line (``secondary``): config 2 (256^3 x 60 SART), config 3
+(512^3 x 90 FISTA, roofline of the fused FGP iteration), the 8-GPU shard of config 4 (128 x 1024^2 x 120 ASD-POCS),
+ASD-POCS in the CPU reference's ART form, a normalised-SIRT iteration with the tile projectors' three roofs -- and the
+CPU baselines (``cpu_baseline`` + configs 1 and 2).  ``--quick`` skips the secondary part.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,15 +33,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-RMW_CEILING_GBS = 5300.0  # measured: tools/micro/copy_patterns.hip (read + write of the slab in place), DESIGN.md section 3
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak
+LDS_PEAK_GBS = 256 * 256 * 2.4   # 256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz = 157 TB/s
+RMW_CEILING_GBS = 5300.0     # measured: tools/micro/copy_patterns.hip (read + write of the slab in place) -- informative
 
 
 def asd_pocs_step(t, st):
     """One outer iteration, state dict st carries beta / dPOCS (defaults of gpu/reconstructor.py:158-161)."""
     if hasattr(t, "SART_tracked"):
+        from tomo_tv_amd._lib import S_DD, S_DIFF2
         # engine (= TomoGPU.asd_pocs): the step norms and snapshot copies ride on the last back-projection / last
-        # descent pass; the residual of the SART result runs on the second stream under the TV steps
+        # descent pass; the residual of the SART result runs on the second stream under the TV steps; one read-back
         if st["i"] == 0:
             t.copy_recon()
             dp = t.SART_tracked(st["beta"], 1)
@@ -54,7 +70,7 @@ def asd_pocs_step(t, st):
         else:
             dp = t.matrix_2norm()
         t.copy_recon()
-        dd = t.data_distance() / st["norm"]
+        dd = t.data_distance(normalize=False) / st["norm"]
         tv = t.tv_gd(10, st["dPOCS"])
         dg = t.matrix_2norm()
     if dg > dp * 0.95 and dd > 0.025:
@@ -63,43 +79,265 @@ def asd_pocs_step(t, st):
     return dd, tv
 
 
-def cpu_baseline(n, nproj, budget_s=20.0):
-    """The C oracle (OpenMP over slices, like ctvlib.cpp:207) on a bounded sample of the same workload."""
+# ---- CPU baselines (the oracle, timed build, on the host cores the box grants) ---------------------------------------
+def _oracle_setup(ns, n, nproj, shepp=False):
     import oracle
-    from tomo_tv_amd.phantom import ellipsoids, tilt_angles
-    if "OMP_NUM_THREADS" not in os.environ:
-        oracle.set_num_threads(oracle.usable_cpus())   # the baseline uses every CPU the host grants
-    threads = oracle.num_threads()
-    ns = max(8, 2 * threads)
+    from tomo_tv_amd.phantom import ellipsoids, shepp_logan, tilt_angles
     ang = tilt_angles(nproj)
-    A = oracle.parallel_ray(n, ang)
     ref = oracle.ctvlib(ns, n, nproj)
-    ref.load_A(A)
-    ref.original_volume = ellipsoids(ns, n)
+    ref.load_A(oracle.parallel_ray(n, ang))
+    ref.original_volume = shepp_logan(n)[None].astype(np.float32) if shepp else ellipsoids(ns, n)
     ref.create_projections()
     ref.initialize_recon_copy()
     ref.tv_eps = 1e-6
-    st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(ns * n * nproj)}
-    # the oracle has the same method names, so the same step function drives it
-    ref.data_distance_n = ref.data_distance
-    class _Shim:
-        def __getattr__(self, k):
-            return getattr(ref, k)
-        def data_distance(self):
-            return ref.data_distance(normalize=False)
-    shim = _Shim()
+    return ref
+
+
+def _timed(fn, budget_s, max_iters):
     t0 = time.perf_counter()
-    iters = 0
+    it = 0
     while True:
-        asd_pocs_step(shim, st)
-        iters += 1
+        fn()
+        it += 1
         el = time.perf_counter() - t0
-        if el > budget_s or iters >= 5:
-            break
-    vox = ns * n * n
-    return {"value": vox * iters / el / 1e9, "unit": "Gvoxel-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{iters} ASD-POCS iterations on a {ns}x{n}x{n} slab, {nproj} tilts (oracle/tomo_oracle.c, OpenMP over slices)",
+        if el > budget_s or it >= max_iters:
+            return it, el
+
+
+def cpu_baselines(n, nproj, budget_s=14.0):
+    """Headline sample + configs 1 and 2.  Returns (cpu_baseline, {config: ...})."""
+    import oracle
+    oracle.select_build("timed")
+    if "OMP_NUM_THREADS" not in os.environ:
+        oracle.set_num_threads(oracle.usable_cpus())   # the baseline uses every CPU the host grants
+    threads = oracle.num_threads()
+    kind = f"port ({oracle.BUILD_FLAGS['timed']}; OpenMP over slices like ctvlib.cpp:207; oracle/tomo_oracle.c)"
+    ns = max(8, 2 * threads)
+    ref = _oracle_setup(ns, n, nproj)
+    st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(ns * n * nproj)}
+    iters, el = _timed(lambda: asd_pocs_step(ref, st), budget_s, 5)
+    head = {"value": ns * n * n * iters / el / 1e9, "unit": "Gvoxel-updates/s", "cores": threads, "kind": kind,
+            "sample": f"{iters} ASD-POCS iterations (SART sweep + 10 TV-GD steps) on a {ns}x{n}x{n} slab of the workload, "
+                      f"{nproj} tilts",
             "iters_per_s_full_volume_equiv": iters / el * ns / n}
+    out = {}
+    # config 1: 2-D 256x256 Shepp-Logan, 50 tilts, SIRT (the reference's CPU-runnable case; Landweber at 1/L)
+    ref = _oracle_setup(1, 256, 50, shepp=True)
+    beta = 1.0 / ref.lipschits()
+    iters, el = _timed(lambda: ref.SIRT(beta), 2.0, 50)
+    out["config1_sirt_256sq_x50tilts"] = {"iters_per_s": iters / el, "ms_per_iter": el / iters * 1e3, "cores": 1,
+                                          "sample": f"{iters} Landweber-SIRT iterations, 1 slice (OpenMP is over slices)"}
+    # config 2: 256^3, 60 tilts: SIRT and SART+TV on a slab sample
+    ns2 = max(8, 2 * threads)
+    ref = _oracle_setup(ns2, 256, 60)
+    beta = 1.0 / ref.lipschits()
+    iters, el = _timed(lambda: ref.SIRT(beta), 3.0, 20)
+    out["config2_sirt_256cube_x60tilts"] = {"iters_per_s_full_volume_equiv": iters / el * ns2 / 256, "cores": threads,
+                                            "gvoxel_updates_per_s": ns2 * 256 * 256 * iters / el / 1e9,
+                                            "sample": f"{iters} Landweber-SIRT iterations on a {ns2}x256x256 slab"}
+    st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(ns2 * 256 * 60)}
+    iters, el = _timed(lambda: asd_pocs_step(ref, st), 4.0, 5)
+    out["config2_sart_tv_256cube_x60tilts"] = {"iters_per_s_full_volume_equiv": iters / el * ns2 / 256, "cores": threads,
+                                               "gvoxel_updates_per_s": ns2 * 256 * 256 * iters / el / 1e9,
+                                               "sample": f"{iters} SART+TV iterations on a {ns2}x256x256 slab"}
+    oracle.select_build("parity")
+    return head, out
+
+
+# ---- per-kernel roofline from the engine's HIP-event log ----------------------------------------------------------------
+class KernelLog:
+    def __init__(self, t, ids):
+        from tomo_tv_amd import _lib
+        self._lib, self.t, self.ids = _lib, t, ids
+        for kid in ids.values():
+            _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
+
+    def read(self):
+        import ctypes
+        out = {}
+        for name, kid in self.ids.items():
+            launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0)
+            self._lib.check(self.t.be.L.tomo_profile_read(self.t.be.h, kid, ctypes.byref(launches), ctypes.byref(total_ms)))
+            self._lib.check(self.t.be.L.tomo_profile_enable(self.t.be.h, kid, 0))
+            out[name] = (int(launches.value), float(total_ms.value))
+        return out
+
+
+def roof(name, cnt, tot_ms, alg_bytes, flops=None, lds_bytes=None):
+    avg_ms = tot_ms / cnt if cnt else 0.0
+    ach = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    r = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "launches": cnt, "avg_ms": avg_ms, "total_ms": tot_ms, "algorithmic_bytes_per_launch": alg_bytes}
+    if flops is not None and avg_ms > 0:      # kernels that are not HBM-bound: the other two roofs (SURVEY.md 8d caveat)
+        r["valu_tflops"] = flops / (avg_ms * 1e-3) / 1e12
+        r["valu_frac"] = r["valu_tflops"] / VALU_PEAK_TFLOPS
+    if lds_bytes is not None and avg_ms > 0:
+        r["lds_gbs"] = lds_bytes / (avg_ms * 1e-3) / 1e9
+        r["lds_frac"] = r["lds_gbs"] / LDS_PEAK_GBS
+    return r
+
+
+def attach_traffic(roofs, shape):
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, separate runs, FETCH_SIZE x2), null if the
+    profile is absent or was taken at another shape.  Measured outside this run by construction (the counters need the
+    profiler); the file names the command."""
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", fn)
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if tuple(doc.get("shape", (512, 512, 90))) != tuple(shape):
+            continue
+        for r in roofs.values():
+            key = r["kernel"].replace(",", ", ")
+            hit = [v for k, v in doc.get("kernels", {}).items() if key in k or r["kernel"] in k]
+            if hit and r.get("traffic") is None:
+                r["traffic"] = hit[0]["hbm_bytes_per_launch"]
+                r["traffic_source"] = f"profiles/{fn} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+        return
+
+
+# ---- secondary configs (N = 1, same process, after the headline) -----------------------------------------------------------
+def _engine(nx, n, nproj):
+    import ctypes
+    from tomo_tv_amd._lib import VOL_ORIGINAL
+    from tomo_tv_amd.engine import tomoengine
+    from tomo_tv_amd.phantom import ellipsoids, tilt_angles
+    t = tomoengine(nx, n, np.deg2rad(tilt_angles(nproj)), device=0)
+    vol = ellipsoids(nx, n)
+    t.be.c("set_volume", VOL_ORIGINAL, vol.ctypes.data_as(ctypes.c_void_p))
+    del vol
+    t.create_projections()
+    t.restart_recon()
+    return t
+
+
+def _time_steps(t, fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    t.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    t.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def secondary_configs(nnz_per_pixel_angle=1.22):
+    from tomo_tv_amd import pytvlib
+    from tomo_tv_amd._lib import K_BP_TILE, K_FGP_GRAD, K_FP_REDUCE, K_FP_TILE, K_SART_FUSED, VOL_YK
+    out = {}
+    # ---- config 2: 256^3, 60 tilts, SART (beta 1, sequential) + data_distance per iteration
+    t = _engine(256, 256, 60)
+    t.initialize_SART("sequential")
+    log = KernelLog(t, {"k_sart_tile<true>": K_SART_FUSED})
+    ms = _time_steps(t, lambda: (t.SART(1.0, 1), t.data_distance()), 5)
+    cnt, tot = log.read()["k_sart_tile<true>"]
+    V = 256.0 ** 3
+    out["config2_sart_256cube_x60tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
+                                            "roofline": roof("k_sart_tile<true>", cnt, tot, 8 * V + 12 * 256 * 256)}
+    del t
+    # ---- config 3: 512^3, 90 tilts: FISTA (lambda 0.1, 10 FGP iterations, cost), then SIRT with the tile projectors' roofs
+    t = _engine(512, 512, 90)
+    V, S, nx, n, P = 512.0 ** 3, 512.0 * 512 * 90, 512, 512, 90
+    pytvlib.initialize_algorithm(t, "fista")
+    st = {"t0": 1.0}
+
+    def fista_iter():
+        pytvlib.run(t, "fista")
+        t.tv_fgp(10, 0.1, vol=VOL_YK)
+        tk = 0.5 * (1 + np.sqrt(1 + 4 * st["t0"] ** 2))
+        t.fista_momentum((st["t0"] - 1) / tk)
+        st["t0"] = tk
+        return 0.5 * t.data_distance() ** 2 + 0.1 * t.tv()
+    log = KernelLog(t, {"k_fgp_fused": K_FGP_GRAD})
+    ms = _time_steps(t, fista_iter, 5)
+    cnt, tot = log.read()["k_fgp_fused"]
+    out["config3_fista_512cube_x90tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
+                                             "roofline": roof("k_fgp_fused", cnt, tot, 28 * V)}
+    t.remove_momentum()
+    t.restart_recon()
+    log = KernelLog(t, {"k_fp_tile": K_FP_TILE, "k_fp_tile_reduce": K_FP_REDUCE, "k_bp_tile": K_BP_TILE})
+    ms = _time_steps(t, lambda: (t.SIRT(1), t.data_distance()), 5)
+    pr = log.read()
+    nnz = nnz_per_pixel_angle * n * n * P
+    avg = lambda k: pr[k][1] / max(pr[k][0], 1)  # noqa: E731
+    fp_ms = avg("k_fp_tile") + avg("k_fp_tile_reduce")
+    out["config3_sirt_512cube_x90tilts"] = {
+        "ms_per_step": ms, "iters_per_s": 1e3 / ms,
+        # all-angle FP = k_fp_tile + k_fp_tile_reduce (4V + 4S algorithmic); one entry = one FMA and one 4-byte LDS read per slice
+        "roofline_fp_all": dict(roof("k_fp_tile+k_fp_tile_reduce", 1, fp_ms, 4 * V + 4 * S, flops=2 * nnz * nx, lds_bytes=4 * nnz * nx),
+                                k_fp_tile_avg_ms=avg("k_fp_tile"), k_fp_tile_reduce_avg_ms=avg("k_fp_tile_reduce")),
+        # all-angle BP (8V + 4S): two FMAs and two LDS row reads per pixel, angle and slice
+        "roofline_bp_all": roof("k_bp_tile", pr["k_bp_tile"][0], pr["k_bp_tile"][1], 8 * V + 4 * S, flops=4.0 * n * n * P * nx,
+                                lds_bytes=8.0 * n * n * P * nx)}
+    del t
+    # ---- ASD-POCS in the CPU reference's form (cpu/sim_ASD.py:64-96: ART sweep + tv + 10 TV-GD steps + 3 norms) at 512^3 x 90
+    from tomo_tv_amd.engine import ctvlib
+    from tomo_tv_amd.phantom import ellipsoids, tilt_angles
+    c = ctvlib(512, 512, 90)
+    c.load_A(pytvlib.parallelRay(512, tilt_angles(90)))
+    c.set_volume(ellipsoids(512, 512), 2)
+    c.create_projections()
+    c.tv_eps = 1e-6
+    sa = {"beta": 0.5, "dPOCS": None}
+
+    def asd_art():
+        c.copy_recon()
+        c.ART(sa["beta"])
+        sa["beta"] *= 0.985
+        dp = c.matrix_2norm()
+        if sa["dPOCS"] is None:
+            sa["dPOCS"] = dp * 0.2
+        dd = c.data_distance()
+        c.copy_recon()
+        c.tv()
+        c.tv_gd(10, sa["dPOCS"])
+        dg = c.matrix_2norm()
+        if dg > dp * 0.95 and dd > 0.02:
+            sa["dPOCS"] *= 0.95
+    ms = _time_steps(c, asd_art, 3)
+    out["asd_pocs_art_512cube_x90tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
+                                            "form": "cpu/sim_ASD.py:64-96 through the ctvlib facade (chained ART sweep, separate norms)"}
+    del c
+    # ---- one GPU's shard of config 4: 128 x 1024^2, 120 tilts, ASD-POCS
+    t = _engine(128, 1024, 120)
+    t.initialize_SART("sequential")
+    st4 = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
+    asd_pocs_step(t, st4)
+    log = KernelLog(t, {"k_sart_tile<true>": K_SART_FUSED})
+    ms = _time_steps(t, lambda: asd_pocs_step(t, st4), 3, warmup=0)
+    cnt, tot = log.read()["k_sart_tile<true>"]
+    V4 = 128.0 * 1024 * 1024
+    out["config4_shard_asd_pocs_128x1024sq_x120tilts"] = {
+        "ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V4 / ms / 1e6,
+        "roofline": roof("k_sart_tile<true>", cnt, tot, 8 * V4 + 12 * 128 * 1024)}
+    del t
+    return out
+
+
+# ---- launcher: a plain `python bench.py --gpus N` starts its own N ranks ---------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """N fresh child processes (this parent never touches the GPU), rank 0's stdout passed through."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -108,41 +346,71 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=512, help="Nray = Ny = Nz")
-    ap.add_argument("--nslice", type=int, default=512, help="slices per GPU")
+    ap.add_argument("--nslice", type=int, default=512, help="slices of the volume (strong) / per GPU (weak)")
     ap.add_argument("--nproj", type=int, default=90)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: ONE volume of --nslice slices sharded over the GPUs (BASELINE's metric); weak: --nslice per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="use the slab-sharded engine + RCCL even with one rank")
+    ap.add_argument("--quick", action="store_true", help="headline only: no secondary configs, no CPU baselines")
+    ap.add_argument("--force-dist", action="store_true", help="use the slab-sharded engine + its communicator even with one rank")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL); tests drive the launcher with gloo")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tomo_set_option), repeatable")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    from tomo_tv_amd import _lib
-    from tomo_tv_amd._lib import K_BP_ANGLE, K_SART_FUSED, VOL_ORIGINAL
-    from tomo_tv_amd.engine import multigpuengine, tomoengine
-    from tomo_tv_amd.phantom import ellipsoids, tilt_angles
     import ctypes
+    from tomo_tv_amd._lib import K_BP_ANGLE, K_SART_FUSED, VOL_ORIGINAL
+    from tomo_tv_amd.distributed import slab_partition
+    from tomo_tv_amd.phantom import ellipsoids, tilt_angles
 
-    n, nproj, nloc = args.n, args.nproj, args.nslice
+    n, nproj = args.n, args.nproj
+    nglobal = args.nslice * (world if args.scaling == "weak" else 1)
     ang = np.deg2rad(tilt_angles(nproj))
     comm = None
+    on_gpu = True
     if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        t = multigpuengine(nloc * world, n, ang)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            from tomo_tv_amd.engine import multigpuengine
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            t = multigpuengine(nglobal, n, ang)
+        else:                                            # launcher test on a CPU box: the numpy slab double of tests/
+            on_gpu = False
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from slab_double import OracleSlabBackend
+            from tomo_tv_amd.distributed import SlabComm
+            from tomo_tv_amd.engine import tomoengine
+
+            class DoubleEngine(tomoengine):
+                _backend_cls = OracleSlabBackend
+
+                def synchronize(self):
+                    pass
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            t = DoubleEngine(nglobal, n, ang, comm=SlabComm())
         comm = t.comm
     else:
-        t = tomoengine(nloc, n, ang, device=0)
-    # synthetic data: every rank's slab is the same seeded phantom (weak scaling: identical per-GPU work)
-    vol = ellipsoids(nloc, n)
+        from tomo_tv_amd.engine import tomoengine
+        t = tomoengine(nglobal, n, ang, device=0)
+    first, nloc = slab_partition(nglobal, world, rank) if comm is not None else (0, nglobal)
+    # synthetic data: strong scaling -> this rank's slab of ONE seeded phantom; weak -> the same phantom on every rank
+    if args.scaling == "strong":
+        vol = np.ascontiguousarray(ellipsoids(nglobal, n)[first:first + nloc])
+    else:
+        vol = ellipsoids(nloc, n)
     t.be.c("set_volume", VOL_ORIGINAL, vol.ctypes.data_as(ctypes.c_void_p))
     del vol
     t.create_projections()
@@ -154,7 +422,11 @@ def main():
     st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
 
     def sync():
-        t.synchronize()
+        if on_gpu:
+            t.synchronize()
+            if comm is not None:
+                import torch
+                torch.cuda.synchronize()
         if comm is not None:
             comm.barrier()
 
@@ -165,28 +437,27 @@ def main():
     tile = not any(o.replace(" ", "") == "sart_tile=0" for o in args.opt)
     K_FUSED_NAME, K_FP_NAME = ("k_sart_tile<true>", "k_sart_tile<false>") if tile else ("k_sart_seg<4,8,true>", "k_sart_seg<4,8,false>")
     K_BP_NAME = "k_bp_angle<4,4,true>"   # the sweep's last back-projection, tracked form (also step norm + snapshot copy)
-    kernels = {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1}   # names as rocprofv3 prints them
-    for kid in kernels.values():
-        _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
+    log = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1}) if on_gpu else None
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         dd, tv = asd_pocs_step(t, st)
     sync()
     el = time.perf_counter() - t0
-    prof = {}
-    for name, kid in kernels.items():
-        launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0)
-        _lib.check(t.be.L.tomo_profile_read(t.be.h, kid, ctypes.byref(launches), ctypes.byref(total_ms)))
-        _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 0))
-        prof[name] = (int(launches.value), float(total_ms.value))
+    prof = log.read() if log else {}
+    per_rank = None
     if comm is not None:
-        import torch
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tt = t.be.tensor([el])
         comm.allreduce_max(tt)
         el = float(tt.item())
+        if prof:   # the dominant kernel's mean launch time on every rank
+            mine = prof[K_FUSED_NAME][1] / max(prof[K_FUSED_NAME][0], 1)
+            allv = t.be.tensor([mine if r == rank else 0.0 for r in range(world)])
+            comm.allreduce_sum(allv)
+            per_rank = [float(v) for v in allv.tolist()]
 
     if rank == 0:
-        vox_total = nloc * world * n * n
+        vox_total = float(nglobal) * n * n
         # Algorithmic bytes per launch (SURVEY.md section 8d, V = voxels of this GPU's slab, fp32):
         #   k_bp_angle<..true>  single-angle voxel update that also forms the step norm and refreshes the snapshot:
         #                       slab + snapshot in, slab + snapshot out, that angle's residual rows = 16V + 4 Nx N
@@ -198,32 +469,17 @@ def main():
                      K_FP_NAME: 4.0 * V + 8.0 * nloc * n}
         roofs = {}
         for name, (cnt, tot) in prof.items():
-            avg_ms = tot / cnt if cnt else 0.0
-            ach = alg_bytes[name] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roofs[name] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": cnt, "avg_ms": avg_ms,
-                           "total_ms": tot, "algorithmic_bytes_per_launch": alg_bytes[name],
-                           # what an in-place read-modify-write pass over the slab reaches on this part in any access
-                           # pattern (tools/micro/copy_patterns.hip: 5.2-5.5 TB/s) -- informative, not the peak
-                           "frac_of_measured_rmw_ceiling": ach / RMW_CEILING_GBS}
-        # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), null if absent
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            match = {"k_sart_seg<4,8,true>": "k_sart_seg<4, 8, true>", "k_bp_angle<4,4,true>": "k_bp_angle<4, 4, true>",
-                     "k_sart_seg<4,8,false>": "k_sart_seg<4, 8, false>", "k_sart_tile<true>": "k_sart_tile<true>",
-                     "k_sart_tile<false>": "k_sart_tile<false>"}
-            if (nloc, n, nproj) == (512, 512, 90):
-                for name in roofs:
-                    key = match[name]
-                    hit = [v for k, v in pmc.items() if key in k]
-                    if hit:
-                        roofs[name]["traffic"] = hit[0]["hbm_bytes_per_launch"]
-                        roofs[name]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
-        except (OSError, KeyError, ValueError):
-            pass
-        dominant = max(roofs.values(), key=lambda r: r["total_ms"])
+            roofs[name] = roof(name, cnt, tot, alg_bytes[name])
+            # what an in-place read-modify-write pass over the slab reaches on this part in any access pattern
+            # (tools/micro/copy_patterns.hip: 5.2-5.5 TB/s) -- informative, not the peak
+            roofs[name]["frac_of_measured_rmw_ceiling"] = roofs[name]["achieved"] / RMW_CEILING_GBS
+        attach_traffic(roofs, (nloc, n, nproj))
+        dominant = max(roofs.values(), key=lambda r: r["total_ms"]) if roofs else None
+        if dominant is not None and per_rank is not None:
+            dominant = dict(dominant, avg_ms_per_rank=per_rank)
+        shape = f"{nglobal}x{n}x{n}"
         out = {
-            "metric": "SART+TV Gvoxel-updates/s (ASD-POCS outer iterations x voxels, 512^3 x 90 tilts per GPU)",
+            "metric": "SART+TV Gvoxel-updates/s (ASD-POCS outer iterations x voxels, 512^3 x 90 tilts, at 1/2/4/8 GPU)",
             "value": vox_total * args.steps / el / 1e9,
             "unit": "Gvoxel-updates/s",
             "n_gpus": world,
@@ -234,20 +490,25 @@ def main():
             # every angle of the SART sweep updates every voxel (SURVEY.md section 8d asks for this figure as well)
             "sart_gvoxel_angle_updates_per_s": vox_total * nproj * args.steps / el / 1e9,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"ASD-POCS iteration (SART sweep beta0=0.25 + 10 TV-GD steps), {nloc}x{n}x{n} voxels per GPU, "
-                                   f"{nproj} tilts -70..70 deg (BASELINE configs[2] shape; headline SART+TV 512^3x90)",
-                       "slices_per_gpu": nloc, "nray": n, "nproj": nproj, "sharding": f"tilt-axis slabs x{world}"},
+            "config": {"workload": f"ASD-POCS iteration (SART sweep beta0=0.25 + 10 TV-GD steps) on ONE {shape} volume, {nproj} tilts "
+                                   f"-70..70 deg (headline SART+TV 512^3x90 = BASELINE configs[2] shape), {nloc} slices on rank 0",
+                       "volume": shape, "slices_per_gpu": nloc, "nray": n, "nproj": nproj,
+                       "sharding": f"tilt-axis slabs x{world} ({args.scaling} scaling)"},
             "final_dd": dd, "final_tv": tv,
             "roofline": dominant,
-            "roofline_bp_angle": roofs[K_BP_NAME],
-            "roofline_fp_angle": roofs[K_FP_NAME],
+            "roofline_bp_angle": roofs.get(K_BP_NAME),
+            "roofline_fp_angle": roofs.get(K_FP_NAME),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, nproj)
+        if world == 1 and comm is None and not args.quick:
+            del t, log
+            t = log = None
+            out["secondary"] = secondary_configs()
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"], out["cpu_baseline_configs"] = cpu_baselines(n, nproj)
         print(json.dumps(out), flush=True)
     if comm is not None:
         import torch.distributed as dist

@@ -239,7 +239,8 @@ int tomo_set_option(tomo_engine *e, const char *name, int value);
  * While enabled, every launch of the named kernel is bracketed by HIP events on the engine's stream;
  * tomo_profile_read synchronises, returns launch count and summed device time, and resets the log. */
 enum tomo_kernel_id { TOMO_K_BP_ANGLE = 0, TOMO_K_FP_ANGLE = 1, TOMO_K_TV_GRAD = 2, TOMO_K_TV_UPDATE = 3,
-                      TOMO_K_FGP_OBJ = 4, TOMO_K_FGP_GRAD = 5, TOMO_K_SART_FUSED = 6, TOMO_K_FP_TILE = 7 };
+                      TOMO_K_FGP_OBJ = 4, TOMO_K_FGP_GRAD = 5 /* also the fused FGP iteration */, TOMO_K_SART_FUSED = 6,
+                      TOMO_K_FP_TILE = 7, TOMO_K_BP_TILE = 8, TOMO_K_FP_REDUCE = 9 };
 int tomo_profile_enable(tomo_engine *e, int kernel, int on);
 int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms);
 

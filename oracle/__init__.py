@@ -31,14 +31,28 @@ def build(force=False):
 
 
 _lib = None
+_SO_TIMED = os.path.join(_HERE, "libtomo_oracle_timed.so")
+BUILD_FLAGS = {"parity": "gcc -O2 -ffp-contract=off -fopenmp", "timed": "gcc -O3 -ffast-math -fopenmp (the reference's make.inc flags)"}
+_build = "parity"
+
+
+def select_build(kind):
+    """``"parity"`` (default: -O2, no contraction -- what every test uses) or ``"timed"`` (-O3 -ffast-math like
+    tomofusion/cpu/utils/make.inc:3 -- ONLY for the timed CPU baseline of bench.py, never for parity)."""
+    global _lib, _build
+    if kind not in BUILD_FLAGS:
+        raise ValueError(kind)
+    if kind != _build:
+        _build, _lib = kind, None
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
-        L = ctypes.CDLL(_SO)
+        so = _SO_TIMED if _build == "timed" else _SO
+        if not os.path.exists(so):
+            build(force=True)
+        L = ctypes.CDLL(so)
         i64, i32, f32, f64 = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_double
         P = ctypes.c_void_p
         L.orc_parallel_ray.restype = i64

@@ -144,6 +144,12 @@ class OracleSlabBackend:
         d = (self.t.g.astype(np.float64) - self.t.b) if False else (self.t.g - self.t.b)
         self.scal[S_DD] = float((d.astype(np.float64) ** 2).sum())
 
+    def c_data_distance_sq_async(self, vid):
+        v = np.ascontiguousarray(self._v(vid))
+        g = np.empty_like(self.t.b)
+        oracle.lib().orc_forward(self.nslice, self.t.Nrow, self.t.Ncol, *self.t._a(), oracle._p(v), oracle._p(g))
+        self.scal[S_DD] = float(((g - self.t.b).astype(np.float64) ** 2).sum())
+
     def c_diff_norm_sq(self, a, b, slot):
         d = self._v(a) - self._v(b)
         self.scal[slot] = float((d.astype(np.float64) ** 2).sum())

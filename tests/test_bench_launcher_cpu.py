@@ -1,0 +1,40 @@
+"""``python bench.py --gpus 2`` must start its own two ranks (the driver launches it plainly) and print ONE JSON line
+with ``n_gpus = 2``.  Driven here on a CPU box: ``--backend gloo`` puts the numpy slab double of tests/slab_double.py
+behind the product's sharded engine, so what is exercised is the launcher, the rank environment, strong / weak slab
+sizes and the max-over-ranks timing -- not the kernels."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--n", "16", "--nproj", "5",
+                        "--steps", "2", "--warmup", "1", "--quick", *extra], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling,nslice,per_gpu", [("strong", 6, 3), ("weak", 3, 3), ("strong", 7, 4)])
+def test_plain_launch_spawns_ranks(scaling, nslice, per_gpu):
+    out = run_bench("--gpus", "2", "--nslice", str(nslice), "--scaling", scaling)
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 2
+    assert out["config"]["slices_per_gpu"] == per_gpu
+    assert out["config"]["volume"] == f"{nslice * (2 if scaling == 'weak' else 1)}x16x16"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and out["final_dd"] > 0 and out["final_tv"] > 0
+
+
+def test_strong_scaling_result_does_not_depend_on_rank_count():
+    """The same global volume on 2 and on 3 ranks: the iteration's global scalars agree (the composition all-reduces them)."""
+    a = run_bench("--gpus", "2", "--nslice", "6")
+    b = run_bench("--gpus", "3", "--nslice", "6")
+    assert b["n_gpus"] == 3
+    assert abs(a["final_dd"] - b["final_dd"]) <= 1e-5 * a["final_dd"] and abs(a["final_tv"] - b["final_tv"]) <= 1e-4 * a["final_tv"]

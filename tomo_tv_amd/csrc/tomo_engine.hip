@@ -29,7 +29,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define LAUNCHCHK() HIPCHK(hipGetLastError())
 #define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); if ((e)->geometry_released) return fail(TOMO_ERR_STATE, "engine geometry was released"); HIPCHK(hipSetDevice((e)->device)); } while (0)
 
-enum { PROF_MAX_KERNELS = 8, PROF_MAX_EVENTS = 1 << 19 };   // 262144 launches per kernel id between two reads
+enum { PROF_MAX_KERNELS = 12, PROF_MAX_EVENTS = 1 << 19 };   // 262144 launches per kernel id between two reads
 
 struct ProfSlot {
     bool on = false;
@@ -265,6 +265,7 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
                                e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, c0, ncp);
             LAUNCHCHK();
         }
+        ProfScope ps(e, TOMO_K_FP_REDUCE);
         int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
         int64_t items = (int64_t)e->nrows * (ncp * 16 / lpr);
         int64_t waves = (items + 64 / lpr - 1) / (64 / lpr);
@@ -388,6 +389,7 @@ static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *
             e->attr_bp = true;
         }
         const int nchunk64 = e->sxc / 64;
+        ProfScope ps(e, TOMO_K_BP_TILE);
         dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * nchunk64)), block(FT_THREADS);
         hipLaunchKernelGGL(k_bp_tile, grid, block, FB_LDS_BYTES + e->np * 4, e->stream, x, e->d_fb_cell, e->d_fb_win, r, colsum, alpha, beta, clamp,
                            e->np, e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, nchunk64);

@@ -49,7 +49,9 @@ for N, P, Nx in [(16, 5, 2), (32, 9, 4), (64, 16, 8)]:
         key = f"eps{eps:g}"
         want = ga[f"final_{key}"]
         dev = lambda tr, k: float(np.max(np.abs(tr[k] - ga[f"{k}_{key}"]) / np.abs(ga[f"{k}_{key}"])))  # noqa: E731
+        first_bad = lambda tr: int(np.argmax(np.abs(tr["dd"] - ga[f"dd_{key}"]) / ga[f"dd_{key}"] > 1e-5)) or 20  # noqa: E731
         rows.append(dict(loop="ART (cpu/sim_ASD.py)", shape=f"{N}x{P}x{Nx}", eps=eps, hip_l2=rel_l2(v_d, want),
+                         hip_first_iter_over_1e5=first_bad(tr_d), oracle_first_iter_over_1e5=first_bad(tr_o),
                          hip_dd=dev(tr_d, "dd"), hip_tv=dev(tr_d, "tv"), oracle_ulp_l2=rel_l2(v_o, want),
                          oracle_ulp_dd=dev(tr_o, "dd"), oracle_ulp_tv=dev(tr_o, "tv"),
                          hip_l2_iter1=None))
@@ -69,14 +71,18 @@ for N, P, Nx in [(16, 5, 2), (32, 9, 4), (64, 16, 8)]:
             outs.append((dd_r, tv_r, r.recon.copy()))
         (dd0, tv0, v0), (dd1, tv1, v1) = outs
         m = lambda a, b: float(np.max(np.abs(a - b) / np.abs(b)))  # noqa: E731
+        fb = lambda a, b: int(np.argmax(np.abs(a - b) / b > 1e-5)) or 20  # noqa: E731
         rows.append(dict(loop="SART (examples/sim_ASD.py)", shape=f"{N}x{P}x{Nx}", eps=eps, hip_l2=rel_l2(d.get_volume(), v0),
+                         hip_first_iter_over_1e5=fb(dd_d, dd0), oracle_first_iter_over_1e5=fb(dd1, dd0),
                          hip_dd=m(dd_d, dd0), hip_tv=m(tv_d, tv0), oracle_ulp_l2=rel_l2(v1, v0), oracle_ulp_dd=m(dd1, dd0),
                          oracle_ulp_tv=m(tv1, tv0), hip_l2_iter1=None))
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "asd_parity.json"), "w"), indent=1)
-print("| loop | N x P x Nx | eps | HIP vs oracle: rel-L2 after 20 it | dd | tv | oracle vs itself (+1 ulp on b): rel-L2 | dd | tv |")
-print("|---|---|---|---|---|---|---|---|---|")
+print("| loop | N x P x Nx | eps | HIP vs oracle: rel-L2 after 20 it | dd | tv | first it. with dd off by > 1e-5 | oracle vs itself (+1 ulp on b): rel-L2 | dd | tv | first it. |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
     print(f"| {r['loop']} | {r['shape']} | {r['eps']:g} | {r['hip_l2']:.1e} | {r['hip_dd']:.1e} | {r['hip_tv']:.1e} | "
-          f"{r['oracle_ulp_l2']:.1e} | {r['oracle_ulp_dd']:.1e} | {r['oracle_ulp_tv']:.1e} |")
+          f"{r['hip_first_iter_over_1e5'] + 1 if r['hip_first_iter_over_1e5'] < 20 else 'none'} | "
+          f"{r['oracle_ulp_l2']:.1e} | {r['oracle_ulp_dd']:.1e} | {r['oracle_ulp_tv']:.1e} | "
+          f"{r['oracle_first_iter_over_1e5'] + 1 if r['oracle_first_iter_over_1e5'] < 20 else 'none'} |")
