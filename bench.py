@@ -359,6 +359,10 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # the one JSON line goes to the real stdout; everything else a library prints there (RCCL's version banner) is sent
+    # to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -509,7 +513,8 @@ def main():
             out["secondary"] = secondary_configs()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"], out["cpu_baseline_configs"] = cpu_baselines(n, nproj)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         import torch.distributed as dist
         dist.barrier()

@@ -109,8 +109,8 @@ int main(int argc, char **argv)
     }
     REQUIRE(worst_bp == 0.0, "backward mismatch %g", worst_bp);
     // ---- fused SART step: per-angle tile segments and cells
-    const int T = 16, SMAXR = 26, MS = Tables::ST_MAXSEG;
-    build_sart_tiles(m, N, P, T, SMAXR, PIXB, t);
+    const int SY = 16, SZ = 8, SMAXR = 19, MS = Tables::ST_MAXSEG;   // = ST_TY, ST_TZ, ST_MAXR of kernels.hip.h
+    build_sart_tiles(m, N, P, SY, SZ, SMAXR, PIXB, t);
     REQUIRE(t.st_ok, "SART tile tables rejected");
     const int stz = t.st_tiles_z, snt = t.st_tiles;
     double worst_st = 0, worst_stbp = 0;
@@ -118,7 +118,7 @@ int main(int argc, char **argv)
         std::vector<double> ps(t.st_max_ids, 0.0);
         std::vector<int> wr(t.st_max_ids, 0);
         for (int k = 0; k < snt; ++k) {
-            int y0 = (k / stz) * T, z0 = (k % stz) * T;
+            int y0 = (k / stz) * SY, z0 = (k % stz) * SZ;
             bool ended = false;
             for (int q = 0; q < MS; ++q) {
                 uint32_t b0 = t.st_seg[(((size_t)i * snt + k) * MS + q) * 2], nb = t.st_seg[(((size_t)i * snt + k) * MS + q) * 2 + 1];
@@ -128,9 +128,9 @@ int main(int argc, char **argv)
                 for (uint32_t e = 0; e < nb * NB; ++e) {
                     uint32_t off = t.st_off[(size_t)b0 * NB + e]; float w = t.st_w[(size_t)b0 * NB + e];
                     uint32_t lp = off / PIXB;
-                    REQUIRE(off % PIXB == 0 && lp <= (uint32_t)(T * T), "bad SART entry offset");
-                    if (lp == (uint32_t)(T * T)) { REQUIRE(w == 0.f, "padding with weight"); continue; }
-                    int y = y0 + lp / T, z = z0 + lp % T;
+                    REQUIRE(off % PIXB == 0 && lp <= (uint32_t)(SY * SZ), "bad SART entry offset");
+                    if (lp == (uint32_t)(SY * SZ)) { REQUIRE(w == 0.f, "padding with weight"); continue; }
+                    int y = y0 + lp / SZ, z = z0 + lp % SZ;
                     REQUIRE(y < N && z < N, "SART entry outside the image");
                     acc += (double)w * x[(int64_t)y * N + z];
                 }
@@ -141,9 +141,9 @@ int main(int argc, char **argv)
             // cells against the cell table
             uint32_t w = t.st_win[(size_t)i * snt + k], lo = w & 0xFFFFu, nr = w >> 16;
             REQUIRE(nr <= (uint32_t)SMAXR, "SART window too wide");
-            for (int lp = 0; lp < T * T; ++lp) {
-                int y = y0 + lp / T, z = z0 + lp % T;
-                const Tables::TileCell &c = t.st_cell[((size_t)i * snt + k) * (T * T) + lp];
+            for (int lp = 0; lp < SY * SZ; ++lp) {
+                int y = y0 + lp / SZ, z = z0 + lp % SZ;
+                const Tables::TileCell &c = t.st_cell[((size_t)i * snt + k) * (SY * SZ) + lp];
                 double a = 0, ref = 0;
                 for (int h = 0; h < 2; ++h) {
                     uint32_t off = h ? c.off1 : c.off0; float wt = h ? c.w1 : c.w0;

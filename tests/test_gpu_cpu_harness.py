@@ -240,7 +240,8 @@ def test_create_projections_snr_branch_and_update_proj_angles(gpu, golden):
     ref.original_volume = vol
     ref.create_projections()
     total = float(ref.b.astype(np.float64).sum())
-    assert abs(float(noisy.astype(np.float64).sum()) - total) <= 1e-5 * total
+    # the total is preserved in expectation: sum(noisy) = total * (sum of the draws) / (Nc * size), 3 sigma here
+    assert abs(float(noisy.astype(np.float64).sum()) - total) <= 3.0 / np.sqrt(100.0 * noisy.size) * total
     ref.poisson_noise(100)
     # same seed, same formula: the draws agree except where a rate sits within rounding of a sampler threshold
     differ = np.abs(noisy - ref.b) > 1e-4 * ref.b.max()

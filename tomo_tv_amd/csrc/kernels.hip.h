@@ -710,7 +710,16 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
 // (consecutive ids, ascending tile) and forms the residual.  Per angle: the slab read once and written once, plus ~9 % for the partials.
 // Two workgroups per CU (75 KB LDS each) overlap one's streaming with the other's LDS phase.  In-place is safe: a
 // workgroup reads and writes only its own tile.
-constexpr int ST_T = 16, ST_PIX = ST_T * ST_T, ST_THREADS = 512, ST_MAXR = 26, ST_MAXSEG = 32;
+// Tile shape: ST_TY rows x ST_TZ columns.  Tilt series cover about -70..70 degrees, so rays run closer to the y axis than to
+// the z axis (E|cos| = 0.77, E|sin| = 0.54): a tall tile is crossed by fewer rays per pixel (16 x 8: 14.8 segments per
+// 128 pixels; 16 x 16: 20.9 per 256).  The 16 x 8 tile needs 40 KB of LDS, so FOUR workgroups of 256 threads share a CU
+// (the 16 x 16 form: 75 KB, two of 512): the same bytes in flight per CU, but four independent load / update / project
+// phases to interleave -- the kernel is bound by how well those phases overlap, not by HBM (a 128-slice slab that sits
+// in the 256 MB Infinity Cache runs at the same rate per byte).
+constexpr int ST_TY = 16, ST_TZ = 8, ST_PIX = ST_TY * ST_TZ, ST_THREADS = 256, ST_MAXR = 19, ST_MAXSEG = 32;
+constexpr int ST_NG = ST_THREADS / 16, ST_SPG = ST_MAXSEG / ST_NG;   // 16-lane groups; ray segments per group
+constexpr int ST_MAXB = (ST_TY + ST_TZ - 1 + 7) / 8;                 // entry batches of the longest segment (TY + TZ - 1 pixels)
+static_assert(ST_PIX == ST_NG * 8, "a group owns 8 pixels");
 constexpr int ST_LDS_V = (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16 + ST_PIX;     // image + zero pixel, window + zero row, cells
 
 template <bool FUSED>
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
                                                            int n, int sx, int tiles_z, int ntiles, int nchunk)
 {
     typedef VecOf<4>::T V;
-    extern __shared__ V st_lds[];                       // ST_LDS_V float4 (75 KB: dynamic)
+    extern __shared__ V st_lds[];                       // ST_LDS_V float4 (dynamic)
     V *img = st_lds, *win = st_lds + (ST_PIX + 1) * 16;
     uint4 *cel = reinterpret_cast<uint4 *>(st_lds + (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16);
     // the chunks of a tile run back to back on one XCD (workgroups b and b+8 share an XCD): they stream the same
@@ -734,29 +743,33 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     const int ty = tile / tiles_z, tz = tile - ty * tiles_z;
     const int t = threadIdx.x, gl = t & 15, g = t >> 4;
     const int off = c * 64 + gl * 4;
-    // the group's 8 pixels: row g/2 of the tile, columns (g&1)*8 .. +7
-    const int y = ty * ST_T + (g >> 1), z0 = tz * ST_T + (g & 1) * 8;
-    // the group's ray segment of "next" and all its entry batches (<= 4: a ray crosses <= 31 pixels of a 16x16 tile) are
-    // fetched first, so the forward-projection phase at the end touches LDS only (its two dependent loads cost 10 us
-    // per launch when issued there)
-    const uint2 sd = segs[(size_t)tile * ST_MAXSEG + g];
-    const uint32_t pid = segid[(size_t)tile * ST_MAXSEG + g];
+    // the group's 8 pixels: local indices g*8 .. g*8+7 (y-major inside the tile)
+    const int y = ty * ST_TY + (g * 8) / ST_TZ, z0 = tz * ST_TZ + (g * 8) % ST_TZ;
+    // the group's ray segments of "next" and all their entry batches are fetched first, so the forward-projection phase
+    // at the end touches LDS only (its two dependent loads cost 10 us per launch when issued there)
+    uint2 sd[ST_SPG];
+    uint32_t pid[ST_SPG];
+#pragma unroll
+    for (int q = 0; q < ST_SPG; ++q) {
+        sd[q] = segs[(size_t)tile * ST_MAXSEG + g + q * ST_NG];
+        pid[q] = segid[(size_t)tile * ST_MAXSEG + g + q * ST_NG];
+    }
     V xv[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
         xv[J] = (y < n && z0 + J < n) ? *reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off) : vzero<4>();
-    constexpr int ST_MAXB = 4;
-    uint2 eb[ST_MAXB];
-    {
-        const uint2 *ep = ent + (size_t)sd.x * FT_BATCH + (gl & 7);
+    uint2 eb[ST_SPG][ST_MAXB];
 #pragma unroll
-        for (int b = 0; b < ST_MAXB; ++b) eb[b] = ((uint32_t)b < sd.y) ? ep[(size_t)b * FT_BATCH] : make_uint2((uint32_t)ST_PIX * 256u, 0u);
+    for (int q = 0; q < ST_SPG; ++q) {
+        const uint2 *ep = ent + (size_t)sd[q].x * FT_BATCH + (gl & 7);
+#pragma unroll
+        for (int b = 0; b < ST_MAXB; ++b) eb[q][b] = ((uint32_t)b < sd[q].y) ? ep[(size_t)b * FT_BATCH] : make_uint2((uint32_t)ST_PIX * 256u, 0u);
     }
     if (FUSED) {
         uint32_t w = wins[tile];
-        if (t < (ST_MAXR + 1) * 16) {
-            int j = t >> 4;
-            win[t] = ((uint32_t)j < (w >> 16)) ? *reinterpret_cast<const V *>(r_prev + ((size_t)(w & 0xFFFFu) + j) * sx + off) : vzero<4>();
+        for (int i = t; i < (ST_MAXR + 1) * 16; i += ST_THREADS) {
+            int j = i >> 4;
+            win[i] = ((uint32_t)j < (w >> 16)) ? *reinterpret_cast<const V *>(r_prev + ((size_t)(w & 0xFFFFu) + j) * sx + c * 64 + (i & 15) * 4) : vzero<4>();
         }
         if (t < ST_PIX) cel[t] = cells[(size_t)tile * ST_PIX + t];
     }
@@ -782,36 +795,39 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
 #pragma unroll
     for (int J = 0; J < 8; ++J) img[(g * 8 + J) * 16 + gl] = xv[J];
     __syncthreads();
-    // forward projection of "next": group g owns the tile's g-th ray segment
-    if (sd.y == 0) return;                                // uniform inside a 16-lane DPP row
+    // forward projection of "next": group g owns the tile's ray segments g, g + ST_NG, ...
     const char *ib = reinterpret_cast<const char *>(img) + gl * 16;
-    V acc = vzero<4>();
-#define ST_LOAD(J) q[J] = *reinterpret_cast<const V *>(ib + row_ror<J>(e.x));
-#define ST_FMA(J) acc += __uint_as_float(row_ror<J>(e.y)) * q[J];
+#define ST_LOAD(J) q_[J] = *reinterpret_cast<const V *>(ib + row_ror<J>(e.x));
+#define ST_FMA(J) acc += __uint_as_float(row_ror<J>(e.y)) * q_[J];
 #pragma unroll
-    for (int b = 0; b < ST_MAXB; ++b) {
-        if ((uint32_t)b < sd.y) {
-            uint2 e = eb[b];
-            V q[FT_BATCH];
-            ST_LOAD(0) ST_LOAD(1) ST_LOAD(2) ST_LOAD(3) ST_LOAD(4) ST_LOAD(5) ST_LOAD(6) ST_LOAD(7)
-            ST_FMA(0) ST_FMA(1) ST_FMA(2) ST_FMA(3) ST_FMA(4) ST_FMA(5) ST_FMA(6) ST_FMA(7)
+    for (int q = 0; q < ST_SPG; ++q) {
+        if (sd[q].y == 0) continue;                       // uniform inside a 16-lane DPP row
+        V acc = vzero<4>();
+#pragma unroll
+        for (int b = 0; b < ST_MAXB; ++b) {
+            if ((uint32_t)b < sd[q].y) {
+                uint2 e = eb[q][b];
+                V q_[FT_BATCH];
+                ST_LOAD(0) ST_LOAD(1) ST_LOAD(2) ST_LOAD(3) ST_LOAD(4) ST_LOAD(5) ST_LOAD(6) ST_LOAD(7)
+                ST_FMA(0) ST_FMA(1) ST_FMA(2) ST_FMA(3) ST_FMA(4) ST_FMA(5) ST_FMA(6) ST_FMA(7)
+            }
         }
+        if (sd[q].y > ST_MAXB) {                          // longer segments (only a user matrix can have them)
+            const uint2 *ep = ent + (size_t)sd[q].x * FT_BATCH + (gl & 7);
+            for (uint32_t b = ST_MAXB; b < sd[q].y; ++b) {
+                uint2 e = ep[(size_t)b * FT_BATCH];
+#pragma unroll
+                for (int J = 0; J < 8; ++J) {
+                    // generic lane exchange (__shfl) instead of the compile-time DPP rotation: rare path
+                    uint32_t ox = (uint32_t)__shfl((int)e.x, (gl + J) & 7, 16), wy = (uint32_t)__shfl((int)e.y, (gl + J) & 7, 16);
+                    acc += __uint_as_float(wy) * *reinterpret_cast<const V *>(ib + ox);
+                }
+            }
+        }
+        *reinterpret_cast<V *>(partial + (size_t)pid[q] * sx + off) = acc;
     }
 #undef ST_FMA
 #undef ST_LOAD
-    if (sd.y > ST_MAXB) {                                 // longer segments (only a user matrix can have them)
-        const uint2 *ep = ent + (size_t)sd.x * FT_BATCH + (gl & 7);
-        for (uint32_t b = ST_MAXB; b < sd.y; ++b) {
-            uint2 e = ep[(size_t)b * FT_BATCH];
-#pragma unroll
-            for (int J = 0; J < 8; ++J) {
-                // generic lane exchange (__shfl) instead of the compile-time DPP rotation: rare path
-                uint32_t ox = (uint32_t)__shfl((int)e.x, (gl + J) & 7, 16), wy = (uint32_t)__shfl((int)e.y, (gl + J) & 7, 16);
-                acc += __uint_as_float(wy) * *reinterpret_cast<const V *>(ib + ox);
-            }
-        }
-    }
-    *reinterpret_cast<V *>(partial + (size_t)pid * sx + off) = acc;
 }
 
 // ---- back-projector, all angles, tile-stationary form ------------------------------------------------------------
@@ -1701,6 +1717,7 @@ __global__ __launch_bounds__(256) void k_fgp_grad(const float *__restrict__ D, f
 // iteration instead of the two of the Obj / Grad pair (tv_fgp.cu:57,81; mpi_ctvlib.cpp:400-422).
 struct FgpEdge { const float *p1_lo; const float *hi; float *send_first; float *send_last; int first, last; };
 
+template <bool SHARDED>
 __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, const float *__restrict__ P1i,
                                                     const float *__restrict__ P2i, const float *__restrict__ P3i,
                                                     float *__restrict__ P1o, float *__restrict__ P2o,
@@ -1720,6 +1737,10 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
     // fid: 0 = A, 1..3 = P1..P3 (the plane order of the hi / send_first buffers)
     auto ld = [&](const float *__restrict__ f, int fid, int y, int zi, int si) -> float {
         int z = z0 - 1 + zi, s = s0 - 1 + si;
+        if (!SHARDED) {      // single slab: every face is a global edge (the form measured at 821 us per iteration)
+            if (y < 0 || y >= n || z < 0 || z >= n || s < 0 || s >= nx) return 0.f;
+            return f[(size_t)(y * n + z) * sx + s];
+        }
         if (y < 0 || y >= n || z < 0 || z >= n) return 0.f;
         if (s < 0) return (fid == 1 && !ed.first && s == -1) ? ed.p1_lo[y * n + z] : 0.f;
         if (s >= nx) return (!ed.last && s == nx) ? ed.hi[fid * npix + y * n + z] : 0.f;
@@ -1797,7 +1818,7 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
             int z = z0 + zq, s = s0 + sq;
             if (z < n && s < nx) {
                 float dc = dl[par][zq][sq];
-                float v1 = (s + 1 < nx || !ed.last) ? dc - dl[par][zq][sq + 1] : 0.f;
+                float v1 = (s + 1 < nx || (SHARDED && !ed.last)) ? dc - dl[par][zq][sq + 1] : 0.f;
                 float v2 = y + 1 < n ? dc - dl[nxt][zq][sq] : 0.f;
                 float v3 = z + 1 < n ? dc - dl[par][zq + 1][sq] : 0.f;
                 float a = keep[q][0] + multip * v1, b = keep[q][1] + multip * v2, c = keep[q][2] + multip * v3;
@@ -1808,7 +1829,7 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
                 }
                 size_t o = (size_t)(y * n + z) * sx + s;
                 P1o[o] = a; P2o[o] = b; P3o[o] = c;
-                if (ed.send_first) {
+                if (SHARDED) {
                     const size_t pix = (size_t)y * n + z;
                     if (s == 0) { ed.send_first[npix + pix] = a; ed.send_first[2 * npix + pix] = b; ed.send_first[3 * npix + pix] = c; }
                     if (s == nx - 1) ed.send_last[pix] = a;

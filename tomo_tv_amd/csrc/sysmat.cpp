@@ -566,19 +566,19 @@ void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows
 }
 
 // Per-angle tile tables of the fused SART step (see sysmat.h); needs t.cell (build_tables).
-void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel_bytes, Tables &t)
+void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, int pixel_bytes, Tables &t)
 {
     constexpr int NB = Tables::TILE_BATCH, MS = Tables::ST_MAXSEG;
     const int64_t nrows = (int64_t)N * P, npix = (int64_t)N * N;
-    const int tiles_1d = (N + T - 1) / T;
-    const uint32_t ntiles = (uint32_t)tiles_1d * tiles_1d;
-    const int TP = T * T;
-    t.st_t = T; t.st_tiles = (int)ntiles; t.st_tiles_z = tiles_1d; t.st_maxr = max_rows;
+    const int tiles_y = (N + TY - 1) / TY, tiles_z = (N + TZ - 1) / TZ;
+    const uint32_t ntiles = (uint32_t)tiles_y * tiles_z;
+    const int TP = TY * TZ;
+    t.st_ty = TY; t.st_tz = TZ; t.st_tiles = (int)ntiles; t.st_tiles_z = tiles_z; t.st_maxr = max_rows;
     const uint32_t zero_row = (uint32_t)max_rows * (uint32_t)pixel_bytes, zero_pix = (uint32_t)TP * (uint32_t)pixel_bytes;
     std::vector<uint32_t> tmp_lpix;
     std::vector<float> tmp_w;
     std::vector<std::vector<RowSeg>> rsegs;
-    split_rows_by_tile(m, N, nrows, T, T, tiles_1d, tmp_lpix, tmp_w, rsegs);
+    split_rows_by_tile(m, N, nrows, TY, TZ, tiles_z, tmp_lpix, tmp_w, rsegs);
     t.st_cell.assign((size_t)P * ntiles * TP, Tables::TileCell{zero_row, 0.f, zero_row, 0.f});
     t.st_win.assign((size_t)P * ntiles, 0);
     t.st_segid.assign((size_t)P * ntiles * MS, 0);
@@ -635,10 +635,10 @@ void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel
             // ray windows and cells
             const Cell *ci = t.cell.data() + (size_t)i * npix;
             for (uint32_t k = 0; k < ntiles; ++k) {
-                int y0 = (int)(k / tiles_1d) * T, z0 = (int)(k % tiles_1d) * T;
+                int y0 = (int)(k / tiles_z) * TY, z0 = (int)(k % tiles_z) * TZ;
                 uint32_t lo = 0xFFFFFFFFu, hi = 0;
-                for (int ly = 0; ly < T && y0 + ly < N; ++ly)
-                    for (int lz = 0; lz < T && z0 + lz < N; ++lz) {
+                for (int ly = 0; ly < TY && y0 + ly < N; ++ly)
+                    for (int lz = 0; lz < TZ && z0 + lz < N; ++lz) {
                         const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
                         if (c.w0 != 0.f) { lo = std::min(lo, c.r0); hi = std::max(hi, c.r0); }
                         if (c.w1 != 0.f) { lo = std::min(lo, c.r1); hi = std::max(hi, c.r1); }
@@ -648,10 +648,10 @@ void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel
                 if (nr > (uint32_t)max_rows) { bad[i] = 1; continue; }
                 t.st_win[(size_t)i * ntiles + k] = lo | (nr << 16);
                 Tables::TileCell *out = t.st_cell.data() + ((size_t)i * ntiles + k) * TP;
-                for (int ly = 0; ly < T && y0 + ly < N; ++ly)
-                    for (int lz = 0; lz < T && z0 + lz < N; ++lz) {
+                for (int ly = 0; ly < TY && y0 + ly < N; ++ly)
+                    for (int lz = 0; lz < TZ && z0 + lz < N; ++lz) {
                         const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
-                        Tables::TileCell &o = out[ly * T + lz];
+                        Tables::TileCell &o = out[ly * TZ + lz];
                         if (c.w0 != 0.f) { o.off0 = (c.r0 - lo) * (uint32_t)pixel_bytes; o.w0 = c.w0; }
                         if (c.w1 != 0.f) { o.off1 = (c.r1 - lo) * (uint32_t)pixel_bytes; o.w1 = c.w1; }
                     }

@@ -64,7 +64,7 @@ struct Tables {
     bool bp_tile_ok = false;                     // false: some window exceeds max_rows (kernel falls back)
     std::vector<uint32_t> bp_win;                // [ntiles * P]  first ray | rays << 16
     std::vector<TileCell> bp_cell;               // [(ntiles * P + pad) * TY*TZ], pixel order inside a tile: y-major
-    // Per-angle tile tables of the fused SART step (k_sart_tile): square tiles of st_t pixels, angle-major.
+    // Per-angle tile tables of the fused SART step (k_sart_tile): tiles of st_ty x st_tz pixels, angle-major.
     //   st_cell[(i*ntiles + tile)*T*T + pixel]  rays of angle i through the pixel as byte offsets into the tile's
     //                                           staged ray window (zero row = row st_maxr)
     //   st_win[i*ntiles + tile]                 first ray | rays << 16 of that window
@@ -74,7 +74,7 @@ struct Tables {
     //   st_off / st_w                           entry batches (TILE_BATCH entries, zero-weight padding -> zero pixel)
     static constexpr int ST_MAXSEG = 32;
     bool st_ok = false;
-    int st_t = 0, st_tiles = 0, st_tiles_z = 0, st_maxr = 0;
+    int st_ty = 0, st_tz = 0, st_tiles = 0, st_tiles_z = 0, st_maxr = 0;
     uint32_t st_max_ids = 0;                     // most partial sums of one angle
     std::vector<TileCell> st_cell;
     std::vector<uint32_t> st_win, st_segid, st_off, st_row_first, st_row_nseg;
@@ -90,7 +90,7 @@ bool build_tables(const Coo &m, int N, int P, Tables &t, std::string &err);
 void build_walk(const Coo &m, int N, int P, Tables &t);
 void build_segments(int N, int P, int seg_len, Tables &t);
 void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t);
-void build_sart_tiles(const Coo &m, int N, int P, int T, int max_rows, int pixel_bytes, Tables &t);
+void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, int pixel_bytes, Tables &t);
 void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t);
 
 }  // namespace tomo

@@ -488,7 +488,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_ft_rsptr, t.rseg_ptr.data(), t.rseg_ptr.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
         release(tent); release(t.tile_off); release(t.tile_w); release(t.rseg_idx); release(t.rseg_ptr); release(t.tile_slot_ptr); release(t.tile_slot_seg0);
-        build_sart_tiles(m, e->n, e->np, ST_T, ST_MAXR, 256, t);
+        build_sart_tiles(m, e->n, e->np, ST_TY, ST_TZ, ST_MAXR, 256, t);
         static_assert(Tables::ST_MAXSEG == ST_MAXSEG, "segment slots per tile");
         e->st_ok = t.st_ok;
         if (e->st_ok) {
@@ -1680,8 +1680,12 @@ int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration)
     if (fgp_sharded(e)) { ed.p1_lo = e->fgp_lo; ed.hi = e->fgp_hi; ed.send_first = e->fgp_send_first; ed.send_last = e->fgp_send_last; }
     {
         ProfScope ps(e, TOMO_K_FGP_GRAD);
-        hipLaunchKernelGGL(k_fgp_fused, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
-                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0, ed);
+        if (fgp_sharded(e))
+            hipLaunchKernelGGL(k_fgp_fused<true>, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                               e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0, ed);
+        else
+            hipLaunchKernelGGL(k_fgp_fused<false>, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                               e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0, ed);
     }
     LAUNCHCHK();
     for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
