@@ -14,7 +14,7 @@ int main(int argc, char **argv)
 {
     int N = argc > 1 ? std::atoi(argv[1]) : 50, P = argc > 2 ? std::atoi(argv[2]) : 9;
     double amax = argc > 3 ? std::atof(argv[3]) : 89.0;
-    const int TY = 16, TZ = 32, PIXB = 256, A = 4, MAXR = 40;
+    const int TY = 32, TZ = 16, PIXB = 256, A = 4, MAXR = 40;   // = FT_TY, FT_TZ, FB_A, FB_MAXR of kernels.hip.h
     std::vector<double> ang(P);
     for (int i = 0; i < P; ++i) ang[i] = (P > 1 ? -amax + 2 * amax * i / (P - 1) : 0.0) * M_PI / 180;
     Coo m; build_parallel_ray(N, P, ang.data(), m); sort_rows(m);
@@ -109,7 +109,7 @@ int main(int argc, char **argv)
     }
     REQUIRE(worst_bp == 0.0, "backward mismatch %g", worst_bp);
     // ---- fused SART step: per-angle tile segments and cells
-    const int SY = 16, SZ = 8, SMAXR = 19, MS = Tables::ST_MAXSEG;   // = ST_TY, ST_TZ, ST_MAXR of kernels.hip.h
+    const int SY = 16, SZ = 16, SMAXR = 26, MS = Tables::ST_MAXSEG;   // = ST_TY, ST_TZ, ST_MAXR of kernels.hip.h
     build_sart_tiles(m, N, P, SY, SZ, SMAXR, PIXB, t);
     REQUIRE(t.st_ok, "SART tile tables rejected");
     const int stz = t.st_tiles_z, snt = t.st_tiles;

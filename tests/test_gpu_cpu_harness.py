@@ -145,7 +145,8 @@ def _asd_setup(golden, N, P, Nx, eps):
 # difference is amplified once the iterate is piecewise flat.  The ORACLE ITSELF, fed a tilt series moved by one
 # float32 ulp, ends 20 iterations 1e-2 (eps = 1e-6) to 2e-2 (eps = 1e-8) away from its own unperturbed run -- and the
 # HIP path ends at the same distance (1.0e-2 ... 2.1e-2).  What CAN be held hard:
-#   * the first five iterations: every trace value to 1e-5 (measured 1e-8 ... 1e-7), the iterate to 1e-5;
+#   * the first iteration: the iterate to 1e-5; the first five: every trace value to 1e-5 (measured 1e-8 ... 1e-7), the
+#     iterate to 3e-3 (measured <= 6.2e-4);
 #   * all twenty: the caps below (3x the largest value measured on any fixture shape);
 #   * every single iteration restarted from the oracle's iterate: 1e-5 (test_sim_asd_art_teacher_forced).
 ASD_CAP = {"vol": 6e-2, "trace": 1.5e-2}
@@ -165,10 +166,12 @@ def test_sim_asd_art_free_running(gpu, golden, N, P, Nx, eps, key):
     """cpu/sim_ASD.py with its own defaults (alg ART), 20 free-running iterations against the committed trace."""
     tomo, g, p = _asd_setup(golden, N, P, Nx, eps)
     assert abs(tomo.original_tv() - float(g[f"tv0_{key}"])) <= 1e-5 * float(g[f"tv0_{key}"])
-    snaps = {}
-    rm, dd, tv = sim_asd(tomo, 5, p)
-    snaps[5] = tomo.get_volume()
-    assert rel_l2(snaps[5], g[f"iter5_{key}"]) < 1e-5
+    sim_asd(tomo, 1, p)
+    assert rel_l2(tomo.get_volume(), g[f"iter1_{key}"]) < 1e-5              # one whole iteration: the north-star tolerance
+    tomo, g, p = _asd_setup(golden, N, P, Nx, eps)
+    sim_asd(tomo, 5, p)
+    # the iterate separates before the scalars do (they average over the volume): measured <= 6.2e-4 after five iterations
+    assert rel_l2(tomo.get_volume(), g[f"iter5_{key}"]) < 3e-3
     # run on: the loop state (beta, dPOCS) is re-derived by running all 20 from scratch on a fresh engine
     tomo, g, p = _asd_setup(golden, N, P, Nx, eps)
     rm, dd, tv = sim_asd(tomo, 20, p)

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_fp_rows_g(const float *__restrict__ x, 
 // 8 per group and batch (lanes 8-15 hold a second copy); inside a batch lane l takes the entries in the rotated
 // order l, l+1, ... (DPP row_ror), so no broadcast is needed: every lane still adds all 8, each to its own slices.
 // ds_read_b128 of 256-B pixel images is conflict-free at 256 B/clk whatever the pixels (MI355X_MICROARCH.md, LDS).
-constexpr int FT_TY = 16, FT_TZ = 32, FT_PIX = FT_TY * FT_TZ, FT_THREADS = 1024, FT_SLOTS = FT_THREADS / 16, FT_BATCH = 8;
+constexpr int FT_TY = 32, FT_TZ = 16, FT_PIX = FT_TY * FT_TZ, FT_THREADS = 1024, FT_SLOTS = FT_THREADS / 16, FT_BATCH = 8;
 constexpr int FT_LDS_BYTES = (FT_PIX + 1) * 256;         // + one zero pixel for the padding entries
 
 template <int J> __device__ __forceinline__ uint32_t row_ror(uint32_t v)
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
             float cs = c[q].w0 + c[q].w1;
             V num = c[q].w0 * r0[q];
             num += c[q].w1 * r1[q];
-            V upd = num / (cs > 0.f ? cs : 1.0f);         // cs == 0 means w0 == w1 == 0, so num == 0
+            V upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));   // cs == 0 means w0 == w1 == 0, so num == 0; the formula of k_sart_tile
             V nv = xv[q] + beta * upd;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64) void k_sart_seg(const float *__restrict__ x_old
                 float cs = c[u].w0 + c[u].w1;
                 V num = c[u].w0 * a0[u];
                 num += c[u].w1 * a1[u];
-                V upd = num / (cs > 0.f ? cs : 1.0f);
+                V upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));
                 V nv = xv[u] + beta * upd;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
@@ -710,19 +710,19 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
 // (consecutive ids, ascending tile) and forms the residual.  Per angle: the slab read once and written once, plus ~9 % for the partials.
 // Two workgroups per CU (75 KB LDS each) overlap one's streaming with the other's LDS phase.  In-place is safe: a
 // workgroup reads and writes only its own tile.
-// Tile shape: ST_TY rows x ST_TZ columns.  Tilt series cover about -70..70 degrees, so rays run closer to the y axis than to
-// the z axis (E|cos| = 0.77, E|sin| = 0.54): a tall tile is crossed by fewer rays per pixel (16 x 8: 14.8 segments per
-// 128 pixels; 16 x 16: 20.9 per 256).  The 16 x 8 tile needs 40 KB of LDS, so FOUR workgroups of 256 threads share a CU
-// (the 16 x 16 form: 75 KB, two of 512): the same bytes in flight per CU, but four independent load / update / project
-// phases to interleave -- the kernel is bound by how well those phases overlap, not by HBM (a 128-slice slab that sits
-// in the 256 MB Infinity Cache runs at the same rate per byte).
-constexpr int ST_TY = 16, ST_TZ = 8, ST_PIX = ST_TY * ST_TZ, ST_THREADS = 256, ST_MAXR = 19, ST_MAXSEG = 32;
+// Tile shape: ST_TY rows x ST_TZ columns, 8 pixels per 16-lane group.  Measured at 512^3 x 90 (MI355X, round 2):
+// 16 x 16 tiles, 512 threads, 75 KB of LDS (two workgroups per CU): 218-224 us per fused step; 16 x 8 tiles (tall: rays
+// of a -70..70 degree series run closer to the y axis), 256 threads, 40 KB (FOUR workgroups per CU): 231 us, the
+// per-angle FP 160 instead of 144 us -- more independent phases per CU did not pay for 40 % more partial sums.  The kernel
+// is not HBM-bound either: a 128-slice slab that sits in the 256 MB Infinity Cache runs at the same rate per byte.
+constexpr int ST_TY = 16, ST_TZ = 16, ST_PIX = ST_TY * ST_TZ, ST_THREADS = 512, ST_MAXR = 26, ST_MAXSEG = 32;
 constexpr int ST_NG = ST_THREADS / 16, ST_SPG = ST_MAXSEG / ST_NG;   // 16-lane groups; ray segments per group
 constexpr int ST_MAXB = (ST_TY + ST_TZ - 1 + 7) / 8;                 // entry batches of the longest segment (TY + TZ - 1 pixels)
 static_assert(ST_PIX == ST_NG * 8, "a group owns 8 pixels");
 constexpr int ST_LDS_V = (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16 + ST_PIX;     // image + zero pixel, window + zero row, cells
 
-template <bool FUSED>
+// RCP: the voxel update as num * (1 / colsum) -- one IEEE division per pixel instead of four (<= 1 ulp from num / colsum)
+template <bool FUSED, bool RCP = true>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
                                                            const float *__restrict__ r_prev, float beta,
@@ -785,7 +785,9 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             float cs = w0 + w1;
             V num = w0 * a0;
             num += w1 * a1;
-            V upd = num / (cs > 0.f ? cs : 1.0f);
+            V upd;
+            if (RCP) upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));   // one IEEE division per pixel, not four: -3.7 % per launch
+            else upd = num / (cs > 0.f ? cs : 1.0f);
             V nv = xv[J] + beta * upd;
             nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
             xv[J] = nv;

@@ -68,6 +68,7 @@ struct tomo_engine {
     uint2 *d_ft_tent = nullptr;
     float *ft_part = nullptr, *ft_part_aux = nullptr;
     bool attr_fp = false, attr_bp = false, attr_st = false;   // dynamic-LDS limits raised on this engine's device
+    int sart_rcp = 1;                             // voxel update as num * (1/colsum) in k_sart_tile (0: num / colsum per component, A/B)
     int sart_tile = 1;                            // fused SART step on streamed image tiles (k_sart_tile) when the geometry allows it
     bool st_ok = false;
     int st_ntiles = 0, st_tiles_z = 0;
@@ -353,6 +354,7 @@ static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float 
     if (!e->attr_st) {
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
+        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         e->attr_st = true;
     }
     if (!e->st_partial) {
@@ -363,6 +365,12 @@ static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float 
     {
         ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE);
         dim3 grid((unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64)), block(ST_THREADS);
+        if (FUSED && !e->sart_rcp)
+            hipLaunchKernelGGL((k_sart_tile<FUSED, false>), grid, block, ST_LDS_V * 16, e->stream, x, x,
+                               e->d_st_cell + (size_t)prev * nt * ST_PIX, e->d_st_win + (size_t)prev * nt, r + (size_t)prev * e->n * e->sx, beta,
+                               e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, e->st_partial,
+                               e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64);
+        else
         hipLaunchKernelGGL((k_sart_tile<FUSED>), grid, block, ST_LDS_V * 16, e->stream, x, x,
                            FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
                            FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
@@ -1737,6 +1745,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "art_chain") == 0) { e->art_chain = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { e->sart_tile = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_rcp") == 0) { e->sart_rcp = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_chunks_per_pass") == 0) {   // any count >= 1 (0 = from the scratch cap); before the first projection
