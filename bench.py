@@ -153,28 +153,46 @@ class KernelLog:
             _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
 
     def read(self):
+        """name -> (launches, summed launch durations in ms, ms during which at least one launch was executing)."""
         import ctypes
         out = {}
         for name, kid in self.ids.items():
-            launches, total_ms = ctypes.c_int64(0), ctypes.c_double(0)
-            self._lib.check(self.t.be.L.tomo_profile_read(self.t.be.h, kid, ctypes.byref(launches), ctypes.byref(total_ms)))
+            launches, total_ms, busy_ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+            self._lib.check(self.t.be.L.tomo_profile_read2(self.t.be.h, kid, ctypes.byref(launches), ctypes.byref(total_ms),
+                                                           ctypes.byref(busy_ms)))
             self._lib.check(self.t.be.L.tomo_profile_enable(self.t.be.h, kid, 0))
-            out[name] = (int(launches.value), float(total_ms.value))
+            out[name] = (int(launches.value), float(total_ms.value), float(busy_ms.value))
         return out
 
 
-def roof(name, cnt, tot_ms, alg_bytes, flops=None, lds_bytes=None):
+def roof(name, cnt, tot_ms, alg_bytes, flops=None, lds_bytes=None, busy_ms=None):
+    """``alg_bytes``: algorithmic bytes of ONE launch.  Launches of one kernel may overlap (the SART sweep runs two sub-slabs
+    on two streams): ``achieved`` is then all launches' bytes over the time at least one of them was executing
+    (``busy_ms``); ``avg_ms`` stays the mean duration of a launch (what rocprofv3 prints), ``achieved_per_launch`` the
+    bytes of a launch over that duration (a launch that shares the chip with its twin)."""
     avg_ms = tot_ms / cnt if cnt else 0.0
-    ach = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    busy = busy_ms if busy_ms else tot_ms
+    ach = alg_bytes * cnt / (busy * 1e-3) / 1e9 if busy > 0 else 0.0
     r = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "traffic": None, "launches": cnt, "avg_ms": avg_ms, "total_ms": tot_ms, "algorithmic_bytes_per_launch": alg_bytes}
-    if flops is not None and avg_ms > 0:      # kernels that are not HBM-bound: the other two roofs (SURVEY.md 8d caveat)
-        r["valu_tflops"] = flops / (avg_ms * 1e-3) / 1e12
+         "traffic": None, "launches": cnt, "avg_ms": avg_ms, "total_ms": tot_ms, "busy_ms": busy,
+         "launches_in_flight": tot_ms / busy if busy > 0 else 0.0, "algorithmic_bytes_per_launch": alg_bytes,
+         "achieved_per_launch": alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0}
+    eff_ms = busy / cnt if cnt else 0.0
+    if flops is not None and eff_ms > 0:      # kernels that are not HBM-bound: the other two roofs (SURVEY.md 8d caveat)
+        r["valu_tflops"] = flops / (eff_ms * 1e-3) / 1e12
         r["valu_frac"] = r["valu_tflops"] / VALU_PEAK_TFLOPS
-    if lds_bytes is not None and avg_ms > 0:
-        r["lds_gbs"] = lds_bytes / (avg_ms * 1e-3) / 1e9
+    if lds_bytes is not None and eff_ms > 0:
+        r["lds_gbs"] = lds_bytes / (eff_ms * 1e-3) / 1e9
         r["lds_frac"] = r["lds_gbs"] / LDS_PEAK_GBS
     return r
+
+
+def sart_sub_slabs(nloc, opts=()):
+    """How many sub-slabs (streams) the engine runs a SART sweep of ``nloc`` slices on (tomo_engine.hip: sart_impl)."""
+    sxc = (nloc + 63) // 64 * 64
+    vec = 4 if sxc % 256 == 0 else 2 if sxc % 128 == 0 else 1
+    on = any(o.replace(" ", "") == "sart_streams=2" for o in opts)        # the engine's default is one chain
+    return 2 if (sxc // (64 * vec) >= 2 and on) else 1
 
 
 def attach_traffic(roofs, shape):
@@ -233,10 +251,11 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     t.initialize_SART("sequential")
     log = KernelLog(t, {"k_sart_tile<true>": K_SART_FUSED})
     ms = _time_steps(t, lambda: (t.SART(1.0, 1), t.data_distance()), 5)
-    cnt, tot = log.read()["k_sart_tile<true>"]
+    cnt, tot, busy = log.read()["k_sart_tile<true>"]
     V = 256.0 ** 3
+    ns = sart_sub_slabs(256)
     out["config2_sart_256cube_x60tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
-                                            "roofline": roof("k_sart_tile<true>", cnt, tot, 8 * V + 12 * 256 * 256)}
+                                            "roofline": roof("k_sart_tile<true>", cnt, tot, (8 * V + 12 * 256 * 256) / ns, busy_ms=busy)}
     del t
     # ---- config 3: 512^3, 90 tilts: FISTA (lambda 0.1, 10 FGP iterations, cost), then SIRT with the tile projectors' roofs
     t = _engine(512, 512, 90)
@@ -253,9 +272,9 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
         return 0.5 * t.data_distance() ** 2 + 0.1 * t.tv()
     log = KernelLog(t, {"k_fgp_fused": K_FGP_GRAD})
     ms = _time_steps(t, fista_iter, 5)
-    cnt, tot = log.read()["k_fgp_fused"]
+    cnt, tot, busy = log.read()["k_fgp_fused"]
     out["config3_fista_512cube_x90tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
-                                             "roofline": roof("k_fgp_fused", cnt, tot, 28 * V)}
+                                             "roofline": roof("k_fgp_fused", cnt, tot, 28 * V, busy_ms=busy)}
     t.remove_momentum()
     t.restart_recon()
     log = KernelLog(t, {"k_fp_tile": K_FP_TILE, "k_fp_tile_reduce": K_FP_REDUCE, "k_bp_tile": K_BP_TILE})
@@ -271,7 +290,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
                                 k_fp_tile_avg_ms=avg("k_fp_tile"), k_fp_tile_reduce_avg_ms=avg("k_fp_tile_reduce")),
         # all-angle BP (8V + 4S): two FMAs and two LDS row reads per pixel, angle and slice
         "roofline_bp_all": roof("k_bp_tile", pr["k_bp_tile"][0], pr["k_bp_tile"][1], 8 * V + 4 * S, flops=4.0 * n * n * P * nx,
-                                lds_bytes=8.0 * n * n * P * nx)}
+                                lds_bytes=8.0 * n * n * P * nx, busy_ms=pr["k_bp_tile"][2])}
     del t
     # ---- ASD-POCS in the CPU reference's form (cpu/sim_ASD.py:64-96: ART sweep + tv + 10 TV-GD steps + 3 norms) at 512^3 x 90
     from tomo_tv_amd.engine import ctvlib
@@ -308,11 +327,12 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     asd_pocs_step(t, st4)
     log = KernelLog(t, {"k_sart_tile<true>": K_SART_FUSED})
     ms = _time_steps(t, lambda: asd_pocs_step(t, st4), 3, warmup=0)
-    cnt, tot = log.read()["k_sart_tile<true>"]
+    cnt, tot, busy = log.read()["k_sart_tile<true>"]
     V4 = 128.0 * 1024 * 1024
+    ns = sart_sub_slabs(128)
     out["config4_shard_asd_pocs_128x1024sq_x120tilts"] = {
         "ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V4 / ms / 1e6,
-        "roofline": roof("k_sart_tile<true>", cnt, tot, 8 * V4 + 12 * 128 * 1024)}
+        "roofline": roof("k_sart_tile<true>", cnt, tot, (8 * V4 + 12 * 128 * 1024) / ns, busy_ms=busy)}
     del t
     return out
 
@@ -449,13 +469,21 @@ def main():
     sync()
     el = time.perf_counter() - t0
     prof = log.read() if log else {}
+    iso = None
+    if on_gpu and sart_sub_slabs(slab_partition(nglobal, world, rank)[1] if comm is not None else nglobal, args.opt) > 1:
+        # the dominant kernel alone on the chip (one chain, one stream), one untimed step: the kernel's own rate
+        t.set_option("sart_streams", 1)
+        log1 = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED})
+        asd_pocs_step(t, st)
+        iso = log1.read()[K_FUSED_NAME]
+        t.set_option("sart_streams", 2)
     per_rank = None
     if comm is not None:
         tt = t.be.tensor([el])
         comm.allreduce_max(tt)
         el = float(tt.item())
         if prof:   # the dominant kernel's mean launch time on every rank
-            mine = prof[K_FUSED_NAME][1] / max(prof[K_FUSED_NAME][0], 1)
+            mine = prof[K_FUSED_NAME][2] / max(prof[K_FUSED_NAME][0], 1)   # busy time per launch
             allv = t.be.tensor([mine if r == rank else 0.0 for r in range(world)])
             comm.allreduce_sum(allv)
             per_rank = [float(v) for v in allv.tolist()]
@@ -472,13 +500,20 @@ def main():
         alg_bytes = {K_BP_NAME: 16.0 * V + 4.0 * nloc * n, K_FUSED_NAME: 8.0 * V + 12.0 * nloc * n,
                      K_FP_NAME: 4.0 * V + 8.0 * nloc * n}
         roofs = {}
-        for name, (cnt, tot) in prof.items():
-            roofs[name] = roof(name, cnt, tot, alg_bytes[name])
+        nsub = sart_sub_slabs(nloc, args.opt)      # launches per angle: the sweep runs as nsub sub-slabs on nsub streams
+        for name, (cnt, tot, busy) in prof.items():
+            roofs[name] = roof(name, cnt, tot, alg_bytes[name] / nsub, busy_ms=busy)
+            roofs[name]["sub_slabs"] = nsub
             # what an in-place read-modify-write pass over the slab reaches on this part in any access pattern
             # (tools/micro/copy_patterns.hip: 5.2-5.5 TB/s) -- informative, not the peak
             roofs[name]["frac_of_measured_rmw_ceiling"] = roofs[name]["achieved"] / RMW_CEILING_GBS
         attach_traffic(roofs, (nloc, n, nproj))
         dominant = max(roofs.values(), key=lambda r: r["total_ms"]) if roofs else None
+        if iso is not None and dominant is not None:
+            r1 = roof(K_FUSED_NAME, iso[0], iso[1], alg_bytes[K_FUSED_NAME], busy_ms=iso[2])
+            dominant = dict(dominant, isolated={k: r1[k] for k in ("achieved", "frac", "avg_ms", "launches", "algorithmic_bytes_per_launch")},
+                            isolated_note="the same kernel with sart_streams=1 (one launch per angle over the whole slab, nothing "
+                                          "else on the chip), one untimed step after the timed region")
         if dominant is not None and per_rank is not None:
             dominant = dict(dominant, avg_ms_per_rank=per_rank)
         shape = f"{nglobal}x{n}x{n}"

@@ -224,6 +224,10 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     row-by-row steps (k_art, which still serves tomo_art_order with a permutation)
  *   "sart_tile" (1):  fused SART steps on image tiles streamed through LDS (k_sart_tile, in place) instead of the ray-walk
  *                     form (k_sart_seg); equal at 512 slices per GPU, 14-18 % faster on slabs of <= 128 slices
+ *   "sart_streams" (1): 2 = the SART sweep of a slab of >= 2 x 64*vec slices runs as two sub-slabs on two streams, the
+ *                     second chain enqueued by a second host thread (slices are independent; each stream fills the other's
+ *                     launch gaps).  Measured: -2.4 % per sweep at 512 slices, +26 % at 1024 (the sub-slabs interleave inside
+ *                     every pixel row), so the default is one chain on the engine's stream
  *   "fp_tile" (1):    all-angle forward projection from LDS-resident image tiles (k_fp_tile + k_fp_tile_reduce);
  *                     0 = ray-driven form selected by "fp_all_lpr"
  *   "fp_tile_scratch_mib" (8192): cap of the tile projector's partial-sum scratch; a larger volume is projected in
@@ -243,6 +247,9 @@ enum tomo_kernel_id { TOMO_K_BP_ANGLE = 0, TOMO_K_FP_ANGLE = 1, TOMO_K_TV_GRAD =
                       TOMO_K_FP_TILE = 7, TOMO_K_BP_TILE = 8, TOMO_K_FP_REDUCE = 9 };
 int tomo_profile_enable(tomo_engine *e, int kernel, int on);
 int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms);
+/* the same, also busy_ms = time during which at least one launch of the kernel was executing (union of the launch
+ * intervals): the SART sweep runs as two sub-slabs on two streams ("sart_streams"), so two launches of a kernel overlap */
+int tomo_profile_read2(tomo_engine *e, int kernel, int64_t *launches, double *total_ms, double *busy_ms);
 
 #ifdef __cplusplus
 }

@@ -155,3 +155,20 @@ def test_fgp_fused_equals_two_kernel_form_at_full_size(tvbig):
     assert np.array_equal(res[1][1], res[0][1]) or rel_l2(res[1][1], res[0][1]) < 1e-7
     t.tv_eps = 1e-6
     assert res[1][1].min() >= 0 and t.tv() < res[1][0]
+
+
+def test_sart_two_stream_sub_slabs_equal_one_chain(big):
+    """"sart_streams" = 2 (two sub-slabs of the slab on two streams, second chain enqueued by a second host thread) changes
+    only the launch structure: every voxel and the tracked step norm are bit-identical to the single chain."""
+    t, x, (nx, n, p), ang = big
+    res = {}
+    for ns in (1, 2):
+        t.set_option("sart_streams", ns)
+        t.restart_recon()
+        t.copy_recon()
+        dp = t.SART_tracked(0.6, 1)
+        t.SART(0.6, 1)
+        res[ns] = (dp, t.get_volume())
+    t.set_option("sart_streams", 1)
+    assert res[1][0] == res[2][0] or abs(res[1][0] - res[2][0]) <= 1e-12 * res[1][0]   # fp64 partial sums, atomics in any order
+    assert np.array_equal(res[1][1], res[2][1])

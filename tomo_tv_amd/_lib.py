@@ -106,6 +106,7 @@ SIGNATURES = {
     "tomo_mm_update": [_p, _p, _p, _i, _p, _f, _f, _f, _p, _i, _i],
     "tomo_profile_enable": [_p, _i, _i],
     "tomo_profile_read": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
+    "tomo_profile_read2": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
 }
 
 _lib = None

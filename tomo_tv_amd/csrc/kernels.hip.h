@@ -472,7 +472,7 @@ template <int VEC, int PPW, bool TRACK>
 __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const CellD *__restrict__ cell,
                                                    const float *__restrict__ r, float beta, int npix, int sx,
                                                    int ngroups, int nchunk, float *__restrict__ track,
-                                                   double *__restrict__ part)
+                                                   double *__restrict__ part, int chunk0)
 {
     typedef typename VecOf<VEC>::T V;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
     int grp = gw - chunk * ngroups;
     int p0 = grp * PPW;
     if (p0 >= npix || chunk >= nchunk) return;   // grid is rounded up to whole workgroups
-    int off = chunk * (64 * VEC) + lane * VEC;
+    int off = (chunk0 + chunk) * (64 * VEC) + lane * VEC;   // chunk0: first chunk of the sub-slab this launch covers
     V xv[PPW], r0[PPW], r1[PPW], tk[PPW];
     CellD c[PPW];
 #pragma unroll
@@ -613,7 +613,8 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
                                                        const uint32_t *__restrict__ row_first,
                                                        const uint32_t *__restrict__ row_nseg,
                                                        const float *__restrict__ b, const float *__restrict__ rowsum,
-                                                       float *__restrict__ r_out, int row0, int nrows, int nchunk, int sx)
+                                                       float *__restrict__ r_out, int row0, int nrows, int nchunk, int sx,
+                                                       int chunk0)
 {
     typedef typename VecOf<VEC>::T V;
     __shared__ V red[3][64];
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
     int lane = threadIdx.x & 63;
     int chunk = blockIdx.x / nrows;
     int row = row0 + (blockIdx.x - chunk * nrows);
-    int off = chunk * (64 * VEC) + lane * VEC;
+    int off = (chunk0 + chunk) * (64 * VEC) + lane * VEC;
     uint32_t first = row_first[row], ns = row_nseg[row];
     uint32_t q = (ns + 3u) >> 2;
     uint32_t sb = min(wave * q, ns), se = min(sb + q, ns);
@@ -721,14 +722,17 @@ constexpr int ST_MAXB = (ST_TY + ST_TZ - 1 + 7) / 8;                 // entry ba
 static_assert(ST_PIX == ST_NG * 8, "a group owns 8 pixels");
 constexpr int ST_LDS_V = (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16 + ST_PIX;     // image + zero pixel, window + zero row, cells
 
-// RCP: the voxel update as num * (1 / colsum) -- one IEEE division per pixel instead of four (<= 1 ulp from num / colsum)
-template <bool FUSED, bool RCP = true>
+// Voxel update: num * (1 / colsum) -- one IEEE division per pixel instead of four (num / colsum per component): -3.7 % per
+// launch (round 2; the kernel is not HBM-bound, see above).  Cells with host-normalised weights (two FMAs per component, no
+// division at all) measured the same 215 us, so the cells keep the raw weights and the formula of k_bp_angle / k_sart_seg:
+// the three forms are bit-identical.
+template <bool FUSED>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
                                                            const float *__restrict__ r_prev, float beta,
                                                            const uint2 *__restrict__ segs, const uint32_t *__restrict__ segid,
                                                            const uint2 *__restrict__ ent, float *__restrict__ partial,
-                                                           int n, int sx, int tiles_z, int ntiles, int nchunk)
+                                                           int n, int sx, int tiles_z, int ntiles, int nchunk, int chunk0)
 {
     typedef VecOf<4>::T V;
     extern __shared__ V st_lds[];                       // ST_LDS_V float4 (dynamic)
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     // pixel lines and read the same tables.  (A persistent form with the next tile prefetched into registers while
     // the current one is in its LDS phases measured 3 % slower.)
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-    const int tile = (l / nchunk) * 8 + xcd, c = l % nchunk;
+    const int tile = (l / nchunk) * 8 + xcd, c = chunk0 + l % nchunk;   // chunk0: first 64-slice chunk of this launch's sub-slab
     if (tile >= ntiles) return;
     const int ty = tile / tiles_z, tz = tile - ty * tiles_z;
     const int t = threadIdx.x, gl = t & 15, g = t >> 4;
@@ -785,9 +789,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             float cs = w0 + w1;
             V num = w0 * a0;
             num += w1 * a1;
-            V upd;
-            if (RCP) upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));   // one IEEE division per pixel, not four: -3.7 % per launch
-            else upd = num / (cs > 0.f ? cs : 1.0f);
+            V upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));
             V nv = xv[J] + beta * upd;
             nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
             xv[J] = nv;
@@ -1500,6 +1502,14 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
 // shifts leave in those lanes; R of the phantom slice s0-1 (needed by lane 0's R(p-i)) is the same formula evaluated on
 // the edge registers.  Same arithmetic, operand order and rounding sequence as k_tv_grad_lds.
 // GRAD = false: the TV value alone (rows y, y+1 only; no phantom slice, no gradient, no store).
+// workgroups (4 waves) of the march kernels' item space, for the XCD-aware map above
+inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
+{
+    const int nzb = (n + tz - 1) / tz;
+    if ((nzb & 7) == 0) return 8u * (unsigned)(((int64_t)(nzb >> 3) * nchunk * nys + 3) / 4);
+    return (unsigned)(((int64_t)nzb * nchunk * nys + 3) / 4);
+}
+
 template <int TZ, bool WITH_TV, bool GRAD = true>
 __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x, Halo h, float *__restrict__ g,
                                                       double *__restrict__ part, float eps, int n, int nx, int sx,
@@ -1508,9 +1518,24 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
     double acc = 0.0, tvacc = 0.0;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;            // (y segment, z block, chunk), chunk fastest
-    if (item < (int64_t)nzb * nchunk * nys) {
-        const int bs = (int)(item % nchunk), bz = (int)((item / nchunk) % nzb), ys = (int)(item / ((int64_t)nchunk * nzb));
+    // Item = (y segment, z block, chunk).  Neighbouring z blocks share two of their ten columns and neighbouring chunks a
+    // slice on either side: when the neighbours run on different XCDs every shared line is fetched from HBM once per XCD
+    // (PMC, round 2: 1.72x the compulsory reads, and the kernel is bound by exactly that traffic: 1.46 GB in 288 us).
+    // Workgroups b and b+8 share an XCD, so each XCD is given a contiguous slab of z blocks and walks it chunk-fastest:
+    // the neighbours are then in flight on the same L2 at the same time.  (tv_march_items sizes the grid.)
+    int bs, bz, ys;
+    bool live;
+    if ((nzb & 7) == 0) {
+        const int zpx = nzb >> 3;
+        const int64_t li = (int64_t)(blockIdx.x >> 3) * 4 + wave;
+        bs = (int)(li % nchunk); bz = (int)(blockIdx.x & 7) * zpx + (int)((li / nchunk) % zpx); ys = (int)(li / ((int64_t)nchunk * zpx));
+        live = ys < nys;
+    } else {
+        const int64_t item = (int64_t)blockIdx.x * 4 + wave;        // chunk fastest
+        bs = (int)(item % nchunk); bz = (int)((item / nchunk) % nzb); ys = (int)(item / ((int64_t)nchunk * nzb));
+        live = ys < nys;
+    }
+    if (live) {
         const int y0 = ys * yseg, y1 = min(y0 + yseg, n);
         const int z0 = bz * TZ, s0 = bs * 64, s = s0 + lane;
         // edge register: lane 0 <- slice s0-1, lane 63 <- slice s0+64; the other lanes re-read their own slice (same
@@ -1731,9 +1756,20 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
     __shared__ float al[TVL_TZ + 2][TVL_PITCH];           // A plane being turned into D
     __shared__ float dl[2][TVL_TZ + 1][TVL_PITCH];        // D planes: row zi' = column z0+zi', element si' = slice s0+si'
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nzb = (n + TVL_TZ - 1) / TVL_TZ;
-    const int bz = blockIdx.x % nzb, bs = blockIdx.x / nzb;
-    const int y0 = blockIdx.y * yseg, y1 = min(y0 + yseg, n);
+    const int nzb = (n + TVL_TZ - 1) / TVL_TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
+    // one workgroup per (y segment, z block, chunk); XCD-aware like k_tv_grad_reg: an XCD (workgroups b, b+8, ...) owns a
+    // contiguous slab of z blocks and walks it chunk-fastest, so the halo columns / slices two neighbours share are fetched
+    // once per L2 (PMC, round 2, blockIdx-ordered z blocks: reads 1.77x compulsory)
+    int bz, bs, ysi;
+    if ((nzb & 7) == 0) {
+        const int zpx = nzb >> 3;
+        const int64_t li = blockIdx.x >> 3;
+        bs = (int)(li % nchunk); bz = (int)(blockIdx.x & 7) * zpx + (int)((li / nchunk) % zpx); ysi = (int)(li / ((int64_t)nchunk * zpx));
+    } else {
+        bs = (int)(blockIdx.x % nchunk); bz = (int)((blockIdx.x / nchunk) % nzb); ysi = (int)(blockIdx.x / ((int64_t)nchunk * nzb));
+    }
+    if (ysi >= nys) return;
+    const int y0 = ysi * yseg, y1 = min(y0 + yseg, n);
     const int z0 = bz * TVL_TZ, s0 = bs * 64;
     const size_t npix = (size_t)n * n;
     // fid: 0 = A, 1..3 = P1..P3 (the plane order of the hi / send_first buffers)

@@ -8,10 +8,13 @@
 #include "kernels.hip.h"
 #include "sysmat.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -34,6 +37,7 @@ enum { PROF_MAX_KERNELS = 12, PROF_MAX_EVENTS = 1 << 19 };   // 262144 launches 
 struct ProfSlot {
     bool on = false;
     std::vector<hipEvent_t> ev;  // pairs
+    hipEvent_t ref = nullptr;    // recorded when the log is switched on: launches on different streams share this time base
     size_t used = 0, dropped = 0;   // dropped: launches that could not be recorded (tomo_profile_read reports them)
 };
 
@@ -68,7 +72,16 @@ struct tomo_engine {
     uint2 *d_ft_tent = nullptr;
     float *ft_part = nullptr, *ft_part_aux = nullptr;
     bool attr_fp = false, attr_bp = false, attr_st = false;   // dynamic-LDS limits raised on this engine's device
-    int sart_rcp = 1;                             // voxel update as num * (1/colsum) in k_sart_tile (0: num / colsum per component, A/B)
+    // The SART chain of one slab is a string of dependent launches (tile step -> residual finish -> tile step ...): ~5.7 us of
+    // idle chip after each and a tail of partly filled CUs at the end of each.  Slices are independent, so the sweep CAN run as
+    // two sub-slabs on two streams, each filling the other's gaps ("sart_streams" = 2).  Measured (round 2, per sweep): two
+    // separate 256-slice engines side by side 18.0 ms against 20.7 for one 512-slice engine -- but two sub-slabs of ONE slab
+    // interleave inside every pixel row (1 KB of every 2 KB) and reach only 19.4 ms at 512 slices and 51.3 against 40.6 ms
+    // at 1024: two kernels striding over alternate halves of the same rows collide in the memory system.  Default 1.
+    // sub_c0 / sub_nc: the 64-slice chunk range the launch helpers address (0 / 0 = whole slab).
+    int sart_streams = 1, sub_c0 = 0, sub_nc = 0;
+    hipStream_t sub_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_sfork = nullptr, ev_sjoin[2] = {nullptr, nullptr};
     int sart_tile = 1;                            // fused SART step on streamed image tiles (k_sart_tile) when the geometry allows it
     bool st_ok = false;
     int st_ntiles = 0, st_tiles_z = 0;
@@ -110,6 +123,7 @@ struct tomo_engine {
     float *fgp_lo = nullptr, *fgp_hi = nullptr, *fgp_send_first = nullptr, *fgp_send_last = nullptr;
     int is_first = 1, is_last = 1;
     ProfSlot prof[PROF_MAX_KERNELS];
+    std::mutex prof_mu;
     size_t vol_elems() const { return (size_t)npix * sx; }
     size_t sino_elems() const { return (size_t)nrows * sx; }
 };
@@ -176,23 +190,35 @@ static int ensure_stage(tomo_engine *e, size_t bytes)
 }
 
 // ---- profiling brackets (bench.py roofline: HIP events on the launch stream) --------------------------
+// Where a launch goes: the engine's stream and the whole slab, or one sub-slab (64-slice chunks [c0, c0 + nc)) on its own
+// stream.  Passed explicitly so that two host threads can enqueue the two sub-slab chains of a SART sweep side by side.
+struct Sub {
+    hipStream_t stream; int c0 = 0, nc = 0;
+};
+static Sub whole(const tomo_engine *e) { return Sub{e->stream, e->sub_c0, e->sub_nc}; }
+
 struct ProfScope {
-    tomo_engine *e; int k; hipEvent_t stop = nullptr;
-    ProfScope(tomo_engine *e_, int k_) : e(e_), k(k_)
+    tomo_engine *e; int k; hipEvent_t stop = nullptr; hipStream_t st;
+    ProfScope(tomo_engine *e_, int k_, hipStream_t st_ = nullptr) : e(e_), k(k_), st(st_ ? st_ : e_->stream)
     {
         ProfSlot &p = e->prof[k];
         if (!p.on) return;
-        if (p.used + 2 > p.ev.size()) {
-            if (p.ev.size() >= PROF_MAX_EVENTS) { ++p.dropped; return; }
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ++p.dropped; return; }
-            p.ev.push_back(a); p.ev.push_back(b);
+        hipEvent_t start;
+        {
+            std::lock_guard<std::mutex> lk(e->prof_mu);       // two threads may log launches of one kernel
+            if (p.used + 2 > p.ev.size()) {
+                if (p.ev.size() >= PROF_MAX_EVENTS) { ++p.dropped; return; }
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ++p.dropped; return; }
+                p.ev.push_back(a); p.ev.push_back(b);
+            }
+            start = p.ev[p.used];
+            stop = p.ev[p.used + 1];
+            p.used += 2;
         }
-        (void)hipEventRecord(p.ev[p.used], e->stream);
-        stop = p.ev[p.used + 1];
-        p.used += 2;
+        (void)hipEventRecord(start, st);
     }
-    ~ProfScope() { if (stop) (void)hipEventRecord(stop, e->stream); }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
 };
 
 // ---- reductions ------------------------------------------------------------------------------------------
@@ -283,30 +309,36 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
 
 constexpr int BP_PPW = 4;
 
-static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_angle, float beta, float *track = nullptr)
+static int launch_bp_angle(tomo_engine *e, const Sub &sb, float *x, int angle, const float *r_angle, float beta, float *track = nullptr)
 {
-    ProfScope ps(e, TOMO_K_BP_ANGLE);
-    int nchunk = e->sxc / (64 * e->vec);
+    ProfScope ps(e, TOMO_K_BP_ANGLE, sb.stream);
+    int nchunk = e->sxc / (64 * e->vec), chunk0 = 0;
+    if (sb.nc) { nchunk = sb.nc / e->vec; chunk0 = sb.c0 / e->vec; }   // sub-slab (whole multiples of 64*vec slices)
     int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
     int64_t waves = (int64_t)ngroups * nchunk;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const CellD *cell = e->d_cell + (size_t)angle * e->npix;
     if (track) {   // caller brackets with reduce_begin / reduce_end
         switch (e->vec) {
-        case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, true>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part); break;
-        case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, true>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part); break;
-        default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, true>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part); break;
+        case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, true>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part, chunk0); break;
+        case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, true>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part, chunk0); break;
+        default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, true>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part, chunk0); break;
         }
         LAUNCHCHK();
         return TOMO_OK;
     }
     switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, false>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr); break;
-    case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, false>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr); break;
-    default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, false>), grid, block, 0, e->stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr); break;
+    case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, false>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr, chunk0); break;
+    case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, false>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr, chunk0); break;
+    default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, false>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr, chunk0); break;
     }
     LAUNCHCHK();
     return TOMO_OK;
+}
+
+static int launch_bp_angle(tomo_engine *e, float *x, int angle, const float *r_angle, float beta, float *track = nullptr)
+{
+    return launch_bp_angle(e, whole(e), x, angle, r_angle, beta, track);
 }
 
 // segmented per-angle step: FUSED -> BP(prev) + FP(next); else plain FP(next).  Leaves the residual rows of `next` in r.
@@ -336,9 +368,9 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
     {
         dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
         switch (e->vec) {
-        case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-        case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-        default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+        case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, 0); break;
+        case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, 0); break;
+        default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, e->stream, e->seg_partial, e->d_row_first, e->d_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, 0); break;
         }
         LAUNCHCHK();
     }
@@ -347,43 +379,42 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
 
 // tile form of the per-angle step (k_sart_tile): FUSED -> BP(prev) + FP(next), in place; else plain FP(next).
 // Leaves the residual rows of `next` in r.
-template <bool FUSED>
-static int launch_sart_tile(tomo_engine *e, float *x, int prev, int next, float *r, float beta)
+// (function attributes and the partial-sum buffer are set up by sart_tile_prepare, on the caller's thread and stream)
+static int sart_tile_prepare(tomo_engine *e)
 {
-    int rc;
     if (!e->attr_st) {
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
-        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         e->attr_st = true;
     }
     if (!e->st_partial) {
-        if ((rc = dev_alloc((void **)&e->st_partial, (size_t)std::max<uint32_t>(1, e->st_max_ids) * e->sx * sizeof(float), true, e->stream))) return rc;
+        int rc = dev_alloc((void **)&e->st_partial, (size_t)std::max<uint32_t>(1, e->st_max_ids) * e->sx * sizeof(float), true, e->stream);
+        if (rc) return rc;
     }
-    const int nchunk64 = e->sxc / 64;
+    return TOMO_OK;
+}
+
+template <bool FUSED>
+static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, int next, float *r, float beta)
+{
+    const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
     const size_t nt = (size_t)e->st_ntiles;
     {
-        ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE);
+        ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE, sb.stream);
         dim3 grid((unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64)), block(ST_THREADS);
-        if (FUSED && !e->sart_rcp)
-            hipLaunchKernelGGL((k_sart_tile<FUSED, false>), grid, block, ST_LDS_V * 16, e->stream, x, x,
-                               e->d_st_cell + (size_t)prev * nt * ST_PIX, e->d_st_win + (size_t)prev * nt, r + (size_t)prev * e->n * e->sx, beta,
-                               e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, e->st_partial,
-                               e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64);
-        else
-        hipLaunchKernelGGL((k_sart_tile<FUSED>), grid, block, ST_LDS_V * 16, e->stream, x, x,
+        hipLaunchKernelGGL((k_sart_tile<FUSED>), grid, block, ST_LDS_V * 16, sb.stream, x, x,
                            FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
                            FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
                            e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, e->st_partial,
-                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64);
+                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64);
         LAUNCHCHK();
     }
-    int nchunk = e->sxc / (64 * e->vec);
+    int nchunk = nchunk64 / e->vec, chunk0 = c64 / e->vec;
     dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
     switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, e->stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-    case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, e->stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
-    default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, e->stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx); break;
+    case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, sb.stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+    case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, sb.stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+    default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, sb.stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
     }
     LAUNCHCHK();
     return TOMO_OK;
@@ -654,12 +685,14 @@ int tomo_destroy(tomo_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
+    for (int u = 0; u < 2; ++u) if (e->sub_stream[u]) { (void)hipStreamSynchronize(e->sub_stream[u]); (void)hipStreamDestroy(e->sub_stream[u]); (void)hipEventDestroy(e->ev_sjoin[u]); }
+    if (e->ev_sfork) (void)hipEventDestroy(e->ev_sfork);
     free_geometry(e);
     void *ptrs[] = {e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_coef, e->sart_alt,
                     e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
-    for (auto &p : e->prof) for (auto ev : p.ev) (void)hipEventDestroy(ev);
+    for (auto &p : e->prof) { for (auto ev : p.ev) (void)hipEventDestroy(ev); if (p.ref) (void)hipEventDestroy(p.ref); }
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return TOMO_OK;
@@ -673,6 +706,7 @@ int tomo_release_geometry(tomo_engine *e)
     NEED(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->aux) HIPCHK(hipStreamSynchronize(e->aux));
+    for (int u = 0; u < 2; ++u) if (e->sub_stream[u]) HIPCHK(hipStreamSynchronize(e->sub_stream[u]));
     e->async_pending = false;
     free_geometry(e);
     return TOMO_OK;
@@ -942,18 +976,58 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
     // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
     if (steps <= 0) return TOMO_OK;
     if (e->sart_tile && e->st_ok) {   // tile form, in place
-        if ((rc = launch_sart_tile<false>(e, x, 0, angle_at(0), r, beta))) return rc;
-        for (int64_t k = 1; k < steps; ++k) {
+        if ((rc = sart_tile_prepare(e))) return rc;
+        // link k of the chain: 0 = FP(a0); 1..steps-1 = BP(a_k-1) + FP(a_k); steps = BP(a_last)
+        auto link = [&](int64_t k, const Sub &sb) -> int {
+            int rc2;
+            if (k == 0) return launch_sart_tile<false>(e, sb, x, 0, angle_at(0), r, beta);
+            if (k == steps) { int last = angle_at(steps - 1); return launch_bp_angle(e, sb, x, last, r + (size_t)last * e->n * e->sx, beta, track); }
             int prev = angle_at(k - 1), next = angle_at(k);
             if (prev == next) {
-                if ((rc = launch_bp_angle(e, x, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc;
-                if ((rc = launch_sart_tile<false>(e, x, 0, next, r, beta))) return rc;
-                continue;
+                if ((rc2 = launch_bp_angle(e, sb, x, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc2;
+                return launch_sart_tile<false>(e, sb, x, 0, next, r, beta);
             }
-            if ((rc = launch_sart_tile<true>(e, x, prev, next, r, beta))) return rc;
+            return launch_sart_tile<true>(e, sb, x, prev, next, r, beta);
+        };
+        auto chain = [&](const Sub &sb) -> int {
+            for (int64_t k = 0; k <= steps; ++k) { int rc2 = link(k, sb); if (rc2) return rc2; }
+            return TOMO_OK;
+        };
+        // Two sub-slabs on two streams when the slab splits into whole 64*vec-slice units (see sart_streams above).  A sweep
+        // is then 2 x 180 launches of ~100 us kernels: one host thread cannot enqueue both chains fast enough to keep both
+        // streams fed (measured: 19.4 ms per sweep against 19.9 on one stream), so the second chain is enqueued by a second
+        // host thread (18.0 ms: what two independent engines on two Python threads reach).
+        const int units = e->sxc / (64 * e->vec);
+        if (e->sart_streams >= 2 && units >= 2) {
+            if (!e->sub_stream[0]) {
+                for (int u = 0; u < 2; ++u) {
+                    HIPCHK(hipStreamCreateWithFlags(&e->sub_stream[u], hipStreamNonBlocking));
+                    HIPCHK(hipEventCreateWithFlags(&e->ev_sjoin[u], hipEventDisableTiming));
+                }
+                HIPCHK(hipEventCreateWithFlags(&e->ev_sfork, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(e->ev_sfork, e->stream));
+            const int u_lo = units / 2;
+            Sub sbs[2] = {Sub{e->sub_stream[0], 0, u_lo * e->vec}, Sub{e->sub_stream[1], u_lo * e->vec, (units - u_lo) * e->vec}};
+            for (int u = 0; u < 2; ++u) HIPCHK(hipStreamWaitEvent(e->sub_stream[u], e->ev_sfork, 0));
+            int rcs[2] = {TOMO_OK, TOMO_OK};
+            std::string err1;
+            const int dev = e->device;
+            std::thread second([&]() {
+                if (hipSetDevice(dev) != hipSuccess) { rcs[1] = TOMO_ERR_HIP; err1 = "hipSetDevice (second enqueue thread)"; return; }
+                rcs[1] = chain(sbs[1]);
+                if (rcs[1]) err1 = g_err;                       // the error text is thread-local
+            });
+            rcs[0] = chain(sbs[0]);
+            second.join();
+            if (rcs[1] && !rcs[0]) { rcs[0] = rcs[1]; g_err = err1; }
+            for (int u = 0; u < 2; ++u)
+                if (hipEventRecord(e->ev_sjoin[u], e->sub_stream[u]) != hipSuccess && !rcs[0]) rcs[0] = fail(TOMO_ERR_HIP, "hipEventRecord(sub-slab join)");
+            for (int u = 0; u < 2; ++u) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_sjoin[u], 0));
+            if (rcs[0]) return rcs[0];
+            return finish();
         }
-        int last = angle_at(steps - 1);
-        if ((rc = launch_bp_angle(e, x, last, r + (size_t)last * e->n * e->sx, beta, track))) return rc;
+        if ((rc = chain(whole(e)))) return rc;
         return finish();
     }
     float *alt;
@@ -1439,8 +1513,7 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
     HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
     const int yseg = 32;
     if (e->tv_lds == 1) {
-        int64_t items = (int64_t)((e->n + 7) / 8) * (e->sxc / 64) * ((e->n + yseg - 1) / yseg);
-        hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+        hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
     } else {
         dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
         hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
@@ -1468,8 +1541,7 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
         ProfScope ps(e, TOMO_K_TV_GRAD);
         if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
             int yseg = 32;   // 8 .. 64 rows per wave measured the same; longer segments leave too few waves
-            int64_t items = (int64_t)((e->n + 7) / 8) * (e->sxc / 64) * ((e->n + yseg - 1) / yseg);
-            dim3 grid((unsigned)((items + 3) / 4));
+            dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
             if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
             else hipLaunchKernelGGL((k_tv_grad_reg<8, false>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr);
         } else if (e->tv_lds) {
@@ -1619,7 +1691,7 @@ static int tv_gd_impl(tomo_engine *e, int ng, float dPOCS, float eps, int track_
     int rc;
     if (!e) return fail(TOMO_ERR_ARG, "null engine");
     // the TV value before descent comes out of the first gradient pass (its denominators are the TV integrand)
-    const bool fold_tv = ng > 0 && e && (e->tv_lds == 8 || e->tv_lds == 1);
+    const bool fold_tv = ng > 0 && (e->tv_lds == 8 || e->tv_lds == 1);
     if (fold_tv) { if ((rc = tomo_halo_local(e, e->tv_target))) return rc; }
     else if ((rc = tomo_tv(e, e->tv_target, eps))) return rc;
     for (int g = 0; g < ng; ++g) {
@@ -1680,8 +1752,9 @@ int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration)
     NEED(e);
     if (!e->fgp_q[2] || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
     const int yseg = 32;
-    const int nzb = (e->n + TVL_TZ - 1) / TVL_TZ;
-    dim3 grid((unsigned)(nzb * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
+    const int nzb = (e->n + TVL_TZ - 1) / TVL_TZ, nys = (e->n + yseg - 1) / yseg, nchunk = e->sxc / 64;
+    // one workgroup per item; an XCD-aligned grid when the z blocks split evenly over the 8 XCDs (k_fgp_fused's item map)
+    dim3 grid((nzb & 7) == 0 ? 8u * (unsigned)((nzb >> 3) * nchunk * nys) : (unsigned)(nzb * nchunk * nys));
     const float multip = 1.0f / (26.0f * lambda);
     FgpEdge ed{};
     ed.first = e->is_first; ed.last = e->is_last;
@@ -1745,7 +1818,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "art_chain") == 0) { e->art_chain = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { e->sart_tile = value ? 1 : 0; return TOMO_OK; }
-    if (std::strcmp(name, "sart_rcp") == 0) { e->sart_rcp = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? 2 : 1; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_chunks_per_pass") == 0) {   // any count >= 1 (0 = from the scratch cap); before the first projection
@@ -1769,20 +1842,45 @@ int tomo_profile_enable(tomo_engine *e, int kernel, int on)
     e->prof[kernel].on = on != 0;
     e->prof[kernel].used = 0;
     e->prof[kernel].dropped = 0;
+    if (on) {
+        if (!e->prof[kernel].ref) HIPCHK(hipEventCreate(&e->prof[kernel].ref));
+        HIPCHK(hipEventRecord(e->prof[kernel].ref, e->stream));
+    }
     return TOMO_OK;
 }
 
-int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms)
+// busy_ms (may be null): time during which AT LEAST ONE launch of the kernel was executing (union of the launch intervals
+// on the common time base) -- with the SART sweep on two streams two launches of one kernel overlap, and sum / launches
+// is then the duration of a launch that shares the chip, not the chip's rate
+int tomo_profile_read2(tomo_engine *e, int kernel, int64_t *launches, double *total_ms, double *busy_ms)
 {
     NEED(e);
     if (kernel < 0 || kernel >= PROF_MAX_KERNELS || !launches || !total_ms) return fail(TOMO_ERR_ARG, "bad argument");
     HIPCHK(hipStreamSynchronize(e->stream));
+    for (int u = 0; u < 2; ++u) if (e->sub_stream[u]) HIPCHK(hipStreamSynchronize(e->sub_stream[u]));
+    if (e->aux) HIPCHK(hipStreamSynchronize(e->aux));
     ProfSlot &p = e->prof[kernel];
     double tot = 0;
+    std::vector<std::pair<float, float>> iv;
     for (size_t i = 0; i + 1 < p.used; i += 2) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
         tot += ms;
+        if (busy_ms && p.ref) {
+            float t0 = 0;
+            HIPCHK(hipEventElapsedTime(&t0, p.ref, p.ev[i]));
+            iv.emplace_back(t0, t0 + ms);
+        }
+    }
+    if (busy_ms) {
+        std::sort(iv.begin(), iv.end());
+        double busy = 0; float cur_a = 0, cur_b = -1;
+        for (auto &q : iv) {
+            if (cur_b < cur_a || q.first > cur_b) { if (cur_b >= cur_a) busy += cur_b - cur_a; cur_a = q.first; cur_b = q.second; }
+            else cur_b = std::max(cur_b, q.second);
+        }
+        if (cur_b >= cur_a) busy += cur_b - cur_a;
+        *busy_ms = busy;
     }
     *launches = (int64_t)(p.used / 2);
     *total_ms = tot;
@@ -1793,6 +1891,11 @@ int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *tot
         return fail(TOMO_ERR_STATE, msg);
     }
     return TOMO_OK;
+}
+
+int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms)
+{
+    return tomo_profile_read2(e, kernel, launches, total_ms, nullptr);
 }
 
 }  // extern "C"
