@@ -115,3 +115,32 @@ def test_tile_tables_replay_the_matrix(tmp_path, N, P, amax):
                    check=True)
     r = subprocess.run([exe, str(N), str(P), str(amax)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_facades_carry_every_method_of_the_reference_tables(golden):
+    """tests/golden/method_tables.json holds the method NAMES of the reference's five pybind11 classes; every one of
+    them must exist on the class of the same name here (the drop-in boundary of SURVEY.md section 8b)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from tomo_tv_amd import chemistry, engine
+    tables = json.load(open(os.path.join(GOLDEN, "method_tables.json")))["tables"]
+    cls = {"tomoengine": engine.tomoengine, "multigpuengine": engine.multigpuengine, "ctvlib": engine.ctvlib,
+           "multimodal": chemistry.multimodal, "multigpufusion": chemistry.multigpufusion}
+    for name, methods in tables.items():
+        missing = [m for m in methods if not callable(getattr(cls[name], m, None))]
+        assert not missing, (name, missing)
+
+
+def test_cpu_harness_signatures_match_the_reference():
+    """cpu/utils/pytvlib.py:171-206: run(tomo, alg, beta=1), initialize_algorithm(tomo, alg, Nray, tiltAngles, angleStart=0),
+    create_projections(tomo, original_volume, SNR=0), load_exp_tilt_series(tomo, tiltSeries)."""
+    import inspect
+    from tomo_tv_amd import cpu_harness as H
+    sig = lambda f: [(p.name, p.default) for p in inspect.signature(f).parameters.values()]  # noqa: E731
+    E = inspect.Parameter.empty
+    assert sig(H.run) == [("tomo", E), ("alg", E), ("beta", 1)]
+    assert sig(H.initialize_algorithm) == [("tomo", E), ("alg", E), ("Nray", E), ("tiltAngles", E), ("angleStart", 0)]
+    assert sig(H.create_projections) == [("tomo", E), ("original_volume", E), ("SNR", 0)]
+    assert sig(H.load_exp_tilt_series) == [("tomo", E), ("tiltSeries", E)]
+    assert sig(H.parallelRay)[0][0] == "Nside"

@@ -130,8 +130,27 @@ def asd_art_traces(shapes, Niter=20):
                             provenance="oracle/ restatement of the Cimmino branch (ctvlib.cpp:198-199,212-216,245-251)")
 
 
+def method_tables():
+    """Method NAMES of the reference's five pybind11 classes (interface data for tests/test_abi_cpu.py)."""
+    import re
+
+    def defs(path):
+        src = open(os.path.join(REF, "tomofusion", path)).read()
+        return sorted(set(re.findall(r'\.def\(\s*"([A-Za-z_0-9]+)"', src[src.index("PYBIND11_MODULE"):])))
+    tables = {"tomoengine": defs("gpu/utils/tomoengine.cpp"), "multigpuengine": defs("gpu/utils/multigpuengine.cpp"),
+              "ctvlib": defs("cpu/utils/ctvlib.cpp"), "multimodal": defs("chemistry/utils/multimodal.cpp"),
+              "multigpufusion": defs("chemistry/utils/multigpufusion.cpp")}
+    json.dump({"provenance": "method NAMES of the reference's pybind11 tables (the .def(\"name\", ...) strings of tomoengine.cpp:487-534, "
+                             "multigpuengine.cpp:385-421, ctvlib.cpp:486-520, multimodal.cpp:520-564, multigpufusion.cpp:463-474), "
+                             "extracted by tools/gen_golden.py", "tables": tables},
+              open(os.path.join(GOLD, "method_tables.json"), "w"), indent=1, sort_keys=True)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-method-tables" in sys.argv:
+        method_tables()
+        return
     if "--only-asd-art" in sys.argv:       # the traces added in round 2; everything else stays byte-identical
         asd_art_traces([(16, 5, 2), (32, 9, 4), (64, 16, 8)])
         return
@@ -294,6 +313,7 @@ def main():
                         dd=np.array(dd), rmse=np.array(rm), lipschitz=np.float32(t.lipschits()),
                         provenance="oracle/ restatement, config 1 (256x256 Shepp-Logan, 50 tilts, SIRT x50)")
     asd_art_traces(shapes)
+    method_tables()
     print("golden written to", GOLD)
 
 
