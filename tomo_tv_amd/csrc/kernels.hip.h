@@ -1502,6 +1502,15 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
 // shifts leave in those lanes; R of the phantom slice s0-1 (needed by lane 0's R(p-i)) is the same formula evaluated on
 // the edge registers.  Same arithmetic, operand order and rounding sequence as k_tv_grad_lds.
 // GRAD = false: the TV value alone (rows y, y+1 only; no phantom slice, no gradient, no store).
+// Round-2 experiments on this kernel (512^3, 288 us = 3.7 TB/s on its 8V compulsory bytes), none of which moved its time:
+//  * the XCD-aware item map below cut the L2-side reads from 1.72x to 1.29x compulsory (PMC) -- the duplicate halo reads had
+//    been Infinity-Cache hits, not HBM traffic;
+//  * a form on float2 z-pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, -27 % vector instructions): 608 vs 598 us per
+//    inner iteration; the whole library built WITHOUT packed fp32 (-target-feature -packed-fp32-ops): the same;
+//  * a workgroup-cooperative form (the 4 waves of a workgroup = 4 adjacent chunks hand lane 63's R to the neighbour through
+//    LDS instead of re-evaluating the phantom slice: -78 instructions per row; buffer loads with scalar row offsets: -28):
+//    616 vs 602 us.
+// So neither the instruction count nor the L2-side traffic is the limiter; what is, is not established.
 // workgroups (4 waves) of the march kernels' item space, for the XCD-aware map above
 inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
 {
@@ -1632,159 +1641,6 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 #undef TVR_RINV
     }
     if (GRAD) block_accumulate(acc, part);
-    if (WITH_TV) {
-        __syncthreads();
-        block_accumulate(tvacc, part_tv);
-    }
-}
-
-// ---- TV gradient, register march, workgroup-cooperative form -----------------------------------------------------------
-// k_tv_grad_reg is bound by its vector instructions (~440 per row and wave; a row takes 4.1 us per wave of which ~2.9 are
-// VALU issue shared by the 4 waves of a SIMD).  Three groups of them are overhead and go here:
-//  * 104 re-evaluate R at the phantom slice s0-1 for the benefit of lane 0 alone.  That value IS R of lane 63 of the wave
-//    that owns the previous chunk -- and the four waves of a workgroup own four adjacent chunks of one (z block, y segment).
-//    They march in step (one barrier per row) and hand lane 63's eight R values to the right-hand neighbour through 256 B
-//    of LDS; only wave 0 of a workgroup (whose left neighbour is another workgroup, or the halo plane) still evaluates the
-//    phantom slice;
-//  * 28 are 64-bit address adds: loads and stores are buffer instructions with the row offset in a scalar register and the
-//    lane offset in a constant vector register (needs the volume to be < 4 GiB: the engine falls back to k_tv_grad_reg);
-//  * the halo selects of the first / last chunk (3 of 4 address selects per element) become two wave-uniform loads per
-//    column and three value selects, inside one wave-uniform branch per row.
-// Same arithmetic, operand order and rounding as k_tv_grad_reg / k_tv_grad_lds: bit-identical results.
-template <bool WITH_TV>
-__global__ __launch_bounds__(256) void k_tv_grad_wg(const float *__restrict__ x, const float *__restrict__ h_lo,
-                                                     const float *__restrict__ h_hi, float *__restrict__ g,
-                                                     double *__restrict__ part, float eps, int n, int nx, int sx,
-                                                     int yseg, double *__restrict__ part_tv, unsigned vol_bytes)
-{
-    constexpr int TZ = 8;
-    __shared__ float xr[2][4][TZ];                                  // [row parity][wave][column]: lane 63's R of the row
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
-    double acc = 0.0, tvacc = 0.0;
-    // item map of k_tv_grad_reg (XCD-aware); nchunk % 4 == 0, so the 4 waves of a workgroup are chunks 4q .. 4q+3 of one
-    // (z block, y segment) and either all live or all idle
-    int bs, bz, ys;
-    if ((nzb & 7) == 0) {
-        const int zpx = nzb >> 3;
-        const int64_t li = (int64_t)(blockIdx.x >> 3) * 4 + wave;
-        bs = (int)(li % nchunk); bz = (int)(blockIdx.x & 7) * zpx + (int)((li / nchunk) % zpx); ys = (int)(li / ((int64_t)nchunk * zpx));
-    } else {
-        const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-        bs = (int)(item % nchunk); bz = (int)((item / nchunk) % nzb); ys = (int)(item / ((int64_t)nchunk * nzb));
-    }
-    if (ys < nys) {                                                   // workgroup-uniform
-        const int y0 = ys * yseg, y1 = min(y0 + yseg, n);
-        const int z0 = bz * TZ, s0 = bs * 64, s = s0 + lane;
-        const bool first = s0 == 0, tail = s0 + 64 >= nx;             // wave-uniform: chunks that touch a halo plane
-        const bool edge = first || tail;
-        // edge register: lane 0 <- slice s0-1, lane 63 <- slice s0+64 (clamped into the row where a halo plane takes over)
-        const int se = lane == 0 ? (first ? s : s0 - 1) : (lane == 63 ? (tail ? s : s0 + 64) : s);
-        const bool m_lo = first && lane == 0, m_hi_c = tail && s >= nx, m_hi_e = tail && (lane == 63 || s >= nx);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)vol_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(g, 0, (int)vol_bytes, 0x00020000);
-        const int vo = s * 4, voe = se * 4;                           // lane byte offsets inside a pixel row
-        int zc[TZ + 2];
-#pragma unroll
-        for (int j = 0; j < TZ + 2; ++j) { int z = (z0 - 1 + j) % n; zc[j] = z < 0 ? z + n : z; }
-        auto yrow = [&](int y) { int r = y % n; return r < 0 ? r + n : r; };
-        float cm[TZ + 2], c0[TZ + 2], cp[TZ + 2], cn[TZ + 2], E0[TZ + 2], Ep[TZ + 2], En[TZ + 2], Rm[TZ + 1], R0[TZ + 1];
-        const int rowb = sx * 4;                                      // bytes per pixel row
-        auto fetch = [&](int y, float *c, float *E) {
-            const int yy = yrow(y) * n;
-#pragma unroll
-            for (int j = 0; j < TZ + 2; ++j) {
-                const int so = __builtin_amdgcn_readfirstlane((int)((unsigned)(yy + zc[j]) * (unsigned)rowb));   // < 4 GiB: checked by the engine
-                c[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, so, 0));
-                E[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voe, so, 0));
-            }
-            if (edge) {
-#pragma unroll
-                for (int j = 0; j < TZ + 2; ++j) {
-                    const float lo = h_lo[yy + zc[j]], hi = h_hi[yy + zc[j]];      // wave-uniform addresses
-                    c[j] = m_hi_c ? hi : c[j];
-                    E[j] = m_lo ? lo : (m_hi_e ? hi : E[j]);
-                }
-            }
-        };
-#define TVW_RINV(C, IP, JP, KP, RR, DD)                                                                   \
-        {                                                                                                 \
-            float d1_ = (C) - (IP), d2_ = (C) - (JP), d3_ = (C) - (KP);                                   \
-            float q_ = __fmaf_rn(d3_, d3_, __fmaf_rn(d2_, d2_, __fmaf_rn(d1_, d1_, eps)));                \
-            float y_ = __frsqrt_rn(q_);                                                                   \
-            float e_ = __fmaf_rn(-__fmul_rn(q_, y_), __fmul_rn(0.5f, y_), 0.5f);                          \
-            RR = __fmaf_rn(y_, e_, y_);                                                                   \
-            DD = __fmul_rn(q_, RR);                                                                       \
-        }
-        auto shr = [&](float old, float v) {                    // lane l <- lane l-1 ; lane 0 keeps `old`
-            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-        };
-        auto shl = [&](float old, float v) {                    // lane l <- lane l+1 ; lane 63 keeps `old`
-            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-        };
-        fetch(y0 - 1, cm, En);
-        fetch(y0, c0, E0);
-        fetch(y0 + 1, cp, Ep);
-#pragma unroll
-        for (int j = 1; j <= TZ; ++j) {
-            float xip = shl(En[j], cm[j]), dd;
-            TVW_RINV(cm[j], xip, c0[j], cm[j + 1], Rm[j], dd)
-            (void)dd;
-        }
-        for (int y = y0; y < y1; ++y) {
-            if (y + 1 < y1) fetch(y + 2, cn, En);               // in flight while this row is computed
-            float xip[TZ + 1];
-#pragma unroll
-            for (int j = 0; j <= TZ; ++j) {
-                float dd;
-                xip[j] = shl(E0[j], c0[j]);
-                TVW_RINV(c0[j], xip[j], cp[j], c0[j + 1], R0[j], dd)
-                if (WITH_TV && j >= 1 && z0 + j - 1 < n && s < nx) tvacc += (double)dd;
-            }
-            // R(p - i) of lane 0 = R of lane 63 of the previous chunk's wave: through LDS for waves 1..3
-            const int par = (y - y0) & 1;
-            if (lane == 63) {
-#pragma unroll
-                for (int j = 1; j <= TZ; ++j) xr[par][wave][j - 1] = R0[j];
-            }
-            __syncthreads();
-            float re[TZ + 1];
-            if (wave == 0) {                                    // left neighbour is another workgroup or the halo plane
-#pragma unroll
-                for (int j = 1; j <= TZ; ++j) {
-                    float dd;
-                    TVW_RINV(E0[j], c0[j], Ep[j], E0[j + 1], re[j], dd)
-                    (void)dd;
-                }
-            } else {
-#pragma unroll
-                for (int j = 1; j <= TZ; ++j) re[j] = xr[par][wave - 1][j - 1];
-            }
-#pragma unroll
-            for (int j = 1; j <= TZ; ++j) {
-                float rim = shr(re[j], R0[j]);
-                float xim = shr(E0[j], c0[j]);
-                float c = c0[j];
-                float v1n = 3.0f * c - xip[j] - cp[j] - c0[j + 1];
-                float gv = v1n * R0[j];
-                gv += (c - xim) * rim;
-                gv += (c - cm[j]) * Rm[j];
-                gv += (c - c0[j - 1]) * R0[j - 1];
-                int z = z0 + j - 1;
-                if (z < n && s < nx) {
-                    const int so = __builtin_amdgcn_readfirstlane((int)((unsigned)(y * n + z) * (unsigned)rowb));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gv), rg, vo, so, 0);
-                    acc += (double)(gv * gv);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TZ + 2; ++j) { cm[j] = c0[j]; c0[j] = cp[j]; cp[j] = cn[j]; E0[j] = Ep[j]; Ep[j] = En[j]; }
-#pragma unroll
-            for (int j = 1; j <= TZ; ++j) Rm[j] = R0[j];
-        }
-#undef TVW_RINV
-    }
-    block_accumulate(acc, part);
     if (WITH_TV) {
         __syncthreads();
         block_accumulate(tvacc, part_tv);

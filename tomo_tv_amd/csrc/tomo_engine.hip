@@ -57,7 +57,7 @@ struct tomo_engine {
     uint2 *d_went = nullptr;
     float lipschitz = 0.f, lipschitz_cimmino = 0.f;
     int sart_fused = 1;                      // 1: SART sweep as a chain of fused BP+FP steps; 0: separate FP and BP per angle
-    int tv_lds = 1, tv_wg = 1, fp_all_lpr = 16;   // tv_wg: the workgroup-cooperative register march where the slab allows it
+    int tv_lds = 1, fp_all_lpr = 16;
     // fp_all_lpr: all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
     SegItemD *d_seg_exec = nullptr;
     std::vector<uint32_t> h_seg_exec_ptr;
@@ -1539,14 +1539,7 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
     }
     {
         ProfScope ps(e, TOMO_K_TV_GRAD);
-        const size_t vbytes = e->vol_elems() * sizeof(float);
-        const bool wg_ok = (e->sxc / 64) % 4 == 0 && vbytes <= 0xFFFFFFFFull && e->n >= 2;
-        if (e->tv_lds == 1 && e->tv_wg && wg_ok) {   // workgroup-cooperative register march (k_tv_grad_wg)
-            int yseg = 32;
-            dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
-            if (with_tv) hipLaunchKernelGGL((k_tv_grad_wg<true>), grid, dim3(256), 0, e->stream, x, h.lo, h.hi, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, (unsigned)vbytes);
-            else hipLaunchKernelGGL((k_tv_grad_wg<false>), grid, dim3(256), 0, e->stream, x, h.lo, h.hi, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, (unsigned)vbytes);
-        } else if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
+        if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
             int yseg = 32;   // 8 .. 64 rows per wave measured the same; longer segments leave too few waves
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
             if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
@@ -1836,7 +1829,6 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
         e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; return TOMO_OK;
     }
-    if (std::strcmp(name, "tv_wg") == 0) { e->tv_wg = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 1 register march, 8 / 16 LDS march (z-columns per workgroup), 0 direct
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
