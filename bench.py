@@ -351,6 +351,8 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
+        # every rank builds its own copy of the tables: share the host CPUs between the ranks
+        env.setdefault("TOMO_BUILD_THREADS", str(max(2, (os.cpu_count() or 8) // n)))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -386,6 +388,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:   # launched by torch.distributed.run: the same CPU sharing as spawn_ranks
+        os.environ.setdefault("TOMO_BUILD_THREADS", str(max(2, (os.cpu_count() or 8) // int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 

@@ -9,6 +9,9 @@
 // so that the float32 weights equal parallelRay's.
 #include "sysmat.h"
 
+#include <sched.h>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -16,6 +19,21 @@
 #include <thread>
 
 namespace tomo {
+
+// Host threads of the table builders: the CPUs this process may actually use (affinity mask; a cgroup quota is not visible
+// here), or TOMO_BUILD_THREADS when set -- one process per GPU builds its own tables, so a launcher that starts N ranks on
+// one node divides the CPUs between them (bench.py does).
+static unsigned builder_threads()
+{
+    if (const char *s = std::getenv("TOMO_BUILD_THREADS")) { int v = std::atoi(s); if (v > 0) return (unsigned)v; }
+    unsigned hw = std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { int c = CPU_COUNT(&set); if (c > 0) hw = std::min<unsigned>(hw ? hw : (unsigned)c, (unsigned)c); }
+#endif
+    return hw ? hw : 1u;
+}
+
 
 static inline double snap10(double v) { return std::fabs(v) < 1e-10 ? 0.0 : v; }
 
@@ -82,7 +100,7 @@ void build_parallel_ray(int N, int P, const double *angles_rad, Coo &out)
     }
     const double half = N / 2.0;
     const int64_t nrays = (int64_t)N * P;
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = builder_threads();
     int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, nrays / 64));
     std::vector<std::vector<uint32_t>> tcols(nth);
     std::vector<std::vector<float>> tvals(nth);
@@ -154,7 +172,7 @@ bool coo_from_triplets(int64_t nrow, int64_t ncol, int64_t nnz, const float *row
 // (row, col) keeps the last assignment.
 void sort_rows(Coo &m)
 {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = builder_threads();
     int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, m.nrow / 256));
     std::vector<uint32_t> keep(m.nrow, 0);
     auto work = [&](int t) {
@@ -277,7 +295,7 @@ void build_walk(const Coo &m, int N, int P, Tables &t)
         t.walk_ptr[r + 1] = t.walk_ptr[r] + (uint32_t)(m.ptr[r + 1] - m.ptr[r]) + extra[r];
     t.walk_pix.resize(t.walk_ptr[nrows]);
     t.walk_w.resize(t.walk_ptr[nrows]);
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = builder_threads();
     int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), P);
     auto work = [&](int th) {
         for (int i = th; i < P; i += nth) {
@@ -366,7 +384,7 @@ static void split_rows_by_tile(const Coo &m, int N, int64_t nrows, int TY, int T
     tmp_lpix.assign(nnz ? nnz : 1, 0u);
     tmp_w.assign(nnz ? nnz : 1, 0.f);
     rsegs.assign(nrows, {});
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = builder_threads();
     int nth = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, nrows / 256));
     auto work = [&](int th) {
         std::vector<std::pair<uint32_t, uint32_t>> key;   // (tile, position in row)
@@ -411,7 +429,7 @@ void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Ta
     std::vector<float> tmp_w;
     std::vector<std::vector<RowSeg>> rsegs;
     split_rows_by_tile(m, N, nrows, TY, TZ, t.tiles_z, tmp_lpix, tmp_w, rsegs);
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = builder_threads();
     (void)nnz;
     // pass 2: bucket the segments by tile
     struct Ref { uint32_t cnt, row, src; };               // src = offset of the segment's entries in the temp
@@ -526,7 +544,7 @@ void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows
     t.bp_win.assign((size_t)ntiles * P, 0);
     t.bp_cell.assign(((size_t)ntiles * P + pad_angles) * TP, Tables::TileCell{zero_off, 0.f, zero_off, 0.f});
     std::vector<uint8_t> bad(ntiles, 0);
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = builder_threads();
     int nth = (int)std::min<uint32_t>(std::max(1u, std::min(hw, 32u)), std::max(1u, ntiles / 8));
     auto work = [&](int th) {
         for (uint32_t k = ntiles * (uint64_t)th / nth; k < ntiles * (uint64_t)(th + 1) / nth; ++k) {
@@ -596,7 +614,7 @@ void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, 
     t.st_w.assign((size_t)(angle_batches[P] + 1) * NB, 0.f);
     std::vector<uint8_t> bad(P, 0);
     std::vector<uint32_t> ids_of(P, 0);
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = builder_threads();
     int nth = (int)std::min<int>(std::max(1u, std::min(hw, 32u)), P);
     auto work = [&](int th) {
         std::vector<uint32_t> nseg(ntiles), fill(ntiles);

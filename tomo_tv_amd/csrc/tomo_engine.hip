@@ -1087,7 +1087,7 @@ int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
         dim3 bgrid((unsigned)(((int64_t)ngroups * nchunk + 3) / 4));
         for (int i = 0; i < e->np; ++i) {
             if ((rc = launch_fp<FP_STORE>(e, x, i * e->n, e->n, nullptr, d))) return rc;
-            hipLaunchKernelGGL(k_art_chain, dim3((unsigned)((e->sx + 255) / 256)), dim3(256), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx);
+            hipLaunchKernelGGL(k_art_chain, dim3((unsigned)(e->sx / 64)), dim3(64 * ART_CW), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx);
             LAUNCHCHK();
             const CellD *cell = e->d_cell + (size_t)i * e->npix;
             const float *ai = a + (size_t)i * e->n * e->sx;
