@@ -223,3 +223,50 @@ def test_pack_tilt_series_layout():
     assert b.shape == (2, 12)
     for s in range(2):
         assert np.array_equal(b[s], ts[s].T.ravel())                   # gpu/reconstructor.py:54-56
+
+
+def test_engine_with_comm_lives_on_the_ranks_current_device(monkeypatch):
+    """With a process group and no explicit device= every engine class must take the device the rank selected
+    (torch.cuda.current_device()), not device 0 (round-1 advisor finding): checked on the constructor logic with a
+    recording backend."""
+    from tomo_tv_amd import chemistry, engine
+
+    seen = []
+
+    class Recorder:
+        def __init__(self, nslice, nray, nproj, angles_rad=None, A=None, device=0):
+            seen.append(device)
+            self.device = device
+
+        def enable_torch(self):
+            pass
+
+        def c(self, *a):
+            pass
+
+        def share_stream_with(self, other):
+            pass
+
+        def lipschitz(self):
+            return 1.0
+
+        def close(self):
+            pass
+
+    class Eng(engine.tomoengine):
+        _backend_cls = Recorder
+
+    class MM(chemistry.multimodal):
+        _engine_cls = Eng
+
+    comm = type("C", (), {"world": 2, "rank": 1})()
+    monkeypatch.setattr(engine._EngineBase, "_current_device", staticmethod(lambda: 5))
+    Eng(8, 16, np.zeros(3), comm=comm)
+    assert seen == [5]
+    Eng(8, 16, np.zeros(3), device=2, comm=comm)
+    assert seen[-1] == 2
+    Eng(8, 16, np.zeros(3))
+    assert seen[-1] == 0                       # no process group: the reference's default GPU 0
+    del seen[:]
+    MM(8, 16, 2, np.zeros(3), np.zeros(4), device=None, comm=comm)
+    assert seen == [5, 5]
