@@ -1,6 +1,8 @@
 """Run by test_gpu_distributed.py in a child process: world_size-1 RCCL group exercising the torch plumbing of the
 slab engine (torch-owned scalar/halo buffers bound into the C ABI, engine on torch's stream, all-reduce on the
-device scalar between the TV gradient and update kernels)."""
+device scalar between the TV gradient and update kernels).  The second sharded engine FORCES the real collectives in the
+one-rank group (all_reduce, broadcast, batch_isend_irecv to itself, all_gather_into_tensor, gather): the RCCL calls, tensor
+devices and stream ordering of the N > 1 path, on the only GPU a test box has."""
 import os
 import sys
 
@@ -26,8 +28,9 @@ N, P, Nx = 32, 7, 70
 ang = np.deg2rad(np.linspace(-60, 60, P))
 x = ellipsoids(Nx, N, seed=5)
 res = []
-for cls in (tomoengine, multigpuengine):
-    t = cls(Nx, N, ang)
+for make in (lambda: tomoengine(Nx, N, ang), lambda: multigpuengine(Nx, N, ang),
+             lambda: multigpuengine(Nx, N, ang, force_collectives=True)):
+    t = make()
     t.set_volume(x, VOL_ORIGINAL)
     t.create_projections()
     t.copy_recon()
@@ -40,10 +43,19 @@ for cls in (tomoengine, multigpuengine):
     out.append(t.tv_fgp(4, 0.05))
     v2 = t.get_volume()
     out.append(t.rmse())
-    res.append((np.array(out), v1, v2, t.get_recon(Nx - 1)))
-(a, a1, a2, a3), (b, b1, b2, b3) = res
-assert np.allclose(a, b, rtol=1e-6), (a, b)
-assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(a3, b3)
+    # the ASD-POCS step with its batched scalar read (one all-reduce of a gathered tensor)
+    from tomo_tv_amd._lib import S_DD, S_DIFF2
+    t.copy_recon()
+    t.SART_tracked(0.5, defer=True)
+    t.data_distance_begin()
+    out += list(t.tv_gd_tracked(3, 0.1, extra=(S_DD, S_DIFF2)))
+    out.append(t.tv_fgp(1, 0.05))                       # single iteration: the Obj / Grad pair with its two exchanges
+    res.append((np.array(out), v1, v2, t.get_recon(Nx - 1), t.get_volume(), t.get_projections()))
+for other in res[1:]:
+    a, b = res[0], other
+    assert np.allclose(a[0], b[0], rtol=1e-6), (a[0], b[0])
+    assert all(np.array_equal(p, q) for p, q in zip(a[1:], b[1:]))
+assert t.get_volume(dst=0).shape == (Nx, N, N)
 assert t.is_multi_gpu_enabled() is False and t.get_gpu_ids() == [0]
 dist.destroy_process_group()
 print("NCCL_WORLD1_OK")

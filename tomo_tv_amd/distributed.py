@@ -31,6 +31,9 @@ def slab_partition(nslice, world, rank):
 class SlabComm:
     """Thin wrapper over a ``torch.distributed`` process group for slab engines."""
     group: object = None
+    # issue the real collectives even in a group of ONE rank (a single-GPU box can then exercise the RCCL calls, tensor
+    # devices and stream ordering of the product's N > 1 path: tests/nccl_world1_script.py)
+    force: bool = False
 
     def __post_init__(self):
         import torch.distributed as dist
@@ -57,22 +60,22 @@ class SlabComm:
 
     def allreduce_sum(self, t):
         """In-place sum of tensor ``t`` over ranks (device tensor for RCCL, CPU tensor for gloo)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
     def allreduce_max(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return t
 
     def broadcast(self, t, src):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.broadcast(t, src=self.global_rank(src), group=self.group)
         return t
 
     def barrier(self):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.barrier(group=self.group)
 
     def exchange_planes(self, first_planes, last_planes, halo_lo, halo_hi):
@@ -80,7 +83,7 @@ class SlabComm:
         The tensors may hold several planes; ``halo_lo`` must match the neighbour's ``last_planes`` in size and
         ``halo_hi`` its ``first_planes``."""
         d = self.dist
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             halo_lo.copy_(last_planes)
             halo_hi.copy_(first_planes)
             return
@@ -96,7 +99,7 @@ class SlabComm:
         ``dst=None``: every rank returns the whole array (all_gather); ``dst=r``: only rank r does, the others
         return None (gather).  Uneven slabs are padded to the largest one for the collective."""
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return local
         maxc = max(counts)
         pad = np.zeros((maxc,) + local.shape[1:], np.float32)
@@ -118,7 +121,7 @@ class SlabComm:
     def all_gather_ints(self, value):
         """One integer per rank, as a list (device ids and the like)."""
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return [int(value)]
         dev = torch.device("cuda", torch.cuda.current_device()) if self.on_device() else "cpu"
         out = torch.zeros(self.world, dtype=torch.int64, device=dev)

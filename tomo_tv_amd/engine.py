@@ -295,14 +295,14 @@ class _EngineBase:
         """(Nslice, Ny, Nz).  Sharded: a collective; ``dst=None`` assembles the volume on every rank, ``dst=r`` on
         rank r only (the others return None)."""
         loc = self.get_volume_local(which)
-        if self.comm is None or self.comm.world == 1:
+        if self.comm is None or (self.comm.world == 1 and not getattr(self.comm, "force", False)):
             return loc
         return self.comm.gather_slabs(loc, self._counts(), device=getattr(self.be, "tdev", None), dst=dst)
 
     def _sino(self, which, dst=None):
         out = np.empty((self.nloc, self.Nrow), np.float32)
         self.be.c("get_sinogram", which, _ptr(out))
-        if self.comm is None or self.comm.world == 1:
+        if self.comm is None or (self.comm.world == 1 and not getattr(self.comm, "force", False)):
             return out
         return self.comm.gather_slabs(out, self._counts(), device=getattr(self.be, "tdev", None), dst=dst)
 
@@ -658,8 +658,8 @@ class multigpuengine(tomoengine):
     Replaces the OpenMP-thread-per-GPU class of tomofusion/gpu/utils/multigpuengine.cpp (host-resident volume,
     dynamic per-slice scheduling, TV on one GPU) by static device-resident slabs + RCCL."""
 
-    def __init__(self, Nslice, Nray, pyAngles=None, group=None):
-        super().__init__(Nslice, Nray, pyAngles, device=None, comm=SlabComm(group))
+    def __init__(self, Nslice, Nray, pyAngles=None, group=None, force_collectives=False):
+        super().__init__(Nslice, Nray, pyAngles, device=None, comm=SlabComm(group, force=force_collectives))
 
     def get_gpu_ids(self):
         return self.comm.all_gather_ints(self.gpuID)
