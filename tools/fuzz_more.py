@@ -4,9 +4,11 @@ Every kernel family against the oracle at random (N, P, Nx, angles); prints the 
 device fault names its case."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import oracle
-from tomo_tv_amd._lib import VOL_ORIGINAL
-from tomo_tv_amd.engine import tomoengine
+from local_ring import ThreadRing
+from tomo_tv_amd._lib import VOL_ORIGINAL, VOL_RECON
+from tomo_tv_amd.engine import ctvlib, system_matrix, tomoengine
 from tomo_tv_amd.phantom import ellipsoids
 def rel(a,b): return float(np.linalg.norm(a.astype(np.float64)-b)/max(np.linalg.norm(b),1e-30))
 rng0 = np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 777)
@@ -28,6 +30,29 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 30):
     print(' tv', flush=True); tv, dg = dev.tv_gd_tracked(2, 0.01); dev.synchronize(); tvr = ref.tv_gd(2, 0.01); e.append(abs(tv-tvr)/tvr); e.append(rel(dev.get_volume(), ref.recon))
     print(' fgp', flush=True); a = dev.tv_fgp(3, 0.02); dev.synchronize(); b = ref.tv_fgp(3, 0.02); e.append(abs(a-b)/b); e.append(rel(dev.get_volume(), ref.recon))
     print(' cgls', flush=True); dev.CGLS(1); dev.synchronize()
+    # two-stream SART == one chain (bitwise)
+    v0 = None
+    for ns in (1, 2):
+        dev.set_option("sart_streams", ns); dev.restart_recon(); dev.SART(0.7, 1); v = dev.get_volume()
+        if v0 is None: v0 = v
+    dev.set_option("sart_streams", 1)
+    e.append(0.0 if np.array_equal(v0, v) else 1.0)
+    # ART (chained, segmented scan) and the Cimmino branch through the ctvlib facade
+    print(' art', flush=True)
+    c = ctvlib(Nx, N, P); c.load_A(system_matrix(N, ang)); c.set_tilt_series(ref.b)
+    ref.row_inner_product(); ref.restart_recon(); ref.ART(0.5); ref.ART(0.45)
+    c.row_inner_product(); c.ART(0.5); c.ART(0.45); e.append(rel(c.get_volume(), ref.recon))
+    # slab-sharded TV / FGP on 2 or 3 slabs of this GPU (thread ring) against the whole slab
+    if Nx >= 3:
+        print(' sharded', flush=True)
+        world = int(rng.integers(2, 4))
+        xs = x + np.float32(0.03) * rng.random(x.shape, dtype=np.float32)
+        def script(t):
+            t.set_volume(xs, VOL_RECON); t.tv_eps = 1e-6
+            a = t.tv_gd(2, 0.05); g1 = t.get_volume(); t.set_volume(xs, VOL_RECON); b = t.tv_fgp(3, 0.03); return a, g1, b, t.get_volume()
+        whole = tomoengine(Nx, N, ang*np.pi/180); w = script(whole)
+        got = ThreadRing(world).run(lambda comm: script(tomoengine(Nx, N, ang*np.pi/180, device=0, comm=comm)))[0]
+        e += [abs(got[0]-w[0])/w[0], rel(got[1], w[1]), abs(got[2]-w[2])/w[2], 0.0 if np.array_equal(got[3], w[3]) else rel(got[3], w[3]) + 1e-5]
     ok = max(e) < 1e-5 and np.isfinite(dev.get_volume()).all()
     bad += (not ok)
     print(f"N={N} P={P} Nx={Nx}: max err {max(e):.2e} {'ok' if ok else 'FAIL ' + str(e)}", flush=True)
