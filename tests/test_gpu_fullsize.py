@@ -172,3 +172,46 @@ def test_sart_two_stream_sub_slabs_equal_one_chain(big):
     t.set_option("sart_streams", 1)
     assert res[1][0] == res[2][0] or abs(res[1][0] - res[2][0]) <= 1e-12 * res[1][0]   # fp64 partial sums, atomics in any order
     assert np.array_equal(res[1][1], res[2][1])
+
+
+def test_config4_whole_volume_on_one_gpu(gpu):
+    """BASELINE config 4 unsharded: 1024^3, 120 tilts on ONE GPU (4 GiB per volume, every byte offset beyond 2^31).
+    The phantom is the 128-slice shard phantom tiled 8 times along the tilt axis, so every 128-slice block of the whole-
+    volume result must equal what a 128 x 1024^2 engine makes of one block (slices share the system matrix): SART sweep
+    voxel for voxel, data distance, and the TV descent of the periodic 8-fold volume."""
+    import psutil
+    if psutil.virtual_memory().available < 40 * 2 ** 30:
+        pytest.skip("needs ~25 GiB of host memory for the 1024^3 arrays")
+    nx, n, p, blk = 1024, 1024, 120, 128
+    ang = np.deg2rad(tilt_angles(p))
+    xb = ellipsoids(blk, n)
+    small = tomoengine(blk, n, ang)
+    small.set_volume(xb, VOL_ORIGINAL)
+    small.create_projections()
+    bb = small.get_projections()
+    small.SART(0.5, 1)
+    want = small.get_volume()
+    dd_small = small.data_distance()
+    del small
+    t = tomoengine(nx, n, ang)
+    t.set_volume(np.tile(xb, (nx // blk, 1, 1)), VOL_ORIGINAL)
+    t.create_projections()
+    b = t.get_projections()
+    assert all(np.array_equal(b[k * blk:(k + 1) * blk], bb) for k in (0, 3, 7))
+    del b
+    t.SART(0.5, 1)
+    got = t.get_volume()
+    for k in (0, 4, 7):
+        assert rel_l2(got[k * blk:(k + 1) * blk], want) < 2e-6, k
+    dd = t.data_distance()
+    assert abs(dd - dd_small * np.sqrt(nx / blk)) <= 1e-5 * dd
+    # TV descent: the 8-fold periodic volume behaves like one period with periodic wrap (what a single slab does)
+    t.tv_eps = 1e-6
+    tv0 = t.tv_gd(2, 1.0)
+    small = tomoengine(blk, n, ang[:2])
+    small.set_volume(want, VOL_RECON)
+    small.tv_eps = 1e-6
+    tv0_small = small.tv_gd(2, 1.0 / np.sqrt(nx / blk))     # the step length is normalised by the global gradient norm
+    assert abs(tv0 - tv0_small * (nx / blk)) <= 2e-6 * tv0
+    got = t.get_volume()
+    assert rel_l2(got[5 * blk:6 * blk], small.get_volume()) < 5e-6
