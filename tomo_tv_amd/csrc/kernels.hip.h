@@ -1238,16 +1238,23 @@ __global__ __launch_bounds__(256) void k_mm_update(MMArgs a, const f4 *__restric
 }
 
 // ---- per-slice scalars (CGLS: every slice is its own least-squares problem with its own alpha, beta) -------
-// sums[s] += sum_m v[m][s]^2 over the rows m of this workgroup; lanes = slices, so the loads are coalesced
+// sums[s] += sum_m v[m][s]^2 over the rows m of this workgroup; a thread owns 4 consecutive slices (one float4 per row), so a
+// wave reads 1 KiB contiguous per row.  (Round 1's scalar form with a 64-bit modulo per element made a CGLS iteration
+// spend twice as long in these helpers as in the projectors.)
 __global__ __launch_bounds__(256) void k_slice_sumsq(const float *__restrict__ v, double *__restrict__ sums, int64_t m,
                                                       int sx, int rows_per_block)
 {
-    int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= sx) return;
-    int64_t m0 = (int64_t)blockIdx.y * rows_per_block, m1 = min(m, m0 + rows_per_block);
-    double acc = 0.0;
-    for (int64_t r = m0; r < m1; ++r) { float a = v[r * sx + s]; acc += (double)(a * a); }
-    atomicAdd(&sums[s], acc);
+    const int s4 = blockIdx.x * 256 + threadIdx.x;                  // float4 column: slices 4*s4 .. 4*s4+3
+    if (s4 * 4 >= sx) return;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_block, m1 = min(m, m0 + rows_per_block);
+    const f4 *p = reinterpret_cast<const f4 *>(v) + s4;
+    const int64_t pitch4 = sx / 4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int64_t r = m0; r < m1; ++r) {
+        f4 a = p[r * pitch4];
+        a0 += (double)(a.x * a.x); a1 += (double)(a.y * a.y); a2 += (double)(a.z * a.z); a3 += (double)(a.w * a.w);
+    }
+    atomicAdd(&sums[4 * s4], a0); atomicAdd(&sums[4 * s4 + 1], a1); atomicAdd(&sums[4 * s4 + 2], a2); atomicAdd(&sums[4 * s4 + 3], a3);
 }
 
 // coef[s] = num[s] / den[s] (0 when den == 0)
@@ -1257,24 +1264,23 @@ __global__ void k_slice_ratio(const double *__restrict__ num, const double *__re
     if (s < sx) coef[s] = den[s] > 0.0 ? (float)(num[s] / den[s]) : 0.f;
 }
 
-// y[m][s] = ay * y[m][s] + sign * coef[s] * x[m][s]      (ay = 1: y += c x ; used with p = z + beta p as y=p, ay->coef)
-__global__ __launch_bounds__(256) void k_slice_axpy(float *__restrict__ y, const float *__restrict__ x,
-                                                     const float *__restrict__ coef, float sign, int64_t n, int sx)
+// y[m][s] = y[m][s] + sign * coef[s] * x[m][s]: float4 grid-stride over n4 = n/4 elements, sx4 = sx/4 float4 per row.
+// The grid stride is a multiple of sx4 (the launcher rounds it), so a thread's slice group -- and its 4 coefficients -- never change.
+__global__ __launch_bounds__(256) void k_slice_axpy(f4 *__restrict__ y, const f4 *__restrict__ x,
+                                                     const f4 *__restrict__ coef, float sign, int64_t n4, int sx4)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        int s = (int)(i % sx);
-        y[i] = y[i] + sign * coef[s] * x[i];
-    }
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const f4 c = sign * coef[i0 % sx4];
+    for (int64_t i = i0; i < n4; i += stride) y[i] = y[i] + c * x[i];
 }
 
 // p[m][s] = z[m][s] + coef[s] * p[m][s]
-__global__ __launch_bounds__(256) void k_slice_xpay(float *__restrict__ p, const float *__restrict__ z,
-                                                     const float *__restrict__ coef, int64_t n, int sx)
+__global__ __launch_bounds__(256) void k_slice_xpay(f4 *__restrict__ p, const f4 *__restrict__ z,
+                                                     const f4 *__restrict__ coef, int64_t n4, int sx4)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        int s = (int)(i % sx);
-        p[i] = z[i] + coef[s] * p[i];
-    }
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const f4 c = coef[i0 % sx4];
+    for (int64_t i = i0; i < n4; i += stride) p[i] = z[i] + c * p[i];
 }
 
 // filtered sinogram for WBP: out[i*N + j][s] = sum_k h[|j - k|] in[i*N + k][s]; one wave = one output ray x 64*VEC slices

@@ -1130,11 +1130,21 @@ int tomo_poisson_residual(tomo_engine *e, int vol, int sino_b, int sino_out)
 static int slice_sumsq(tomo_engine *e, const float *v, int64_t m, double *sums)
 {
     HIPCHK(hipMemsetAsync(sums, 0, e->sx * sizeof(double), e->stream));
-    int rpb = (int)std::max<int64_t>(64, (m + 1023) / 1024);
-    dim3 grid((unsigned)((e->sx + 255) / 256), (unsigned)((m + rpb - 1) / rpb));
+    int rpb = (int)std::max<int64_t>(64, (m + 4095) / 4096);
+    dim3 grid((unsigned)((e->sx / 4 + 255) / 256), (unsigned)((m + rpb - 1) / rpb));
     hipLaunchKernelGGL(k_slice_sumsq, grid, dim3(256), 0, e->stream, v, sums, m, e->sx, rpb);
     LAUNCHCHK();
     return TOMO_OK;
+}
+
+// grid of the per-slice axpy kernels: its stride (blocks * 256 float4) must be a multiple of sx/4 so that a thread keeps its
+// slice group; sx is a multiple of 64, so sx/4 divides 256 * (sx/4) / gcd -- simply take a block count that is a multiple of sx/64
+static unsigned slice_grid(const tomo_engine *e, int64_t n4)
+{
+    const int64_t unit = std::max(1, e->sx / 64);          // blocks per 4 rows... 256 float4 = 1024 floats = 1024/sx rows
+    int64_t b = std::min<int64_t>((n4 + 255) / 256, 8192);
+    b = std::max<int64_t>(unit, (b / unit) * unit);
+    return (unsigned)b;
 }
 
 int tomo_cgls(tomo_engine *e, int vol, int niter)
@@ -1161,14 +1171,14 @@ int tomo_cgls(tomo_engine *e, int vol, int niter)
         if ((rc = launch_fp_all<FP_STORE>(e, e->cg_p, nullptr, e->cg_w))) return rc;
         if ((rc = slice_sumsq(e, e->cg_w, e->nrows, tmp))) return rc;
         ratio(gam, tmp);
-        hipLaunchKernelGGL(k_slice_axpy, dim3(grid_1d(nv / 4)), dim3(256), 0, e->stream, x, e->cg_p, e->cg_coef, 1.f, nv, e->sx);
-        hipLaunchKernelGGL(k_slice_axpy, dim3(grid_1d(ns / 4)), dim3(256), 0, e->stream, r, e->cg_w, e->cg_coef, -1.f, ns, e->sx);
+        hipLaunchKernelGGL(k_slice_axpy, dim3(slice_grid(e, nv / 4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)e->cg_p, (const f4 *)e->cg_coef, 1.f, nv / 4, e->sx / 4);
+        hipLaunchKernelGGL(k_slice_axpy, dim3(slice_grid(e, ns / 4)), dim3(256), 0, e->stream, (f4 *)r, (const f4 *)e->cg_w, (const f4 *)e->cg_coef, -1.f, ns / 4, e->sx / 4);
         // z = A^T r ; beta = |z|^2 / gamma ; gamma = |z|^2 ; p = z + beta p
         if ((rc = launch_bp_all(e, e->cg_z, r, nullptr, 0.f, 1.f, 0))) return rc;
         if ((rc = slice_sumsq(e, e->cg_z, e->npix, tmp))) return rc;
         ratio(tmp, gam);
         HIPCHK(hipMemcpyAsync(gam, tmp, e->sx * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-        hipLaunchKernelGGL(k_slice_xpay, dim3(grid_1d(nv / 4)), dim3(256), 0, e->stream, e->cg_p, e->cg_z, e->cg_coef, nv, e->sx);
+        hipLaunchKernelGGL(k_slice_xpay, dim3(slice_grid(e, nv / 4)), dim3(256), 0, e->stream, (f4 *)e->cg_p, (const f4 *)e->cg_z, (const f4 *)e->cg_coef, nv / 4, e->sx / 4);
         LAUNCHCHK();
     }
     return tomo_positivity(e, vol);
