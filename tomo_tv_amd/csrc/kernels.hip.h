@@ -726,6 +726,13 @@ constexpr int ST_LDS_V = (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16 + ST_PIX;     //
 // launch (round 2; the kernel is not HBM-bound, see above).  Cells with host-normalised weights (two FMAs per component, no
 // division at all) measured the same 215 us, so the cells keep the raw weights and the formula of k_bp_angle / k_sart_seg:
 // the three forms are bit-identical.
+#ifdef TOMO_WHATIF   // measurement builds only (make EXTRA=-DTOMO_WHATIF): switch parts of k_sart_tile off, results are WRONG
+__device__ int g_sart_whatif = 0;   // 1 no x stores, 2 no BP arithmetic, 4 no FP phase, 8 no window / cell staging, 16 no tile loads
+#define ST_WI(bit) (wi_ & (bit))
+#else
+#define ST_WI(bit) 0
+#endif
+
 template <bool FUSED>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
@@ -735,6 +742,9 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
                                                            int n, int sx, int tiles_z, int ntiles, int nchunk, int chunk0)
 {
     typedef VecOf<4>::T V;
+#ifdef TOMO_WHATIF
+    const int wi_ = g_sart_whatif;
+#endif
     extern __shared__ V st_lds[];                       // ST_LDS_V float4 (dynamic)
     V *img = st_lds, *win = st_lds + (ST_PIX + 1) * 16;
     uint4 *cel = reinterpret_cast<uint4 *>(st_lds + (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16);
@@ -761,7 +771,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     V xv[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
-        xv[J] = (y < n && z0 + J < n) ? *reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off) : vzero<4>();
+        xv[J] = (y < n && z0 + J < n && !ST_WI(16)) ? *reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off) : vzero<4>();
     uint2 eb[ST_SPG][ST_MAXB];
 #pragma unroll
     for (int q = 0; q < ST_SPG; ++q) {
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
 #pragma unroll
         for (int b = 0; b < ST_MAXB; ++b) eb[q][b] = ((uint32_t)b < sd[q].y) ? ep[(size_t)b * FT_BATCH] : make_uint2((uint32_t)ST_PIX * 256u, 0u);
     }
-    if (FUSED) {
+    if (FUSED && !ST_WI(8)) {
         uint32_t w = wins[tile];
         for (int i = t; i < (ST_MAXR + 1) * 16; i += ST_THREADS) {
             int j = i >> 4;
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
         if (t < ST_PIX) cel[t] = cells[(size_t)tile * ST_PIX + t];
     }
     if (t < 16) img[ST_PIX * 16 + t] = vzero<4>();
-    if (FUSED) {
+    if (FUSED && !ST_WI(2)) {
         __syncthreads();
         const char *wb = reinterpret_cast<const char *>(win) + gl * 16;
 #pragma unroll
@@ -793,8 +803,15 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             V nv = xv[J] + beta * upd;
             nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
             xv[J] = nv;
-            if (y < n && z0 + J < n) *reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off) = nv;
+            if (y < n && z0 + J < n && !ST_WI(1)) *reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off) = nv;
         }
+    }
+    if (ST_WI(4)) {
+        if (FUSED && ST_WI(2) && !ST_WI(1)) {   // copy-through when the update is off but the stores are on
+#pragma unroll
+            for (int J = 0; J < 8; ++J) if (y < n && z0 + J < n) *reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off) = xv[J];
+        }
+        return;
     }
 #pragma unroll
     for (int J = 0; J < 8; ++J) img[(g * 8 + J) * 16 + gl] = xv[J];
