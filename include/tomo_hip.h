@@ -219,6 +219,9 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "tv_lds" (1):     TV gradient kernel: 1 = register march (one wave = 8 z-columns x 64 slices, rows in registers,
  *                     slice neighbours by DPP; bit-identical to the LDS march and 13 % faster), 8 / 16 = LDS march with that
  *                     many z-columns per workgroup, 0 = direct-global stencil
+ *   "tv_recompute" (1): a tv_gd inner iteration as "norm pass (sum g^2, nothing stored) + update pass that re-evaluates g and writes
+ *                     x_new into a second buffer" instead of "gradient pass (store g) + update pass (read x, g; write x)": one volume
+ *                     write instead of two -- HBM writes are the scarce resource (3 TB/s against ~6 for reads); bit-identical
  *   "fgp_fused" (1):  one fused kernel per FGP iteration (single slab)
  *   "art_chain" (1):  tomo_art in natural row order as per-angle FP + ray recurrence + BP (k_art_chain) instead of
  *                     row-by-row steps (k_art, which still serves tomo_art_order with a permutation)

@@ -1434,6 +1434,20 @@ __global__ __launch_bounds__(256) void k_tv_grad(const float *__restrict__ x, Ha
 //    reciprocal R = 1/D (<= 1 ulp) is shared through LDS, and the gradient is
 //    g = (3c - x_ip - x_jp - x_kp) R(p) + (c - x_im) R(p-i) + (c - x_jm) R(p-j) + (c - x_km) R(p-k).
 //    (v * (1/D) instead of v / D: at most one ulp per term away from the reference's expression.)
+// The gradient value from its thirteen inputs, with every rounding written out (explicit fma / mul / sub): the march kernels
+// are instantiated in several modes (store / norm only / recompute-and-update; LDS or register march) and the compiler's
+// contraction choices differ between instantiations -- this keeps all of them bit-identical.
+__device__ __forceinline__ float tv_gval(float c, float xip, float xjp, float xkp, float r0, float xim, float rim,
+                                          float xjm, float rjm, float xkm, float rkm)
+{
+    float v1n = __fsub_rn(__fsub_rn(__fmaf_rn(3.0f, c, -xip), xjp), xkp);
+    float gv = __fmul_rn(v1n, r0);
+    gv = __fmaf_rn(__fsub_rn(c, xim), rim, gv);
+    gv = __fmaf_rn(__fsub_rn(c, xjm), rjm, gv);
+    gv = __fmaf_rn(__fsub_rn(c, xkm), rkm, gv);
+    return gv;
+}
+
 constexpr int TVL_TZ = 8;          // z-columns per workgroup of the FGP kernel (2 per wave)
 constexpr int TVL_PITCH = 66;      // 64 slices + halo each side
 
@@ -1533,11 +1547,9 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
             int z = z0 + zi - 1;
             if (z < n && s < nx) {
                 float c = ring[m1][zi][si];
-                float v1n = 3.0f * c - ring[m1][zi][si + 1] - ring[m2][zi][si] - ring[m1][zi + 1][si];
-                float gv = v1n * rinv[rc][zi][si];
-                gv += (c - ring[m1][zi][si - 1]) * rinv[rc][zi][si - 1];
-                gv += (c - ring[m0][zi][si]) * rinv[rp][zi][si];
-                gv += (c - ring[m1][zi - 1][si]) * rinv[rc][zi - 1][si];
+                float gv = tv_gval(c, ring[m1][zi][si + 1], ring[m2][zi][si], ring[m1][zi + 1][si], rinv[rc][zi][si],
+                                   ring[m1][zi][si - 1], rinv[rc][zi][si - 1], ring[m0][zi][si], rinv[rp][zi][si],
+                                   ring[m1][zi - 1][si], rinv[rc][zi - 1][si]);
                 g[(size_t)(y * n + z) * sx + s] = gv;
                 acc += (double)(gv * gv);
             }
@@ -1578,14 +1590,27 @@ inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
     return (unsigned)(((int64_t)nzb * nchunk * nys + 3) / 4);
 }
 
-template <int TZ, bool WITH_TV, bool GRAD = true>
+// MODE (round 2).  HBM WRITES are the scarce resource on this part (a 537 MB memset runs at 3.0 TB/s, a read stream at ~6;
+// tools/whatif_sart.py), and a tv_gd inner iteration as "gradient pass (write g) + update pass (read x, g; write x)" writes the
+// volume twice.  So the gradient is never stored:
+//   TVM_NORM    the pass only accumulates sum g^2 (and, WITH_TV, the TV value): reads x, writes nothing;
+//   TVM_UPDATE  the pass re-evaluates g (bit for bit the same arithmetic) and writes x_new = x - (dPOCS g)/||g|| into a SECOND
+//               buffer (neighbours still read the old x), clamp / wrapped halo planes / tracked norm + snapshot as in
+//               k_tv_update.  One volume write per inner iteration instead of two, 8 instead of 12 bytes read.
+//   TVM_STORE   the round-1 form (g stored; k_tv_update applies it): kept for the A/B option and the other kernel forms.
+enum { TVM_STORE = 0, TVM_NORM = 1, TVM_UPDATE = 2 };
+struct TvUpd { float *x_out; const double *gnorm2; float dPOCS; int clamp; float *track; float *wrap_lo; float *wrap_hi; };
+
+template <int TZ, bool WITH_TV, bool GRAD = true, int MODE = TVM_STORE>
 __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x, Halo h, float *__restrict__ g,
                                                       double *__restrict__ part, float eps, int n, int nx, int sx,
-                                                      int yseg, double *__restrict__ part_tv)
+                                                      int yseg, double *__restrict__ part_tv, TvUpd up = TvUpd{})
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
     double acc = 0.0, tvacc = 0.0;
+    float nrm_ = 1.f;
+    if (MODE == TVM_UPDATE) nrm_ = (float)sqrt(*up.gnorm2);
     // Item = (y segment, z block, chunk).  Neighbouring z blocks share two of their ten columns and neighbouring chunks a
     // slice on either side: when the neighbours run on different XCDs every shared line is fetched from HBM once per XCD
     // (PMC, round 2: 1.72x the compulsory reads, and the kernel is bound by exactly that traffic: 1.46 GB in 288 us).
@@ -1678,16 +1703,31 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                 float rim = shr(re, R0[j]);
                 float xim = shr(E0[j], c0[j]);
                 float c = c0[j];
-                float v1n = 3.0f * c - xip[j] - cp[j] - c0[j + 1];
-                float gv = v1n * R0[j];
-                gv += (c - xim) * rim;
-                gv += (c - cm[j]) * Rm[j];
-                gv += (c - c0[j - 1]) * R0[j - 1];
+                float gv = tv_gval(c, xip[j], cp[j], c0[j + 1], R0[j], xim, rim, cm[j], Rm[j], c0[j - 1], R0[j - 1]);
                 int z = z0 + j - 1;
                 if (z < n && s < nx) {
-                    float *gr = g + (size_t)(y * n + z) * sx;
-                    gr[(unsigned)s] = gv;
-                    acc += (double)(gv * gv);
+                    if (MODE == TVM_STORE) {
+                        float *gr = g + (size_t)(y * n + z) * sx;
+                        gr[(unsigned)s] = gv;
+                        acc += (double)(gv * gv);
+                    } else if (MODE == TVM_NORM) {
+                        acc += (double)(gv * gv);
+                    } else {   // TVM_UPDATE: the expression of k_tv_update
+                        const size_t pix = (size_t)(y * n + z);
+                        float v = __fsub_rn(c, __fdiv_rn(__fmul_rn(up.dPOCS, gv), nrm_));   // = k_tv_update's x - (dPOCS g)/||g||
+                        if (up.clamp) v = fmaxf(v, 0.f);
+                        up.x_out[pix * sx + (unsigned)s] = v;
+                        if (up.wrap_lo) {
+                            if (s == 0) up.wrap_hi[pix] = v;
+                            if (s == nx - 1) up.wrap_lo[pix] = v;
+                        }
+                        if (up.track) {
+                            float *tr = up.track + pix * sx;
+                            float d = v - tr[(unsigned)s];
+                            acc += (double)(d * d);
+                            tr[(unsigned)s] = v;
+                        }
+                    }
                 }
             }
             // rotate the rows by register moves (rotating them by name, a 4x unrolled loop, costs a wave of occupancy:

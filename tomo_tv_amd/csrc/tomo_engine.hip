@@ -58,6 +58,11 @@ struct tomo_engine {
     float lipschitz = 0.f, lipschitz_cimmino = 0.f;
     int sart_fused = 1;                      // 1: SART sweep as a chain of fused BP+FP steps; 0: separate FP and BP per angle
     int tv_lds = 1, fp_all_lpr = 16;
+    // tv_recompute: a tv_gd inner iteration as "norm pass (no store) + recompute-and-update pass into a second buffer" instead
+    // of "gradient pass (store g) + update pass": one volume write instead of two (HBM writes are the scarce resource)
+    int tv_recompute = 1;
+    float tv_last_eps = 1e-6f;
+    float *tv_alt = nullptr, *halo_lo_alt = nullptr, *halo_hi_alt = nullptr;
     // fp_all_lpr: all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
     SegItemD *d_seg_exec = nullptr;
     std::vector<uint32_t> h_seg_exec_ptr;
@@ -688,7 +693,7 @@ int tomo_destroy(tomo_engine *e)
     for (int u = 0; u < 2; ++u) if (e->sub_stream[u]) { (void)hipStreamSynchronize(e->sub_stream[u]); (void)hipStreamDestroy(e->sub_stream[u]); (void)hipEventDestroy(e->ev_sjoin[u]); }
     if (e->ev_sfork) (void)hipEventDestroy(e->ev_sfork);
     free_geometry(e);
-    void *ptrs[] = {e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_coef, e->sart_alt,
+    void *ptrs[] = {e->tv_alt, e->halo_lo_alt, e->halo_hi_alt, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_coef, e->sart_alt,
                     e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -1523,7 +1528,7 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
     HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
     const int yseg = 32;
     if (e->tv_lds == 1) {
-        hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
+        hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
     } else {
         dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
         hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
@@ -1549,11 +1554,17 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
     }
     {
         ProfScope ps(e, TOMO_K_TV_GRAD);
-        if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
+        e->tv_last_eps = eps;
+        if (e->tv_lds == 1 && e->tv_recompute) {   // sum g^2 (and TV) only: the update pass re-evaluates g (TVM_UPDATE)
+            int yseg = 32;
+            dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
+            if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
+            else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
+        } else if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
             int yseg = 32;   // 8 .. 64 rows per wave measured the same; longer segments leave too few waves
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
-            if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
-            else hipLaunchKernelGGL((k_tv_grad_reg<8, false>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr);
+            if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
+            else hipLaunchKernelGGL((k_tv_grad_reg<8, false>), grid, dim3(256), 0, e->stream, x, h, g, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
         } else if (e->tv_lds) {
             int yseg = 32;
             if (e->tv_lds == 16) {
@@ -1613,6 +1624,36 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
         // of the snapshot): order this write behind it on the device; tomo_async_wait later is still valid
         if ((rc = order_after_async(e))) return rc;
         if ((rc = reduce_begin(e))) return rc;
+    }
+    if (e->tv_lds == 1 && e->tv_recompute) {
+        // recompute-and-update pass: reads x (+ the halo planes the norm pass used), writes x_new into the second buffer,
+        // which then becomes the volume.  The wrapped planes of x_new go to a second pair of halo buffers (this pass still
+        // reads the old ones), swapped in afterwards; halo buffers bound by the caller are refreshed by a gather launch.
+        float *alt;
+        if ((rc = get_scratch(e, &e->tv_alt, &alt))) return rc;
+        const bool own_halo = e->halo_lo == e->halo_lo_own || e->halo_lo == e->halo_lo_alt;
+        float *wl = plane_last, *wh = plane_first;
+        if (wrap && own_halo) {
+            if (!e->halo_lo_alt) {
+                if ((rc = dev_alloc((void **)&e->halo_lo_alt, e->npix * sizeof(float), true, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->halo_hi_alt, e->npix * sizeof(float), true, e->stream))) return rc;
+            }
+            wl = e->halo_lo == e->halo_lo_own ? e->halo_lo_alt : e->halo_lo_own;
+            wh = e->halo_hi == e->halo_hi_own ? e->halo_hi_alt : e->halo_hi_own;
+        }
+        Halo h{e->halo_lo, e->halo_hi};
+        TvUpd up{alt, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, track, wl, wh};
+        {
+            ProfScope ps(e, TOMO_K_TV_UPDATE);
+            int yseg = 32;
+            dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
+            hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
+        }
+        LAUNCHCHK();
+        e->vol[e->tv_target] = alt; e->tv_alt = x;              // the updated volume lives in the partner buffer
+        if (wrap && own_halo) { e->halo_lo = wl; e->halo_hi = wh; }
+        else if (wrap) { if ((rc = tomo_halo_local(e, e->tv_target))) return rc; }
+        return track ? reduce_end(e, slot) : TOMO_OK;
     }
     int64_t n4 = e->vol_elems() / 4;
     {
@@ -1842,6 +1883,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
         e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; return TOMO_OK;
     }
+    if (std::strcmp(name, "tv_recompute") == 0) { e->tv_recompute = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 1 register march, 8 / 16 LDS march (z-columns per workgroup), 0 direct
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
