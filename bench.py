@@ -146,22 +146,51 @@ def cpu_baselines(n, nproj, budget_s=14.0):
 
 # ---- per-kernel roofline from the engine's HIP-event log ----------------------------------------------------------------
 class KernelLog:
+    """The engine's HIP-event log of the named kernels.  A sub-slab group (tomoengine(..., sub_slabs=K)) logs per sub-slab
+    engine; the launches of all of them are put on one time base (same device) and merged."""
+
     def __init__(self, t, ids):
         from tomo_tv_amd import _lib
-        self._lib, self.t, self.ids = _lib, t, ids
-        for kid in ids.values():
-            _lib.check(t.be.L.tomo_profile_enable(t.be.h, kid, 1))
+        self._lib, self.ids = _lib, ids
+        self.kids = list(getattr(t.be, "kids", [t.be]))
+        for kid in self.kids:
+            for kid_id in ids.values():
+                _lib.check(kid.L.tomo_profile_enable(kid.h, kid_id, 1))
 
     def read(self):
         """name -> (launches, summed launch durations in ms, ms during which at least one launch was executing)."""
         import ctypes
         out = {}
-        for name, kid in self.ids.items():
-            launches, total_ms, busy_ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
-            self._lib.check(self.t.be.L.tomo_profile_read2(self.t.be.h, kid, ctypes.byref(launches), ctypes.byref(total_ms),
-                                                           ctypes.byref(busy_ms)))
-            self._lib.check(self.t.be.L.tomo_profile_enable(self.t.be.h, kid, 0))
-            out[name] = (int(launches.value), float(total_ms.value), float(busy_ms.value))
+        L = self.kids[0].L
+        for name, kid_id in self.ids.items():
+            if len(self.kids) == 1:
+                launches, total_ms, busy_ms = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+                self._lib.check(L.tomo_profile_read2(self.kids[0].h, kid_id, ctypes.byref(launches), ctypes.byref(total_ms),
+                                                     ctypes.byref(busy_ms)))
+                out[name] = (int(launches.value), float(total_ms.value), float(busy_ms.value))
+            else:
+                iv = []
+                for kid in self.kids:
+                    n = ctypes.c_int(0)
+                    self._lib.check(L.tomo_profile_intervals(kid.h, kid_id, self.kids[0].h, None, None, 0, ctypes.byref(n)))
+                    t0, t1 = np.zeros(max(n.value, 1)), np.zeros(max(n.value, 1))
+                    self._lib.check(L.tomo_profile_intervals(kid.h, kid_id, self.kids[0].h, t0.ctypes.data_as(ctypes.c_void_p),
+                                                             t1.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n)))
+                    iv += list(zip(t0[:n.value], t1[:n.value]))
+                iv.sort()
+                busy, cur_a, cur_b = 0.0, 0.0, -1.0
+                for a, b in iv:
+                    if cur_b < cur_a or a > cur_b:
+                        if cur_b >= cur_a:
+                            busy += cur_b - cur_a
+                        cur_a, cur_b = a, b
+                    else:
+                        cur_b = max(cur_b, b)
+                if cur_b >= cur_a:
+                    busy += cur_b - cur_a
+                out[name] = (len(iv), float(sum(b - a for a, b in iv)), float(busy))
+            for kid in self.kids:
+                self._lib.check(L.tomo_profile_enable(kid.h, kid_id, 0))
         return out
 
 
@@ -403,6 +432,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the slab-sharded engine + its communicator even with one rank")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL); tests drive the launcher with gloo")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tomo_set_option), repeatable")
+    ap.add_argument("--sub-slabs", type=int, default=1,
+                    help="run the GPU's slab as K sub-slab engines side by side (engine.py: _GroupBackend; single GPU only). "
+                         "Measured -1...-3 %% per step at K = 2 and box-dependent, so the default is one engine")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -458,7 +490,7 @@ def main():
         comm = t.comm
     else:
         from tomo_tv_amd.engine import tomoengine
-        t = tomoengine(nglobal, n, ang, device=0)
+        t = tomoengine(nglobal, n, ang, device=0, sub_slabs=max(1, args.sub_slabs))
     first, nloc = slab_partition(nglobal, world, rank) if comm is not None else (0, nglobal)
     # synthetic data: strong scaling -> this rank's slab of ONE seeded phantom; weak -> the same phantom on every rank
     if args.scaling == "strong":
@@ -500,7 +532,7 @@ def main():
     el = time.perf_counter() - t0
     prof = log.read() if log else {}
     iso = None
-    if on_gpu and sart_sub_slabs(slab_partition(nglobal, world, rank)[1] if comm is not None else nglobal, args.opt) > 1:
+    if on_gpu and getattr(t, "sub_slabs", 1) == 1 and sart_sub_slabs(slab_partition(nglobal, world, rank)[1] if comm is not None else nglobal, args.opt) > 1:
         # the dominant kernel alone on the chip (one chain, one stream), one untimed step: the kernel's own rate
         t.set_option("sart_streams", 1)
         log1 = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED})
@@ -530,7 +562,7 @@ def main():
         alg_bytes = {K_BP_NAME: 16.0 * V + 4.0 * nloc * n, K_FUSED_NAME: 8.0 * V + 12.0 * nloc * n,
                      K_FP_NAME: 4.0 * V + 8.0 * nloc * n}
         roofs = {}
-        nsub = sart_sub_slabs(nloc, args.opt)      # launches per angle: the sweep runs as nsub sub-slabs on nsub streams
+        nsub = sart_sub_slabs(nloc, args.opt) * max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)   # launches per angle
         for name, (cnt, tot, busy) in prof.items():
             roofs[name] = roof(name, cnt, tot, alg_bytes[name] / nsub, busy_ms=busy)
             roofs[name]["sub_slabs"] = nsub
@@ -566,7 +598,8 @@ def main():
             "config": {"workload": f"ASD-POCS iteration (SART sweep beta0=0.25 + 10 TV-GD steps) on ONE {shape} volume, {nproj} tilts "
                                    f"-70..70 deg (headline SART+TV 512^3x90 = BASELINE configs[2] shape), {nloc} slices on rank 0",
                        "volume": shape, "slices_per_gpu": nloc, "nray": n, "nproj": nproj,
-                       "sharding": f"tilt-axis slabs x{world} ({args.scaling} scaling)"},
+                       "sharding": f"tilt-axis slabs x{world} ({args.scaling} scaling)",
+                       "sub_slabs_per_gpu": getattr(t, "sub_slabs", 1)},
             "final_dd": dd, "final_tv": tv,
             "roofline": dominant,
             "roofline_bp_angle": roofs.get(K_BP_NAME),

@@ -44,6 +44,7 @@ enum tomo_scalar { TOMO_S_DD = 0,      /* sum (A x - b)^2            data_distan
                    TOMO_S_RMSE = 4,    /* sum (recon - original)^2   rmse           */
                    TOMO_S_COST = 5,    /* Poisson-ML cost            poisson_ML     */
                    TOMO_S_L1 = 6,      /* sum |recon|                l1_norm        */
+                   TOMO_S_GNORM_ALL = 8, /* sum g^2 over the sub-slab engines of a slab group (tomo_scalar_sum_from) */
                    TOMO_S_DIFF2 = 7,   /* a second step-norm slot: ASD-POCS keeps the SART step norm here until the
                                           iteration's scalars are read together (one all-reduce, one read-back) */
                    TOMO_S_COUNT = 16 };
@@ -163,6 +164,14 @@ int tomo_halo_pack(tomo_engine *e, int field, int last, void *device_dst); /* fi
 int tomo_halo_pack_both(tomo_engine *e, int field, void *first_plane, void *last_plane);  /* both planes, one launch */
 int tomo_halo_local(tomo_engine *e, int field);
 enum tomo_field { TOMO_FIELD_FGP_D = 100, TOMO_FIELD_FGP_P1 = 101 };
+/* Several slab engines on ONE device (a slab run as K sub-slabs, each with its own allocations and stream, so that their
+ * dependent launch chains overlap): the three calls the coupling of the sub-slabs needs -- stream ordering, halo planes taken
+ * straight from the neighbours' volumes (ring of sub-slabs = the periodic wrap of ctvlib.cpp:348,421; mpi_ctvlib.cpp:400-422
+ * does it with MPI), and the sum of the engines' partial sums on the device (mpi_ctvlib.cpp:547 MPI_Allreduce).
+ * "tv_gnorm_slot" (tomo_set_option) names the scalar slot the TV update reads ||g||^2 from. */
+int tomo_wait_for(tomo_engine *e, tomo_engine *other);
+int tomo_halo_from(tomo_engine *e, int field, tomo_engine *lo_src, tomo_engine *hi_src);
+int tomo_scalar_sum_from(tomo_engine *e, int dst_slot, tomo_engine **srcs, int n, int src_slot);
 /* global-edge flags for the non-periodic FGP stencil (tv_fgp.cu:57,81) */
 int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last);
 
@@ -253,6 +262,8 @@ int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *tot
 /* the same, also busy_ms = time during which at least one launch of the kernel was executing (union of the launch
  * intervals): the SART sweep runs as two sub-slabs on two streams ("sart_streams"), so two launches of a kernel overlap */
 int tomo_profile_read2(tomo_engine *e, int kernel, int64_t *launches, double *total_ms, double *busy_ms);
+/* launch intervals [t0, t1) in ms on the time base of ref_engine's log (engines of a slab group); cap = 0 only counts */
+int tomo_profile_intervals(tomo_engine *e, int kernel, tomo_engine *ref_engine, double *t0, double *t1, int cap, int *count);
 
 #ifdef __cplusplus
 }

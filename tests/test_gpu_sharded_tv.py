@@ -165,3 +165,72 @@ def test_sharded_tv_equals_whole_slab_at_full_size(gpu, world, nx, n):
     del want["gd"]
     got_pair = run_sharded(world, nx, n, ang, x, script(False))
     assert rel_l2(got_pair["fgp"], want["fgp"]) < 2e-6 and rel_l2(got_pair["gd"], got["gd"]) == 0.0
+
+
+# ---- K sub-slab engines on one GPU behind ONE facade (tomoengine(..., sub_slabs=K): engine.py _GroupBackend) ---------------
+@pytest.mark.parametrize("K,nx", [(2, 11), (3, 70), (2, 130)])
+def test_sub_slab_group_equals_one_engine(gpu, K, nx):
+    """Every facade call on a sub-slab group gives what one engine gives: volumes to 2e-6, scalars to 2e-6."""
+    n, p = 32, 7
+    ang = np.deg2rad(np.linspace(-60, 60, p))
+    x = noisy_phantom(nx, n, 11)
+    res = []
+    for k in (1, K):
+        t = tomoengine(nx, n, ang, sub_slabs=k)
+        t.tv_eps = 1e-6
+        t.set_volume(x, 2)
+        t.create_projections()
+        out = {"b": t.get_projections()}
+        t.initialize_SART("sequential")
+        t.copy_recon()
+        out["dp"] = t.SART_tracked(0.5, 1)
+        out["sart"] = t.get_volume()
+        out["dd"] = t.data_distance()
+        out["tv"] = t.tv()
+        t.data_distance_begin()
+        out["tv0"], out["dg"], dd2 = t.tv_gd_tracked(3, 0.2, extra=(S_DD,))
+        out["dd_async"] = float(np.sqrt(dd2))
+        out["gd"] = t.get_volume()
+        out["tmp"] = t.get_volume(VOL_TEMP)
+        out["fgp_tv"] = t.tv_fgp(4, 0.05)
+        out["fgp"] = t.get_volume()
+        t.SIRT(2)
+        out["sirt"] = t.get_volume()
+        out["slice"] = t.get_recon(nx - 2)
+        img = np.full((n, n), 0.25, np.float32)
+        t.set_recon(img, 1)
+        out["set"] = t.get_recon(1)
+        out["rmse"] = t.rmse()
+        res.append(out)
+    a, b = res
+    # (the kernels pick their vector width from the slab's slice count, so even slice-independent operators agree to
+    # rounding, not bit for bit -- like two half-slab engines in test_gpu_fullsize.py)
+    assert rel_l2(b["b"], a["b"]) < 1e-6 and rel_l2(b["sart"], a["sart"]) < 2e-6
+    for k in ("dp", "dd", "tv", "tv0", "dg", "dd_async", "fgp_tv", "rmse"):
+        assert abs(a[k] - b[k]) <= 2e-6 * abs(a[k]), (k, a[k], b[k])
+    assert abs(a["dd"] - a["dd_async"]) <= 1e-6 * a["dd"]
+    for k in ("gd", "fgp", "sirt"):
+        assert rel_l2(b[k], a[k]) < 2e-6, k
+    assert np.array_equal(b["gd"], b["tmp"]) and np.array_equal(b["slice"], b["sirt"][nx - 2]) and np.array_equal(b["set"], a["set"])
+
+
+def test_sub_slab_group_asd_pocs_at_full_size(gpu):
+    """512 x 512^2, 90 tilts: three ASD-POCS iterations of TomoGPU on two sub-slabs against one slab."""
+    from tomo_tv_amd.phantom import tilt_angles
+    from tomo_tv_amd.reconstructor import TomoGPU
+    nx, n, p = 512, 512, 90
+    ang = tilt_angles(p)
+    one = tomoengine(nx, n, np.deg2rad(ang))
+    one.set_volume(ellipsoids(nx, n), 2)
+    one.create_projections()
+    ts = one.get_projections().reshape(nx, p, n).transpose(0, 2, 1)
+    del one
+    out = []
+    for k in (1, 2):
+        rec = TomoGPU(ang, ts, sub_slabs=k)
+        rec.tomo.tv_eps = 1e-6
+        dd, tv = rec.asd_pocs(Niter=3)
+        out.append((dd.copy(), tv.copy(), rec.tomo.get_volume()))
+        del rec
+    assert np.allclose(out[0][0], out[1][0], rtol=5e-6) and np.allclose(out[0][1], out[1][1], rtol=5e-6)
+    assert rel_l2(out[1][2], out[0][2]) < 2e-5

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libtomo_hip.so")
 VOL_RECON, VOL_TEMP, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD = 0, 1, 2, 3, 4
 SINO_B, SINO_G, SINO_R, SINO_USER0 = 0, 1, 2, 3
 VOL_USER0 = 5
-S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_DIFF2, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 16
+S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_DIFF2, S_GNORM_ALL, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 16
 FIELD_FGP_D, FIELD_FGP_P1 = 100, 101
 K_BP_ANGLE, K_FP_ANGLE, K_TV_GRAD, K_TV_UPDATE, K_FGP_OBJ, K_FGP_GRAD, K_SART_FUSED, K_FP_TILE, K_BP_TILE, K_FP_REDUCE = range(10)
 
@@ -68,6 +68,10 @@ SIGNATURES = {
     "tomo_halo_pack_both": [_p, _i, _p, _p],
     "tomo_halo_local": [_p, _i],
     "tomo_set_slab_edges": [_p, _i, _i],
+    "tomo_wait_for": [_p, _p],
+    "tomo_halo_from": [_p, _i, _p, _p],
+    "tomo_scalar_sum_from": [_p, _i, _p, _i, _i],
+    "tomo_profile_intervals": [_p, _i, _p, _p, _p, _i, ctypes.POINTER(_i)],
     "tomo_tv_partial": [_p, _i, _f],
     "tomo_tv_set_target": [_p, _i],
     "tomo_tv_grad": [_p, _f],

@@ -1342,6 +1342,15 @@ __global__ void k_halo_pack(const float *__restrict__ x, float *__restrict__ dst
     if (i < npix) dst[i] = x[(size_t)i * sx + s];
 }
 
+// dst = sum of n device doubles (the partial sums several slab engines on one device hold for the same quantity)
+struct SumSrc { const double *p[8]; int n; };
+__global__ void k_sum_doubles(SumSrc src, double *__restrict__ dst)
+{
+    double s = 0.0;
+    for (int i = 0; i < src.n; ++i) s += *src.p[i];
+    *dst = s;
+}
+
 // periodic wrap of a single slab in one launch: lo = last slice, hi = slice 0
 __global__ void k_halo_wrap(const float *__restrict__ x, float *__restrict__ lo, float *__restrict__ hi, int npix, int sx, int nx)
 {

@@ -61,6 +61,8 @@ struct tomo_engine {
     // tv_recompute: a tv_gd inner iteration as "norm pass (no store) + recompute-and-update pass into a second buffer" instead
     // of "gradient pass (store g) + update pass": one volume write instead of two (HBM writes are the scarce resource)
     int tv_recompute = 1;
+    int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
+    hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
     float tv_last_eps = 1e-6f;
     float *tv_alt = nullptr, *halo_lo_alt = nullptr, *halo_hi_alt = nullptr;
     // fp_all_lpr: all-angle FP: lanes per ray of the narrow-chunk form (0 = wide form)
@@ -692,6 +694,7 @@ int tomo_destroy(tomo_engine *e)
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (int u = 0; u < 2; ++u) if (e->sub_stream[u]) { (void)hipStreamSynchronize(e->sub_stream[u]); (void)hipStreamDestroy(e->sub_stream[u]); (void)hipEventDestroy(e->ev_sjoin[u]); }
     if (e->ev_sfork) (void)hipEventDestroy(e->ev_sfork);
+    if (e->ev_peer) (void)hipEventDestroy(e->ev_peer);
     free_geometry(e);
     void *ptrs[] = {e->tv_alt, e->halo_lo_alt, e->halo_hi_alt, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_coef, e->sart_alt,
                     e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
@@ -1498,6 +1501,53 @@ int tomo_halo_local(tomo_engine *e, int field)
     return TOMO_OK;
 }
 
+// ---- several slab engines on ONE device (tomo_tv_amd/engine.py: _GroupBackend) ------------------------------------------------
+// A slab can be run as K sub-slabs, each a complete engine with its own allocations and stream: the dependent launch chains of
+// the sub-slabs (a SART sweep is 180 of them) then fill each other's launch gaps and kernel tails.  Slices only couple in the 3-D
+// TV stencils and in the global sums; these three calls are what the coupling needs.
+
+// e's stream waits for everything enqueued on other's stream so far
+int tomo_wait_for(tomo_engine *e, tomo_engine *other)
+{
+    NEED(e);
+    if (!other) return fail(TOMO_ERR_ARG, "null engine");
+    if (other->device != e->device) return fail(TOMO_ERR_ARG, "engines on different devices");
+    if (other == e || other->stream == e->stream) return TOMO_OK;
+    if (!other->ev_peer) HIPCHK(hipEventCreateWithFlags(&other->ev_peer, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(other->ev_peer, other->stream));
+    HIPCHK(hipStreamWaitEvent(e->stream, other->ev_peer, 0));
+    return TOMO_OK;
+}
+
+// e's halo planes from its neighbours' volumes: lo = LAST slice of lo_src's field, hi = FIRST slice of hi_src's field (the
+// caller orders the streams: tomo_wait_for).  The ring of sub-slabs of one volume gives the periodic wrap of ctvlib.cpp:348,421.
+int tomo_halo_from(tomo_engine *e, int field, tomo_engine *lo_src, tomo_engine *hi_src)
+{
+    NEED(e);
+    if (!lo_src || !hi_src) return fail(TOMO_ERR_ARG, "null engine");
+    if (lo_src->n != e->n || hi_src->n != e->n || lo_src->device != e->device || hi_src->device != e->device) return fail(TOMO_ERR_ARG, "engines differ in image size or device");
+    float *xl, *xh; int rc;
+    if ((rc = field_ptr(lo_src, field, &xl)) || (rc = field_ptr(hi_src, field, &xh))) return rc;
+    dim3 grid((unsigned)((e->npix + 255) / 256));
+    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, e->stream, xl, e->halo_lo, (int)e->npix, lo_src->sx, lo_src->nx - 1);
+    hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, e->stream, xh, e->halo_hi, (int)e->npix, hi_src->sx, 0);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+// scalar dst_slot of e = sum over the engines' src_slot partial sums, on e's stream (caller orders the streams)
+int tomo_scalar_sum_from(tomo_engine *e, int dst_slot, tomo_engine **srcs, int n, int src_slot)
+{
+    NEED(e);
+    if (!srcs || n < 1 || n > 8 || dst_slot < 0 || dst_slot >= TOMO_S_COUNT || src_slot < 0 || src_slot >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad argument");
+    SumSrc s{};
+    s.n = n;
+    for (int i = 0; i < n; ++i) { if (!srcs[i] || srcs[i]->device != e->device) return fail(TOMO_ERR_ARG, "bad source engine"); s.p[i] = srcs[i]->d_scal + src_slot; }
+    hipLaunchKernelGGL(k_sum_doubles, dim3(1), dim3(1), 0, e->stream, s, e->d_scal + dst_slot);
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
 int tomo_set_slab_edges(tomo_engine *e, int is_first, int is_last)
 {
     if (!e) return fail(TOMO_ERR_ARG, "null engine");
@@ -1642,7 +1692,7 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
             wh = e->halo_hi == e->halo_hi_own ? e->halo_hi_alt : e->halo_hi_own;
         }
         Halo h{e->halo_lo, e->halo_hi};
-        TvUpd up{alt, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, track, wl, wh};
+        TvUpd up{alt, e->d_scal + e->gnorm_slot, dPOCS, clamp, track, wl, wh};
         {
             ProfScope ps(e, TOMO_K_TV_UPDATE);
             int yseg = 32;
@@ -1659,8 +1709,8 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
     {
         ProfScope ps(e, TOMO_K_TV_UPDATE);
         float *wl = wrap ? e->halo_lo : plane_last, *wh = wrap ? e->halo_hi : plane_first;
-        if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)track, e->d_part, wl, wh, e->nx, e->sx / 4);
-        else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + TOMO_S_GNORM, dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr, wl, wh, e->nx, e->sx / 4);
+        if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + e->gnorm_slot, dPOCS, clamp, n4, (f4 *)track, e->d_part, wl, wh, e->nx, e->sx / 4);
+        else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + e->gnorm_slot, dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr, wl, wh, e->nx, e->sx / 4);
     }
     LAUNCHCHK();
     return track ? reduce_end(e, slot) : TOMO_OK;
@@ -1883,6 +1933,10 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
         e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; return TOMO_OK;
     }
+    if (std::strcmp(name, "tv_gnorm_slot") == 0) {
+        if (value < 0 || value >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
+        e->gnorm_slot = value; return TOMO_OK;
+    }
     if (std::strcmp(name, "tv_recompute") == 0) { e->tv_recompute = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 1 register march, 8 / 16 LDS march (z-columns per workgroup), 0 direct
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
@@ -1944,6 +1998,28 @@ int tomo_profile_read2(tomo_engine *e, int kernel, int64_t *launches, double *to
         std::string msg = std::to_string(p.dropped) + " launches were not recorded (event log full)";
         p.dropped = 0;
         return fail(TOMO_ERR_STATE, msg);
+    }
+    return TOMO_OK;
+}
+
+// the launch intervals of a kernel [t0, t1) in ms since ref_engine's log of the same kernel was switched on (engines of a slab
+// group share one device: their events are on one time base); does not reset the log
+int tomo_profile_intervals(tomo_engine *e, int kernel, tomo_engine *ref_engine, double *t0, double *t1, int cap, int *count)
+{
+    NEED(e);
+    if (kernel < 0 || kernel >= PROF_MAX_KERNELS || !ref_engine || !count) return fail(TOMO_ERR_ARG, "bad argument");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    ProfSlot &p = e->prof[kernel];
+    hipEvent_t ref = ref_engine->prof[kernel].ref;
+    if (!ref) return fail(TOMO_ERR_STATE, "the reference engine's log is not enabled");
+    int n = (int)(p.used / 2);
+    *count = n;
+    if (!t0 || !t1 || cap < n) return cap == 0 ? TOMO_OK : fail(TOMO_ERR_ARG, "interval buffers too small");
+    for (int i = 0; i < n; ++i) {
+        float a = 0, d = 0;
+        HIPCHK(hipEventElapsedTime(&a, ref, p.ev[2 * i]));
+        HIPCHK(hipEventElapsedTime(&d, p.ev[2 * i], p.ev[2 * i + 1]));
+        t0[i] = a; t1[i] = a + d;
     }
     return TOMO_OK;
 }

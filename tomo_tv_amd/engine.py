@@ -15,7 +15,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COST, S_COUNT, S_DD, S_DIFF, S_DIFF2, S_GNORM, S_L1, S_RMSE, S_TV, SINO_B,
+from ._lib import (FIELD_FGP_D, FIELD_FGP_P1, S_COST, S_COUNT, S_DD, S_DIFF, S_DIFF2, S_GNORM, S_GNORM_ALL, S_L1, S_RMSE, S_TV, SINO_B,
                    SINO_G, VOL_ORIGINAL, VOL_RECON, VOL_RECON_OLD, VOL_TEMP, VOL_YK, check)
 from .distributed import SlabComm, slab_partition
 
@@ -143,15 +143,231 @@ class _SlabBackend:
                                     float(lamC_over_L), float(lamH), he.h, int(upd_vol), int(model_vol)))
 
 
+class _GroupBackend:
+    """K sub-slab engines on ONE device behind the backend interface (``tomoengine(..., sub_slabs=K)``).
+
+    A SART sweep is a chain of 180 dependent launches; two such chains on two streams can fill each other's launch gaps
+    and kernel ramps.  Measured at 512^3 x 90 (tools/exp_two_engines_step.py, ASD-POCS step, no event logging): one engine
+    27.7-28.2 ms; two UNCOUPLED 256-slice engines on two threads 25.6-26.9 ms; this group of two coupled sub-slabs
+    27.3-27.6 ms; four 30.5 ms.  The gain is small and varies from box to box, so nothing selects it by default.  The
+    sub-slabs must be SEPARATE allocations (sub-slabs interleaved inside one slab's rows collide in the memory system:
+    "sart_streams"), so each is a complete engine: own volumes, own tables, own stream.  Slices only couple in the 3-D TV stencils and in the global sums: halo planes are taken straight from
+    the neighbour's volume on the device (``tomo_halo_from``), streams are ordered with events (``tomo_wait_for``), partial
+    sums are added on the device where a kernel needs the total (``tomo_scalar_sum_from``: ||grad TV||^2) and on the host
+    where Python reads them.  This is the single-device form of the slab sharding of ``distributed.py`` (the reference's
+    MPI ring, mpi_ctvlib.cpp:400-422,547); everything is enqueued by ONE Python thread except the sweeps themselves.
+    """
+
+    def __init__(self, nslice, nray, nproj, angles_rad=None, A=None, device=0, sub_slabs=2):
+        K = int(sub_slabs)
+        if not 2 <= K <= 8 or K > nslice:
+            raise ValueError("sub_slabs must be 2..8 and at most the number of slices")
+        self.nslice, self.nray, self.nproj, self.device = nslice, nray, nproj, device
+        self.parts = [slab_partition(nslice, K, k) for k in range(K)]
+        self.kids = [_SlabBackend(c, nray, nproj, angles_rad=angles_rad, A=A, device=device) for _, c in self.parts]
+        self.L, self.h = self.kids[0].L, None
+        self._tv_target = VOL_RECON
+        for k, kid in enumerate(self.kids):
+            kid.c("set_option", b"tv_gnorm_slot", S_GNORM_ALL)
+            kid.c("set_slab_edges", int(k == 0), int(k == K - 1))     # FGP's non-periodic boundary (tv_fgp.cu:57,81)
+        self._hs = (ctypes.c_void_p * K)(*[kid.h for kid in self.kids])
+
+    # ---- plumbing ---------------------------------------------------------------------------------------------
+    def close(self):
+        for kid in getattr(self, "kids", []):
+            kid.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scalars(self):
+        return np.sum([kid.scalars() for kid in self.kids], axis=0)
+
+    def lipschitz(self):
+        return self.kids[0].lipschitz()
+
+    def enable_torch(self):
+        raise _lib.TomoError("sub_slabs and a process group are alternatives: shard over ranks OR over sub-slabs of one GPU")
+
+    def share_stream_with(self, other):
+        raise _lib.TomoError("a sub-slab group has one stream per sub-slab: not usable as one side of a multimodal pair")
+
+    def _all(self, name, *args):
+        for kid in self.kids:
+            kid.c(name, *args)
+
+    def _threads(self, name, *args):
+        """The same long call on every sub-slab at once: sub-slabs 1.. on helper threads (ctypes drops the GIL)."""
+        import threading
+        errs = []
+
+        def run(kid):
+            try:
+                kid.c(name, *args)
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+                errs.append(e)
+        ths = [threading.Thread(target=run, args=(kid,)) for kid in self.kids[1:]]
+        for t in ths:
+            t.start()
+        run(self.kids[0])
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    @staticmethod
+    def _shift(ptr, nbytes):
+        return ctypes.c_void_p((ptr.value if isinstance(ptr, ctypes.c_void_p) else int(ptr)) + nbytes)
+
+    def _rows(self, name, which, ptr, rowbytes):
+        for (first, _), kid in zip(self.parts, self.kids):
+            kid.c(name, which, self._shift(ptr, first * rowbytes))
+
+    def _owner(self, s):
+        for k, (first, cnt) in enumerate(self.parts):
+            if first <= s < first + cnt:
+                return self.kids[k], s - first
+        raise IndexError(f"slice {s} out of range")
+
+    def _fill_halos(self, field):
+        """Every sub-slab's halo planes from its ring neighbours' volumes (stream-ordered behind their last write)."""
+        K = len(self.kids)
+        for k, kid in enumerate(self.kids):
+            lo, hi = self.kids[(k - 1) % K], self.kids[(k + 1) % K]
+            for o in {id(lo): lo, id(hi): hi}.values():
+                check(self.L.tomo_wait_for(kid.h, o.h))
+            check(self.L.tomo_halo_from(kid.h, int(field), lo.h, hi.h))
+
+    def _sum_gnorm(self):
+        """||grad TV||^2 over the sub-slabs, left in S_GNORM_ALL of every sub-slab (the update kernels read it there)."""
+        for kid in self.kids:
+            for o in self.kids:
+                if o is not kid:
+                    check(self.L.tomo_wait_for(kid.h, o.h))
+            check(self.L.tomo_scalar_sum_from(kid.h, S_GNORM_ALL, self._hs, len(self.kids), S_GNORM))
+
+    # ---- the calls of the backend interface ------------------------------------------------------------------------
+    _UNSUPPORTED = {"tv_partial", "tv_grad", "tv_grad_tv", "tv_update", "tv_update_planes", "tv_update_tracked", "halo_pack",
+                    "halo_pack_both", "halo_local", "bind_halo", "bind_scalar_buffer", "bind_fgp_halo", "fgp_begin", "fgp_begin_vol",
+                    "fgp_obj", "fgp_grad", "fgp_end", "fgp_fused_begin", "fgp_fused_step", "fgp_fused_end", "set_stream",
+                    "sino_proj_max", "sino_proj_scale", "art_order", "release_geometry"}
+
+    def c(self, name, *args):
+        f = getattr(self, "c_" + name, None)
+        if f is not None:
+            return f(*args)
+        if name in self._UNSUPPORTED:
+            raise _lib.TomoError(f"tomo_{name} is a per-slab step form: not offered on a sub-slab group")
+        self._all(name, *args)           # slice-independent: the same call on every sub-slab
+
+    def c_set_tilt_series(self, ptr):
+        self._rows("set_sinogram", SINO_B, ptr, self.nray * self.nproj * 4)
+
+    def c_set_sinogram(self, which, ptr):
+        self._rows("set_sinogram", which, ptr, self.nray * self.nproj * 4)
+
+    def c_get_sinogram(self, which, ptr):
+        self._rows("get_sinogram", which, ptr, self.nray * self.nproj * 4)
+
+    def c_set_volume(self, which, ptr):
+        self._rows("set_volume", which, ptr, self.nray * self.nray * 4)
+
+    def c_get_volume(self, which, ptr):
+        self._rows("get_volume", which, ptr, self.nray * self.nray * 4)
+
+    def c_set_slice(self, vol, s, ptr):
+        kid, ls = self._owner(s)
+        kid.c("set_slice", vol, ls, ptr)
+
+    def c_get_slice(self, vol, s, ptr):
+        kid, ls = self._owner(s)
+        kid.c("get_slice", vol, ls, ptr)
+
+    def c_set_option(self, name, value):
+        if name == b"tv_gnorm_slot":
+            raise _lib.TomoError("tv_gnorm_slot is managed by the group")
+        self._all("set_option", name, value)
+
+    # the long dependent chains: all sub-slabs at once
+    def c_sart(self, *a):
+        self._threads("sart", *a)
+
+    def c_sart_data(self, *a):
+        self._threads("sart_data", *a)
+
+    def c_sart_tracked(self, *a):
+        self._threads("sart_tracked", *a)
+
+    def c_art(self, *a):
+        self._threads("art", *a)
+
+    def c_read_scalars(self, ptr, count):
+        v = self.scalars()
+        (ctypes.c_double * count).from_address(ptr.value)[:] = list(v[:count])
+
+    # 3-D TV: slices couple across the sub-slabs
+    def c_tv_set_target(self, vol):
+        self._tv_target = int(vol)
+        self._all("tv_set_target", vol)
+
+    def c_tv(self, vol, eps):
+        self._fill_halos(vol)
+        self._all("tv_partial", vol, eps)
+
+    def _tv_gd(self, ng, dPOCS, eps, track, slot):
+        tgt = self._tv_target
+        if ng <= 0:
+            self.c_tv(tgt, eps)
+            self._all("positivity", tgt)
+            if track >= 0:
+                self._all("diff_norm_sq", tgt, track, slot)
+                self._all("copy_volume", track, tgt)
+            return
+        for g in range(ng):
+            self._fill_halos(tgt)
+            self._all("tv_grad_tv" if g == 0 else "tv_grad", eps)     # sub-slab sums of g^2 (first pass: of TV too)
+            self._sum_gnorm()
+            if g == ng - 1 and track >= 0:
+                self._all("tv_update_tracked", dPOCS, 1, track, slot)
+            else:
+                self._all("tv_update", dPOCS, int(g == ng - 1))
+
+    def c_tv_gd(self, ng, dPOCS, eps):
+        self._tv_gd(int(ng), dPOCS, eps, -1, 0)
+
+    def c_tv_gd_tracked(self, ng, dPOCS, eps, track, slot):
+        self._tv_gd(int(ng), dPOCS, eps, int(track), int(slot))
+
+    def c_tv_fgp(self, iters, lam):
+        self.c_tv_fgp_vol(VOL_RECON, iters, lam)
+
+    def c_tv_fgp_vol(self, vol, iters, lam):
+        """FGP-TV over the sub-slabs with the Obj / Grad pair (tv_fgp.cu:244-268) and a halo fill before each."""
+        self.c_tv(vol, 1e-6)                                           # TV of the input (tv_fgp.cu:231-238)
+        self._all("fgp_begin_vol", vol)
+        for _ in range(int(iters)):
+            self._fill_halos(FIELD_FGP_P1)
+            self._all("fgp_obj", lam)
+            self._fill_halos(FIELD_FGP_D)
+            self._all("fgp_grad", lam)
+        self._all("fgp_end", int(iters))
+
+
 class _EngineBase:
     """Shared implementation; ``comm`` is None for one slab = whole volume."""
 
     _backend_cls = _SlabBackend
 
-    def _setup(self, Nslice, Nray, Nproj, angles_rad=None, A=None, device=None, comm=None):
+    def _setup(self, Nslice, Nray, Nproj, angles_rad=None, A=None, device=None, comm=None, sub_slabs=1):
         self.Nslice_, self.Ny, self.Nz, self.Nproj = int(Nslice), int(Nray), int(Nray), int(Nproj)
         self.Nrow, self.Ncol = self.Ny * self.Nproj, self.Ny * self.Nz
         self.comm = comm
+        self.sub_slabs = int(sub_slabs)
+        if self.sub_slabs > 1 and comm is not None:
+            raise ValueError("sub_slabs (several slab engines on one GPU) and comm (one slab per rank) are alternatives")
         if comm is not None:
             self.first, self.nloc = slab_partition(self.Nslice_, comm.world, comm.rank)
             if self.nloc == 0:
@@ -182,6 +398,10 @@ class _EngineBase:
             return 0
 
     def _make_backend(self, angles_rad=None, A=None):
+        if self.sub_slabs > 1:
+            self.be = _GroupBackend(self.nloc, self.Ny, self.Nproj, angles_rad=angles_rad, A=A, device=self.gpuID,
+                                    sub_slabs=self.sub_slabs)
+            return
         self.be = self._backend_cls(self.nloc, self.Ny, self.Nproj, angles_rad=angles_rad, A=A, device=self.gpuID)
         if self.comm is not None:
             self.be.enable_torch()
@@ -495,6 +715,8 @@ class _EngineBase:
         """New tilt geometry with the reconstruction kept (tomoengine.cpp:128-149, ctvlib.cpp:317-333): the old tables
         are released BEFORE the new ones are built (one set in memory), the new engine adopts the volumes (no copy),
         the stored options and the shared stream are re-applied, the Lipschitz constants refreshed."""
+        if self.sub_slabs > 1:
+            raise _lib.TomoError("changing the tilt geometry of a sub-slab group is not supported: build a new engine")
         old = self.be
         old.c("release_geometry")          # tables and sinograms go, the volumes stay on the device
         self.Nproj = int(Nproj)
@@ -515,9 +737,11 @@ class _EngineBase:
 class tomoengine(_EngineBase):
     """``tomoengine(Nslice, Nray, angles_rad)`` -- tomofusion/gpu/utils/tomoengine.cpp:48-84."""
 
-    def __init__(self, Nslice, Nray, pyAngles=None, device=None, comm=None):
+    def __init__(self, Nslice, Nray, pyAngles=None, device=None, comm=None, sub_slabs=1):
+        """``sub_slabs=K`` (an extension, default 1): run the slab as K sub-slab engines on this GPU, each on its own
+        stream, so that their dependent launch chains overlap (``_GroupBackend``: -1...-3 % per ASD-POCS step at K = 2)."""
         ang = np.zeros(1) if pyAngles is None else np.ascontiguousarray(pyAngles, dtype=np.float64).ravel()
-        self._setup(Nslice, Nray, ang.size, angles_rad=ang, device=device, comm=comm)
+        self._setup(Nslice, Nray, ang.size, angles_rad=ang, device=device, comm=comm, sub_slabs=sub_slabs)
 
     # GPU selection (tomoengine.cpp:87-95): the device is fixed at construction in this build
     def set_gpu(self, gpu_id):

@@ -32,8 +32,9 @@ def determine_gpu_config(gpu_id=-1):
 
 class TomoGPU:
 
-    def __init__(self, tiltAngles, tiltSeries=None, gpu_id=-1, verbose=False):
-        """tiltAngles in degrees, tiltSeries (Nslice, Nray, Nangles) with axis 0 = tilt axis."""
+    def __init__(self, tiltAngles, tiltSeries=None, gpu_id=-1, verbose=False, sub_slabs=1):
+        """tiltAngles in degrees, tiltSeries (Nslice, Nray, Nangles) with axis 0 = tilt axis.  ``sub_slabs=K`` (an extension,
+        single GPU): run the volume as K sub-slab engines side by side on the GPU (engine.py: ``_GroupBackend``)."""
         pytvlib.check_hip()
         tiltAngles = np.asarray(tiltAngles, dtype=np.float64)
         self.Nslice, self.Nray, self.Nangles = tiltSeries.shape
@@ -41,7 +42,7 @@ class TomoGPU:
             raise ValueError("tiltAngles and tiltSeries disagree on the number of projections")
         config = determine_gpu_config(gpu_id)
         if config == "singleconfig":
-            self.tomo = tomoengine(self.Nslice, self.Nray, np.deg2rad(tiltAngles), device=max(gpu_id, 0))
+            self.tomo = tomoengine(self.Nslice, self.Nray, np.deg2rad(tiltAngles), device=max(gpu_id, 0), sub_slabs=sub_slabs)
         else:
             self.tomo = multigpuengine(self.Nslice, self.Nray, np.deg2rad(tiltAngles))
         self.verbose = verbose

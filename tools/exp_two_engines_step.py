@@ -12,8 +12,8 @@ from tomo_tv_amd._lib import VOL_ORIGINAL
 n, P = 512, 90
 ang = np.deg2rad(tilt_angles(P))
 
-def make(nx):
-    t = tomoengine(nx, n, ang)
+def make(nx, sub=1):
+    t = tomoengine(nx, n, ang, sub_slabs=sub)
     t.set_volume(ellipsoids(nx, n), VOL_ORIGINAL)
     t.create_projections()
     t.initialize_SART("sequential")
@@ -36,6 +36,10 @@ def run(engs, reps=5):
 one = make(512)
 print("one engine, 512 slices: %.2f ms per ASD-POCS step" % run([one]))
 del one
+for sub in (2, 2, 4):
+    grp = make(512, sub)
+    print("one engine, 512 slices as %d coupled sub-slabs (sub_slabs=%d): %.2f ms per step" % (sub, sub, run([grp])))
+    del grp
 for k in (2,):
     engs = [make(512 // k) for _ in range(k)]
     print("%d engines x %d slices on %d threads: %.2f ms per step (all 512 slices)" % (k, 512 // k, k, run(engs)))
