@@ -234,3 +234,41 @@ def test_sub_slab_group_asd_pocs_at_full_size(gpu):
         del rec
     assert np.allclose(out[0][0], out[1][0], rtol=5e-6) and np.allclose(out[0][1], out[1][1], rtol=5e-6)
     assert rel_l2(out[1][2], out[0][2]) < 2e-5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_chemicaltomo_on_real_kernels(gpu, world):
+    """Config 5's engine (multimodal: HAADF + 2 elements) slab-sharded over 2 / 3 ranks on one GPU (thread ring) against the
+    single-slab engine: Poisson-ML costs, per-projection max rescale (all-reduce max), fused data-fusion step, 4-D FGP with
+    its halo exchanges (multimodal.cpp:277-304,312-328,425-491; multigpufusion.cpp is the reference's sharded class)."""
+    from tomo_tv_amd.chemistry import create_weighted_summation_weights, multimodal
+    n, nx, nel = 32, 11, 2
+    ha, ca = np.deg2rad(np.linspace(-70, 70, 9)), np.deg2rad(np.linspace(-64, 68, 7))
+    w = create_weighted_summation_weights([31, 8], 1.6, 3)
+    gt = np.stack([ellipsoids(nx, n, seed=40 + e, k=8) * np.float32(0.6 + 0.3 * e) for e in range(nel)])
+    # measurements from a single-slab engine's own operators
+    mk = multimodal(nx, n, nel, ha, ca)
+    mk.set_gamma(1.6); mk.set_weights(w); mk.set_volume(gt); mk._mm_model()
+    mk.he.be.c("forward_projection", mk.MODEL, 0)
+    bh = mk.he.get_projections(); bh = bh / bh.max()
+    for e in range(nel):
+        mk.ce.be.c("forward_projection", int(mk._x[e]), int(mk._b[e]))
+    bc = mk.get_chem_projections(); bc = bc / bc.max()
+    del mk
+
+    def script(comm):
+        mm = multimodal(nx, n, nel, ha, ca, device=0, comm=comm)
+        mm.set_gamma(1.6); mm.set_weights(w)
+        mm.set_haadf_tilt_series(bh); mm.set_chem_tilt_series(bc)
+        mm.set_measureChem(True); mm.set_measureHaadf(True); mm.estimate_lipschitz()
+        out = [mm.poisson_ml(0.05) for _ in range(3)]
+        mm.rescale_tomograms(10); mm.rescale_projections()
+        for _ in range(2):
+            out += list(mm.sirt_data_fusion(10, 0.05, 3))
+            out.append(mm.tv_fgp_4D(3, 1e-4))
+        out.append(mm.data_distance())
+        return np.array(out), mm.get_volume(), mm.get_haadf_projections()
+    want = script(None)
+    got = ThreadRing(world).run(script)[0]
+    assert np.allclose(got[0], want[0], rtol=2e-5), (got[0], want[0])
+    assert rel_l2(got[1], want[1]) < 2e-5 and rel_l2(got[2], want[2]) < 1e-6
