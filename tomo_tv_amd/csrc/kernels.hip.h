@@ -1590,7 +1590,10 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
 //  * a workgroup-cooperative form (the 4 waves of a workgroup = 4 adjacent chunks hand lane 63's R to the neighbour through
 //    LDS instead of re-evaluating the phantom slice: -78 instructions per row; buffer loads with scalar row offsets: -28):
 //    616 vs 602 us.
-// So neither the instruction count nor the L2-side traffic is the limiter; what is, is not established.
+// With the gradient no longer stored (MODE below) the norm pass takes 231 us for 0.69 GB of reads and the update pass 332 us: a
+// what-if build without the phantom-slice evaluation (-104 of ~440 instructions per row) runs an inner iteration in 470 instead
+// of 530 us, and 4 z-columns per wave (68 VGPRs, 7 waves per SIMD instead of 4) in the same 530: the passes are about half
+// instruction-bound, not occupancy-bound.  Handing R across chunk edges costs what it saves in every form tried.
 // workgroups (4 waves) of the march kernels' item space, for the XCD-aware map above
 inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
 {

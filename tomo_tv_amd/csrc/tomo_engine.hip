@@ -60,7 +60,7 @@ struct tomo_engine {
     int tv_lds = 1, fp_all_lpr = 16;
     // tv_recompute: a tv_gd inner iteration as "norm pass (no store) + recompute-and-update pass into a second buffer" instead
     // of "gradient pass (store g) + update pass": one volume write instead of two (HBM writes are the scarce resource)
-    int tv_recompute = 1;
+    int tv_recompute = 1, tv_tz = 8;              // tv_tz: z-columns per wave of the register march (8 or 4)
     int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
     hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
     float tv_last_eps = 1e-6f;
@@ -1607,9 +1607,15 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
         e->tv_last_eps = eps;
         if (e->tv_lds == 1 && e->tv_recompute) {   // sum g^2 (and TV) only: the update pass re-evaluates g (TVM_UPDATE)
             int yseg = 32;
+            if (e->tv_tz == 4) {
+                dim3 grid(tv_march_grid(e->n, 4, e->sxc / 64, (e->n + yseg - 1) / yseg));
+                if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<4, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
+                else hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
+            } else {
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
             if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
             else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
+            }
         } else if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
             int yseg = 32;   // 8 .. 64 rows per wave measured the same; longer segments leave too few waves
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
@@ -1696,8 +1702,13 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
         {
             ProfScope ps(e, TOMO_K_TV_UPDATE);
             int yseg = 32;
+            if (e->tv_tz == 4) {
+                dim3 grid(tv_march_grid(e->n, 4, e->sxc / 64, (e->n + yseg - 1) / yseg));
+                hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
+            } else {
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
             hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
+            }
         }
         LAUNCHCHK();
         e->vol[e->tv_target] = alt; e->tv_alt = x;              // the updated volume lives in the partner buffer
@@ -1937,6 +1948,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         if (value < 0 || value >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
         e->gnorm_slot = value; return TOMO_OK;
     }
+    if (std::strcmp(name, "tv_tz") == 0) { e->tv_tz = value == 4 ? 4 : 8; return TOMO_OK; }
     if (std::strcmp(name, "tv_recompute") == 0) { e->tv_recompute = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 1 register march, 8 / 16 LDS march (z-columns per workgroup), 0 direct
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
