@@ -422,7 +422,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=512, help="Nray = Ny = Nz")
+    ap.add_argument("--n", "--nray", dest="n", type=int, default=512, help="Nray = Ny = Nz (--nray: torch.distributed.run reads a bare --n as one of its own options)")
     ap.add_argument("--nslice", type=int, default=512, help="slices of the volume (strong) / per GPU (weak)")
     ap.add_argument("--nproj", type=int, default=90)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",

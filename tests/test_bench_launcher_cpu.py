@@ -38,3 +38,24 @@ def test_strong_scaling_result_does_not_depend_on_rank_count():
     b = run_bench("--gpus", "3", "--nslice", "6")
     assert b["n_gpus"] == 3
     assert abs(a["final_dd"] - b["final_dd"]) <= 1e-5 * a["final_dd"] and abs(a["final_tv"] - b["final_tv"]) <= 1e-4 * a["final_tv"]
+
+
+def test_torchrun_launch_uses_the_ranks_it_is_given():
+    """The driver's N > 1 form: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`` -- bench.py must take RANK / WORLD_SIZE from the environment (no second spawn)
+    and rank 0 alone prints the JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--nray", "16",
+                        "--nproj", "5", "--nslice", "6", "--steps", "2", "--warmup", "1", "--quick"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["slices_per_gpu"] == 3 and out["value"] > 0
