@@ -523,7 +523,8 @@ def main():
     tile = not any(o.replace(" ", "") == "sart_tile=0" for o in args.opt)
     K_FUSED_NAME, K_FP_NAME = ("k_sart_tile<true>", "k_sart_tile<false>") if tile else ("k_sart_seg<4,8,true>", "k_sart_seg<4,8,false>")
     K_BP_NAME = "k_bp_angle<4,4,true>"   # the sweep's last back-projection, tracked form (also step norm + snapshot copy)
-    log = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1}) if on_gpu else None
+    K_TVN_NAME, K_TVU_NAME = "k_tv_grad_reg<8,*,true,TVM_NORM>", "k_tv_grad_reg<8,false,true,TVM_UPDATE>"
+    log = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}) if on_gpu else None
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -559,13 +560,16 @@ def main():
         #                       out = 8V + 12 Nx N   (the tile form's partial sums are traffic, not algorithmic bytes)
         #   per-angle FP        slab in + b rows in + residual rows out = 4V + 8 Nx N
         V = float(nloc) * n * n
+        #   TV norm pass        reads the slab, writes nothing = 4V
+        #   TV update pass      re-evaluates g, writes x_new = 8V; the last of the 10 also reads and rewrites the snapshot (16V)
         alg_bytes = {K_BP_NAME: 16.0 * V + 4.0 * nloc * n, K_FUSED_NAME: 8.0 * V + 12.0 * nloc * n,
-                     K_FP_NAME: 4.0 * V + 8.0 * nloc * n}
+                     K_FP_NAME: 4.0 * V + 8.0 * nloc * n, K_TVN_NAME: 4.0 * V, K_TVU_NAME: (9 * 8.0 + 16.0) / 10 * V}
         roofs = {}
         nsub = sart_sub_slabs(nloc, args.opt) * max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)   # launches per angle
         for name, (cnt, tot, busy) in prof.items():
-            roofs[name] = roof(name, cnt, tot, alg_bytes[name] / nsub, busy_ms=busy)
-            roofs[name]["sub_slabs"] = nsub
+            per = nsub if name in (K_BP_NAME, K_FUSED_NAME, K_FP_NAME) else max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)
+            roofs[name] = roof(name, cnt, tot, alg_bytes[name] / per, busy_ms=busy)
+            roofs[name]["sub_slabs"] = per
             # what an in-place read-modify-write pass over the slab reaches on this part in any access pattern
             # (tools/micro/copy_patterns.hip: 5.2-5.5 TB/s) -- informative, not the peak
             roofs[name]["frac_of_measured_rmw_ceiling"] = roofs[name]["achieved"] / RMW_CEILING_GBS
@@ -604,6 +608,10 @@ def main():
             "roofline": dominant,
             "roofline_bp_angle": roofs.get(K_BP_NAME),
             "roofline_fp_angle": roofs.get(K_FP_NAME),
+            # the TV descent: a norm pass + a recompute-and-update pass per inner iteration (gradient never stored); these two
+            # are about half instruction-bound, their launches overlap the data distance on the second stream
+            "roofline_tv_norm": roofs.get(K_TVN_NAME),
+            "roofline_tv_update": roofs.get(K_TVU_NAME),
         }
         if world == 1 and comm is None and not args.quick:
             del t, log
