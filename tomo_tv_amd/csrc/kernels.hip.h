@@ -53,9 +53,10 @@ __device__ __forceinline__ void block_accumulate(double v, double *__restrict__ 
     if (threadIdx.x == 0) atomicAdd(&part[blockIdx.x & (NPART - 1)], red[0] + red[1] + red[2] + red[3]);
 }
 
-__global__ void k_finalize(const double *__restrict__ part, double *__restrict__ dst)
+__global__ void k_finalize(double *__restrict__ part, double *__restrict__ dst)
 {
     double v = part[threadIdx.x];  // launched with NPART threads
+    part[threadIdx.x] = 0.0;       // leave the buffer ready for the next reduction (no memset launch per reduction)
     __shared__ double red[NPART / 64];
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;

@@ -120,6 +120,7 @@ struct tomo_engine {
     size_t stage_bytes = 0;
     // scalars
     double *d_scal = nullptr, *d_scal_own = nullptr, *d_part = nullptr, *d_part_aux = nullptr, *d_part_tv = nullptr;
+    bool part_open[3] = {false, false, false};   // main / aux / tv partial sums: a reduction is in flight (see part_begin)
     hipStream_t aux = nullptr;                    // second stream for work that is independent of the main sequence
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool async_pending = false;
@@ -229,13 +230,29 @@ struct ProfScope {
 };
 
 // ---- reductions ------------------------------------------------------------------------------------------
-static int reduce_begin(tomo_engine *e) { HIPCHK(hipMemsetAsync(e->d_part, 0, NPART * sizeof(double), e->stream)); return TOMO_OK; }
-static int reduce_end(tomo_engine *e, int slot)
+// The partial-sum buffers are zero between reductions: they are allocated zeroed and k_finalize clears what it has read,
+// so a reduction costs no memset launch.  Only a reduction that was abandoned half-way (an error return between begin
+// and end) leaves its buffer marked open, and the next begin clears it.
+static bool &part_open(tomo_engine *e, const double *part)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part, e->d_scal + slot);
-    LAUNCHCHK();
+    return part == e->d_part_tv ? e->part_open[2] : part == e->d_part_aux ? e->part_open[1] : e->part_open[0];
+}
+static int part_begin(tomo_engine *e, double *part)
+{
+    bool &open = part_open(e, part);
+    if (open) HIPCHK(hipMemsetAsync(part, 0, NPART * sizeof(double), e->stream));
+    open = true;
     return TOMO_OK;
 }
+static int part_end(tomo_engine *e, double *part, int slot)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, part, e->d_scal + slot);
+    LAUNCHCHK();
+    part_open(e, part) = false;
+    return TOMO_OK;
+}
+static int reduce_begin(tomo_engine *e) { return part_begin(e, e->d_part); }
+static int reduce_end(tomo_engine *e, int slot) { return part_end(e, e->d_part, slot); }
 
 static int grid_1d(int64_t n4) { int64_t b = (n4 + 255) / 256; return (int)std::min<int64_t>(std::max<int64_t>(b, 1), 4096); }
 
@@ -1575,7 +1592,7 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
     }
     // the march of the gradient kernels without their gradient half: x is read once
     if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
-    HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
+    if ((rc = part_begin(e, e->d_part_tv))) return rc;
     const int yseg = 32;
     if (e->tv_lds == 1) {
         hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
@@ -1584,9 +1601,7 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
         hipLaunchKernelGGL((k_tv_grad_lds<8, true, false>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv);
     }
     LAUNCHCHK();
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part_tv, e->d_scal + TOMO_S_TV);
-    LAUNCHCHK();
-    return TOMO_OK;
+    return part_end(e, e->d_part_tv, TOMO_S_TV);
 }
 
 static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
@@ -1600,7 +1615,7 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
     if (with_tv && e->tv_lds != 8 && e->tv_lds != 1) with_tv = false;
     if (with_tv) {
         if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
-        HIPCHK(hipMemsetAsync(e->d_part_tv, 0, NPART * sizeof(double), e->stream));
+        if ((rc = part_begin(e, e->d_part_tv))) return rc;
     }
     {
         ProfScope ps(e, TOMO_K_TV_GRAD);
@@ -1636,10 +1651,7 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
         }
     }
     LAUNCHCHK();
-    if (with_tv) {
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(NPART), 0, e->stream, e->d_part_tv, e->d_scal + TOMO_S_TV);
-        LAUNCHCHK();
-    }
+    if (with_tv && (rc = part_end(e, e->d_part_tv, TOMO_S_TV))) return rc;
     return reduce_end(e, TOMO_S_GNORM);
 }
 
