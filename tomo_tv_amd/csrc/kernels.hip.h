@@ -609,6 +609,7 @@ __global__ __launch_bounds__(64) void k_sart_seg(const float *__restrict__ x_old
 // r[row][s] = (b - sum of the row's partials) / rowsum   (0 where rowsum == 0).  A row's partials have consecutive ids.
 // One workgroup per (row, chunk): its four waves each add a quarter of the list (the tile form leaves ~N/11 partials
 // per ray), the quarters are combined in fixed order through LDS.
+constexpr int RF_U = 12;
 template <int VEC>
 __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ partial,
                                                        const uint32_t *__restrict__ row_first,
@@ -625,24 +626,26 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
     int row = row0 + (blockIdx.x - chunk * nrows);
     int off = (chunk0 + chunk) * (64 * VEC) + lane * VEC;
     uint32_t first = row_first[row], ns = row_nseg[row];
+    // the measurement row and the row sum do not depend on the partials: in flight from the start (wave 0 uses them)
+    size_t o = (size_t)row * sx + off;
+    V bv = vzero<VEC>();
+    float rs = 0.f;
+    if (wave == 0) { bv = *reinterpret_cast<const V *>(b + o); rs = rowsum[row]; }
     uint32_t q = (ns + 3u) >> 2;
     uint32_t sb = min(wave * q, ns), se = min(sb + q, ns);
     V acc = vzero<VEC>();
     const float *pp = partial + (size_t)first * sx + off;
-    for (uint32_t s = sb; s < se; s += 8) {           // 8 independent loads per trip, summed in segment order
-        V t[8];
+    for (uint32_t s = sb; s < se; s += RF_U) {        // RF_U independent loads per trip (one trip at the tile form's ~N/11
+        V t[RF_U];                                    // partials per ray), summed in segment order
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (s + u < se) ? *reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx) : vzero<VEC>();
+        for (int u = 0; u < RF_U; ++u) t[u] = (s + u < se) ? *reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx) : vzero<VEC>();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += t[u];
+        for (int u = 0; u < RF_U; ++u) acc += t[u];
     }
     if (wave > 0) red[wave - 1][lane] = acc;
     __syncthreads();
     if (wave != 0) return;
     acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
-    size_t o = (size_t)row * sx + off;
-    V bv = *reinterpret_cast<const V *>(b + o);
-    float rs = rowsum[row];
     V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
     *reinterpret_cast<V *>(r_out + o) = r;
 }
@@ -734,18 +737,98 @@ __device__ int g_sart_whatif = 0;   // 1 no x stores, 2 no BP arithmetic, 4 no F
 #define ST_WI(bit) 0
 #endif
 
-template <bool FUSED>
+// ---- cooperative residual rows (COOP) -----------------------------------------------------------------------------
+// The chain "tile step; k_resid_finish; tile step; ..." pays one short kernel and two launch boundaries per angle for the
+// residual rows (12 + 4 us of 230 at 512^3, 4 + 4 of 37 on a 64-slice slab of a multi-GPU run).  In the COOP form the tile
+// step of link k first turns the partial sums that link k-1 left (they are complete: kernel boundary) into the residual
+// rows of angle "prev" itself: the first `nred` workgroups of the grid -- the ones that start first -- each take a share
+// of the (row, 64-slice chunk) items, one wave per item with its four 16-lane quarters in the role of k_resid_finish's four
+// waves (same split, same order of additions, same division: bit-identical rows).  Rows are published write-through
+// (sc1 stores, s_waitcnt vmcnt(0), then one agent-scope flag store per row and chunk carrying this launch's epoch); a
+// tile workgroup polls the flags of its window rows (one wave, sc1 loads) and stages the rows with sc1 loads.  The reducer
+// duty comes before any wait, so nothing can deadlock whatever the dispatch order or residency; a workgroup whose rows are
+// not flagged after `spin` polls computes them itself from the partials (same arithmetic, into LDS only).
+// Measured: no gain (see "sart_coop" in tomo_engine.hip) -- kept as an option with its tests (tests/test_gpu_sart_coop.py).
+struct StCoop {
+    const float *p_read;            // partial sums of angle "prev" (written by the previous link)
+    const uint32_t *row_first, *row_nseg;   // of angle prev
+    const float *b;                 // measured rows of angle prev
+    const float *rowsum;            // of angle prev
+    float *r_out;                   // residual rows of angle prev (= r_prev of the tile step)
+    uint32_t *flags;                // [row][chunk of the whole slab]
+    uint32_t epoch;
+    int nred, nitems, nchunk_all, spin;
+};
+
+__device__ __forceinline__ void st_store_sc1(float *p, VecOf<4>::T v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ VecOf<4>::T st_load_sc1(const float *base, uint32_t byte_off)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);   // aux 16 = sc1
+}
+
+// One wave: the residual row `row` (of angle prev) for 64-slice chunk cc.  Returns the row in the 16 lanes of quarter 0.
+// U = loads in flight per trip (the additions run in list order whatever U is).
+template <int U>
+__device__ __forceinline__ VecOf<4>::T st_resid_row(const StCoop &co, int row, int cc, int sx)
+{
+    typedef VecOf<4>::T V;
+    const int ln = threadIdx.x & 63, qd = ln >> 4, l16 = ln & 15;
+    const uint32_t first = co.row_first[row], ns = co.row_nseg[row];
+    const int off = cc * 64 + l16 * 4;
+    const size_t o = (size_t)row * sx + off;
+    V bv = *reinterpret_cast<const V *>(co.b + o);
+    const float rs = co.rowsum[row];
+    const uint32_t q = (ns + 3u) >> 2;
+    const uint32_t sb = min((uint32_t)qd * q, ns), se = min(sb + q, ns);
+    V acc = vzero<4>();
+    const float *pp = co.p_read + (size_t)first * sx + off;
+    for (uint32_t s = sb; s < se; s += U) {
+        V t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = (s + u < se) ? *reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx) : vzero<4>();
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += t[u];
+    }
+    V a1, a2, a3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a1[c] = __shfl(acc[c], l16 + 16, 64);
+        a2[c] = __shfl(acc[c], l16 + 32, 64);
+        a3[c] = __shfl(acc[c], l16 + 48, 64);
+    }
+    acc = ((acc + a1) + a2) + a3;
+    return rs > 0.f ? (bv - acc) / rs : vzero<4>();
+}
+
+template <bool FUSED, bool COOP = false>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
                                                            const float *__restrict__ r_prev, float beta,
                                                            const uint2 *__restrict__ segs, const uint32_t *__restrict__ segid,
                                                            const uint2 *__restrict__ ent, float *__restrict__ partial,
-                                                           int n, int sx, int tiles_z, int ntiles, int nchunk, int chunk0)
+                                                           int n, int sx, int tiles_z, int ntiles, int nchunk, int chunk0,
+                                                           StCoop co)
 {
     typedef VecOf<4>::T V;
 #ifdef TOMO_WHATIF
     const int wi_ = g_sart_whatif;
 #endif
+    static_assert(!COOP || FUSED, "the cooperative residual rows feed the voxel update");
+    if (COOP && (int)blockIdx.x < co.nred) {
+        // reducer duty (before anything this workgroup could wait for): items (row, chunk), one wave each
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        for (int it = blockIdx.x * (ST_THREADS / 64) + wv; it < co.nitems; it += co.nred * (ST_THREADS / 64)) {
+            const int row = it / nchunk, cc = chunk0 + it - row * nchunk;
+            V rr = st_resid_row<RF_U>(co, row, cc, sx);
+            if (ln < 16) st_store_sc1(co.r_out + (size_t)row * sx + cc * 64 + ln * 4, rr);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ln == 0) __hip_atomic_store(co.flags + (size_t)row * co.nchunk_all + cc, co.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     extern __shared__ V st_lds[];                       // ST_LDS_V float4 (dynamic)
     V *img = st_lds, *win = st_lds + (ST_PIX + 1) * 16;
     uint4 *cel = reinterpret_cast<uint4 *>(st_lds + (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16);
@@ -762,6 +845,18 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     const int y = ty * ST_TY + (g * 8) / ST_TZ, z0 = tz * ST_TZ + (g * 8) % ST_TZ;
     // the group's ray segments of "next" and all their entry batches are fetched first, so the forward-projection phase
     // at the end touches LDS only (its two dependent loads cost 10 us per launch when issued there)
+    // COOP: the first look at the window rows' flags is issued ahead of the tile loads (loads return in order: issued
+    // behind them it would come back only after the whole tile, and the rows could be requested only then)
+    uint32_t wflag = 0, wbase = 0, wcnt = 0;
+    const uint32_t *wfp = nullptr;
+    if (FUSED && COOP) {
+        const uint32_t w = wins[tile];
+        wbase = w & 0xFFFFu; wcnt = w >> 16;
+        if (t < 64) {
+            wfp = co.flags + (size_t)(wbase + min((uint32_t)t, wcnt ? wcnt - 1 : 0u)) * co.nchunk_all + c;
+            wflag = ((uint32_t)t < wcnt) ? __hip_atomic_load(wfp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : co.epoch;
+        }
+    }
     uint2 sd[ST_SPG];
     uint32_t pid[ST_SPG];
 #pragma unroll
@@ -780,7 +875,35 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
 #pragma unroll
         for (int b = 0; b < ST_MAXB; ++b) eb[q][b] = ((uint32_t)b < sd[q].y) ? ep[(size_t)b * FT_BATCH] : make_uint2((uint32_t)ST_PIX * 256u, 0u);
     }
-    if (FUSED && !ST_WI(8)) {
+    if (FUSED && COOP) {
+        __shared__ int st_rows_ready;
+        if (t < 64) {   // one wave polls the flags of the window's rows
+            bool ok;
+            int spins = 0;
+            for (;;) {
+                ok = __all(wflag == co.epoch);
+                if (ok || ++spins > co.spin) break;
+                __builtin_amdgcn_s_sleep(2);
+                wflag = ((uint32_t)t < wcnt) ? __hip_atomic_load(wfp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : co.epoch;
+            }
+            if (co.spin < 0) ok = false;                 // tests: every workgroup takes the do-it-yourself path
+            if (t == 0) st_rows_ready = ok;
+        }
+        if (t < ST_PIX) cel[t] = cells[(size_t)tile * ST_PIX + t];
+        __syncthreads();
+        if (st_rows_ready) {
+            for (int i = t; i < (ST_MAXR + 1) * 16; i += ST_THREADS) {
+                int j = i >> 4;
+                win[i] = ((uint32_t)j < wcnt) ? st_load_sc1(r_prev, (uint32_t)((((size_t)wbase + j) * sx + c * 64 + (i & 15) * 4) * sizeof(float))) : vzero<4>();
+            }
+        } else {        // rows not published in time (reducer workgroups not resident yet): this workgroup's own copy
+            const int wv = t >> 6, ln = t & 63;
+            for (int j = wv; j < ST_MAXR + 1; j += ST_THREADS / 64) {
+                V rr = ((uint32_t)j < wcnt) ? st_resid_row<2>(co, (int)wbase + j, c, sx) : vzero<4>();
+                if (ln < 16) win[j * 16 + ln] = rr;
+            }
+        }
+    } else if (FUSED && !ST_WI(8)) {
         uint32_t w = wins[tile];
         for (int i = t; i < (ST_MAXR + 1) * 16; i += ST_THREADS) {
             int j = i >> 4;

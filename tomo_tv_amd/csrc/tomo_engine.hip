@@ -61,6 +61,7 @@ struct tomo_engine {
     // tv_recompute: a tv_gd inner iteration as "norm pass (no store) + recompute-and-update pass into a second buffer" instead
     // of "gradient pass (store g) + update pass": one volume write instead of two (HBM writes are the scarce resource)
     int tv_recompute = 1, tv_tz = 8;              // tv_tz: z-columns per wave of the register march (8 or 4)
+    int tv_yseg = 0;                              // rows per wave of the register march; 0 = by slab size (tv_rows_per_wave)
     int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
     hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
     float tv_last_eps = 1e-6f;
@@ -96,7 +97,15 @@ struct tomo_engine {
     uint4 *d_st_cell = nullptr;
     uint32_t *d_st_win = nullptr, *d_st_segid = nullptr, *d_st_row_first = nullptr, *d_st_row_nseg = nullptr;
     uint2 *d_st_seg = nullptr, *d_st_ent = nullptr;
-    float *st_partial = nullptr;
+    float *st_partial = nullptr, *st_partial2 = nullptr;   // tile partial sums; the second buffer of the cooperative chain (links alternate)
+    uint32_t *st_flags = nullptr;                          // [ray of an angle][64-slice chunk]: epoch of the launch that published the residual row
+    uint32_t st_epoch = 0;
+    // "sart_coop" = 1: residual rows inside the tile step (k_sart_tile COOP) instead of one k_resid_finish launch per angle.
+    // Off by default -- measured (round 2, 512^2 x 90): the step kernel grows by what the dropped launch and its two
+    // boundaries cost (221 vs 210 us at 512 slices: 27.3 ms per ASD-POCS step either way) and by more on thin slabs
+    // (64 slices: 37.0 vs 30.8 us, 5.25 vs 4.87 ms per step): the first workgroups cannot start their voxel update before
+    // the rows exist, so the reduction is serial either way and only moves inside the launch.
+    int sart_coop = 0, sart_coop_spin = 4096, st_resident = 0;
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
     bool fb_ok = false;
     uint4 *d_fb_cell = nullptr;
@@ -254,6 +263,7 @@ static int part_end(tomo_engine *e, double *part, int slot)
 static int reduce_begin(tomo_engine *e) { return part_begin(e, e->d_part); }
 static int reduce_end(tomo_engine *e, int slot) { return part_end(e, e->d_part, slot); }
 
+constexpr int TV_YSEG_MIN = 8, TV_WAVES_WANTED = 8192;
 static int grid_1d(int64_t n4) { int64_t b = (n4 + 255) / 256; return (int)std::min<int64_t>(std::max<int64_t>(b, 1), 4096); }
 
 // ---- projector launches -------------------------------------------------------------------------------------
@@ -404,42 +414,94 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
 // tile form of the per-angle step (k_sart_tile): FUSED -> BP(prev) + FP(next), in place; else plain FP(next).
 // Leaves the residual rows of `next` in r.
 // (function attributes and the partial-sum buffer are set up by sart_tile_prepare, on the caller's thread and stream)
-static int sart_tile_prepare(tomo_engine *e)
+static int sart_tile_prepare(tomo_engine *e, bool coop)
 {
     if (!e->attr_st) {
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
+        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         e->attr_st = true;
     }
+    const size_t pbytes = (size_t)std::max<uint32_t>(1, e->st_max_ids) * e->sx * sizeof(float);
     if (!e->st_partial) {
-        int rc = dev_alloc((void **)&e->st_partial, (size_t)std::max<uint32_t>(1, e->st_max_ids) * e->sx * sizeof(float), true, e->stream);
+        int rc = dev_alloc((void **)&e->st_partial, pbytes, true, e->stream);
         if (rc) return rc;
+    }
+    if (coop && !e->st_partial2) {
+        int rc = dev_alloc((void **)&e->st_partial2, pbytes, true, e->stream);
+        if (rc) return rc;
+        if ((rc = dev_alloc((void **)&e->st_flags, (size_t)e->n * (e->sxc / 64) * sizeof(uint32_t), true, e->stream))) return rc;
+        // workgroups that start together: the reducer duty is dealt to that many (2 per CU by LDS; any value is correct)
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, e->device));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sart_tile<true, true>, ST_THREADS, ST_LDS_V * 16));
+        e->st_resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
     }
     return TOMO_OK;
 }
 
+// residual rows of angle `next` from the tile partial sums in `partial` (k_resid_finish)
+static int launch_resid_finish_tile(tomo_engine *e, const Sub &sb, const float *partial, int next, float *r)
+{
+    const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
+    int nchunk = nchunk64 / e->vec, chunk0 = c64 / e->vec;
+    dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
+    switch (e->vec) {
+    case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+    case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+    default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+    }
+    LAUNCHCHK();
+    return TOMO_OK;
+}
+
+// finish = false leaves the partial sums of `next` in `partial` for the next link's reducer duty (cooperative chain)
 template <bool FUSED>
-static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, int next, float *r, float beta)
+static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, int next, float *r, float beta,
+                            float *partial = nullptr, bool finish = true)
 {
     const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
     const size_t nt = (size_t)e->st_ntiles;
+    if (!partial) partial = e->st_partial;
     {
         ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE, sb.stream);
         dim3 grid((unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64)), block(ST_THREADS);
         hipLaunchKernelGGL((k_sart_tile<FUSED>), grid, block, ST_LDS_V * 16, sb.stream, x, x,
                            FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
                            FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
-                           e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, e->st_partial,
-                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64);
+                           e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, partial,
+                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, StCoop{});
         LAUNCHCHK();
     }
-    int nchunk = nchunk64 / e->vec, chunk0 = c64 / e->vec;
-    dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
-    switch (e->vec) {
-    case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, sb.stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
-    case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, sb.stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
-    default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, sb.stream, e->st_partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
-    }
+    return finish ? launch_resid_finish_tile(e, sb, partial, next, r) : TOMO_OK;
+}
+
+// cooperative link: residual rows of `prev` from p_read (reducer duty of the first workgroups), BP(prev) + FP(next) -> p_write
+static int launch_sart_coop(tomo_engine *e, const Sub &sb, float *x, int prev, int next, float *r, float beta,
+                            const float *p_read, float *p_write, uint32_t epoch)
+{
+    const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
+    const size_t nt = (size_t)e->st_ntiles;
+    ProfScope ps(e, TOMO_K_SART_FUSED, sb.stream);
+    const unsigned nblocks = (unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64);
+    StCoop co;
+    co.p_read = p_read;
+    co.row_first = e->d_st_row_first + (size_t)prev * e->n;
+    co.row_nseg = e->d_st_row_nseg + (size_t)prev * e->n;
+    co.b = e->cur_b + (size_t)prev * e->n * e->sx;
+    co.rowsum = e->d_rowsum + (size_t)prev * e->n;
+    co.r_out = r + (size_t)prev * e->n * e->sx;
+    co.flags = e->st_flags;
+    co.epoch = epoch;
+    co.nitems = e->n * nchunk64;
+    co.nred = (int)std::min<unsigned>(nblocks, (unsigned)std::max(1, e->st_resident));
+    co.nchunk_all = e->sxc / 64;
+    co.spin = e->sart_coop_spin;
+    hipLaunchKernelGGL((k_sart_tile<true, true>), dim3(nblocks), dim3(ST_THREADS), ST_LDS_V * 16, sb.stream, x, x,
+                       e->d_st_cell + (size_t)prev * nt * ST_PIX, e->d_st_win + (size_t)prev * nt, r + (size_t)prev * e->n * e->sx, beta,
+                       e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, p_write,
+                       e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, co);
     LAUNCHCHK();
     return TOMO_OK;
 }
@@ -692,7 +754,7 @@ int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const 
 static void free_geometry(tomo_engine *e)
 {
     void **ptrs[] = {(void **)&e->d_st_cell, (void **)&e->d_st_win, (void **)&e->d_st_segid, (void **)&e->d_st_seg, (void **)&e->d_st_ent,
-                     (void **)&e->d_st_row_first, (void **)&e->d_st_row_nseg, (void **)&e->st_partial, (void **)&e->d_fb_cell, (void **)&e->d_fb_win,
+                     (void **)&e->d_st_row_first, (void **)&e->d_st_row_nseg, (void **)&e->st_partial, (void **)&e->st_partial2, (void **)&e->st_flags, (void **)&e->d_fb_cell, (void **)&e->d_fb_win,
                      (void **)&e->d_ft_slot_ptr, (void **)&e->d_ft_slot_seg0, (void **)&e->d_ft_tent, (void **)&e->d_ft_rsptr, (void **)&e->d_ft_rsidx,
                      (void **)&e->ft_part, (void **)&e->ft_part_aux, (void **)&e->cg_w, (void **)&e->fbp_h, (void **)&e->d_seg_exec,
                      (void **)&e->d_row_first, (void **)&e->d_row_nseg, (void **)&e->seg_partial, (void **)&e->d_wptr, (void **)&e->d_went,
@@ -1001,10 +1063,24 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
     // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
     if (steps <= 0) return TOMO_OK;
     if (e->sart_tile && e->st_ok) {   // tile form, in place
-        if ((rc = sart_tile_prepare(e))) return rc;
+        // cooperative chain (k_sart_tile COOP): needs consecutive angles to differ (np >= 2) and whole 64-slice chunks
+        const bool coop = e->sart_coop && e->np >= 2 && steps >= 2;
+        if ((rc = sart_tile_prepare(e, coop))) return rc;
+        const uint32_t epoch0 = e->st_epoch + 1;             // link k publishes with epoch0 + k (both sub-slab chains alike)
+        if (coop) e->st_epoch += (uint32_t)(steps + 1);
         // link k of the chain: 0 = FP(a0); 1..steps-1 = BP(a_k-1) + FP(a_k); steps = BP(a_last)
         auto link = [&](int64_t k, const Sub &sb) -> int {
             int rc2;
+            if (coop) {
+                float *pk = (k & 1) ? e->st_partial2 : e->st_partial, *pk1 = (k & 1) ? e->st_partial : e->st_partial2;   // P[k&1], P[(k-1)&1]
+                if (k == 0) return launch_sart_tile<false>(e, sb, x, 0, angle_at(0), r, beta, pk, false);
+                if (k == steps) {
+                    int last = angle_at(steps - 1);
+                    if ((rc2 = launch_resid_finish_tile(e, sb, pk1, last, r))) return rc2;
+                    return launch_bp_angle(e, sb, x, last, r + (size_t)last * e->n * e->sx, beta, track);
+                }
+                return launch_sart_coop(e, sb, x, angle_at(k - 1), angle_at(k), r, beta, pk1, pk, epoch0 + (uint32_t)k);
+            }
             if (k == 0) return launch_sart_tile<false>(e, sb, x, 0, angle_at(0), r, beta);
             if (k == steps) { int last = angle_at(steps - 1); return launch_bp_angle(e, sb, x, last, r + (size_t)last * e->n * e->sx, beta, track); }
             int prev = angle_at(k - 1), next = angle_at(k);
@@ -1604,6 +1680,18 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
     return part_end(e, e->d_part_tv, TOMO_S_TV);
 }
 
+// Rows a wave of the register march walks.  32 at a full slab (8 chunks x 64 z-blocks x 16 segments = 8192 waves at 512^3);
+// a thin slab of a multi-GPU run has too few waves at that length (64 slices: 1024 waves, 4 per CU), so the segments
+// shrink until there are ~8 waves per SIMD lane group again -- the 2 halo rows a segment re-reads cost less than the idle CUs.
+static int tv_rows_per_wave(const tomo_engine *e, int tz)
+{
+    if (e->tv_yseg > 0) return e->tv_yseg;
+    const int64_t cols = (int64_t)((e->n + tz - 1) / tz) * (e->sxc / 64);
+    int yseg = 32;
+    while (yseg > TV_YSEG_MIN && cols * ((e->n + yseg - 1) / yseg) < TV_WAVES_WANTED) yseg >>= 1;
+    return yseg;
+}
+
 static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
 {
     NEED(e);
@@ -1621,7 +1709,7 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
         ProfScope ps(e, TOMO_K_TV_GRAD);
         e->tv_last_eps = eps;
         if (e->tv_lds == 1 && e->tv_recompute) {   // sum g^2 (and TV) only: the update pass re-evaluates g (TVM_UPDATE)
-            int yseg = 32;
+            const int yseg = tv_rows_per_wave(e, e->tv_tz == 4 ? 4 : 8);
             if (e->tv_tz == 4) {
                 dim3 grid(tv_march_grid(e->n, 4, e->sxc / 64, (e->n + yseg - 1) / yseg));
                 if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<4, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
@@ -1713,7 +1801,7 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
         TvUpd up{alt, e->d_scal + e->gnorm_slot, dPOCS, clamp, track, wl, wh};
         {
             ProfScope ps(e, TOMO_K_TV_UPDATE);
-            int yseg = 32;
+            const int yseg = tv_rows_per_wave(e, e->tv_tz == 4 ? 4 : 8);
             if (e->tv_tz == 4) {
                 dim3 grid(tv_march_grid(e->n, 4, e->sxc / 64, (e->n + yseg - 1) / yseg));
                 hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
@@ -1946,6 +2034,8 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? 2 : 1; return TOMO_OK; }
+    if (std::strcmp(name, "sart_coop") == 0) { e->sart_coop = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_chunks_per_pass") == 0) {   // any count >= 1 (0 = from the scratch cap); before the first projection
@@ -1961,6 +2051,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         e->gnorm_slot = value; return TOMO_OK;
     }
     if (std::strcmp(name, "tv_tz") == 0) { e->tv_tz = value == 4 ? 4 : 8; return TOMO_OK; }
+    if (std::strcmp(name, "tv_yseg") == 0) { e->tv_yseg = value < 0 ? 0 : value; return TOMO_OK; }
     if (std::strcmp(name, "tv_recompute") == 0) { e->tv_recompute = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 1 register march, 8 / 16 LDS march (z-columns per workgroup), 0 direct
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
