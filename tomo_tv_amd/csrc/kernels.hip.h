@@ -1718,6 +1718,9 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
 // what-if build without the phantom-slice evaluation (-104 of ~440 instructions per row) runs an inner iteration in 470 instead
 // of 530 us, and 4 z-columns per wave (68 VGPRs, 7 waves per SIMD instead of 4) in the same 530: the passes are about half
 // instruction-bound, not occupancy-bound.  Handing R across chunk edges costs what it saves in every form tried.
+// What did help a little: evaluating R at the phantom slice once per row for all columns on PACKED inputs (lane j = column j,
+// two gather loads per row) instead of once per column on the edge registers: -72 vector instructions per row, an inner
+// iteration 516 -> 500 us at 512 slices, 93 -> 90.5 us at 64 (same box, both libraries side by side).
 // workgroups (4 waves) of the march kernels' item space, for the XCD-aware map above
 inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
 {
@@ -1810,9 +1813,22 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
         auto shl = [&](float old, float v) {                    // lane l <- lane l+1 ; lane 63 keeps `old`
             return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
         };
+        // Phantom slice s0-1, packed: lane j (< TZ+2) holds column j's value at slice s0-1 (PE*) and at slice s0 (PC*) of a
+        // row, so R at the phantom slice is ONE evaluation per row for all columns (lanes 1..TZ) instead of one full-wave
+        // evaluation per column of which only lane 0 was used (104 of ~440 vector instructions per row).  Two gather loads
+        // per row (hits: the column loads of this wave and of the neighbouring chunk touch the same lines).
+        float PE0 = 0.f, PEp = 0.f, PEn = 0.f, PC0 = 0.f, PCn = 0.f;
+        int zl;
+        { int z = (z0 - 1 + (lane < TZ + 2 ? lane : 0)) % n; zl = z < 0 ? z + n : z; }
+        auto fetch_ph = [&](int y, float &pe, float &pc) {
+            int pix = yrow(y) * n + zl;
+            pe = tv_ld(x, h, pix, s0 - 1, nx, sx);
+            pc = tv_ld(x, h, pix, s0, nx, sx);
+        };
         if (GRAD) fetch(y0 - 1, cm, En);
         fetch(y0, c0, E0);
         fetch(y0 + 1, cp, Ep);
+        if (GRAD) { float pcp; fetch_ph(y0, PE0, PC0); fetch_ph(y0 + 1, PEp, pcp); PCn = pcp; }
         // R of row y0-1 for the output columns (its +y neighbour is row y0)
 #pragma unroll
         for (int j = 1; GRAD && j <= TZ; ++j) {
@@ -1821,7 +1837,16 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
             (void)dd;
         }
         for (int y = y0; y < y1; ++y) {
-            if (y + 1 < y1) fetch(y + 2, cn, En);               // in flight while this row is computed
+            float PCp = PCn;                                    // slice s0 of row y+1 (fetched with its PE)
+            if (y + 1 < y1) { fetch(y + 2, cn, En); if (GRAD) fetch_ph(y + 2, PEn, PCn); }   // in flight while this row is computed
+            // R at the phantom slice of row y, all columns at once: lane j <- column j
+            float REp;
+            if (GRAD) {
+                float kp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, PE0), 0x101, 0xf, 0xf, false));   // row_shl:1 -> column j+1
+                float dd;
+                TVR_RINV(PE0, PC0, PEp, kp, REp, dd)
+                (void)dd;
+            }
             float xip[TZ + 1];
 #pragma unroll
             for (int j = 0; j <= TZ; ++j) {
@@ -1832,10 +1857,8 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
             }
 #pragma unroll
             for (int j = 1; GRAD && j <= TZ; ++j) {
-                // R at the phantom slice s0-1 (lane 0 of the edge registers), then R(p-i) by the shift
-                float re, dd;
-                TVR_RINV(E0[j], c0[j], Ep[j], E0[j + 1], re, dd)
-                (void)dd;
+                // R at the phantom slice s0-1 (lane j of the packed evaluation), then R(p-i) by the shift
+                float re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, REp), j));
                 float rim = shr(re, R0[j]);
                 float xim = shr(E0[j], c0[j]);
                 float c = c0[j];
@@ -1870,6 +1893,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
             // 141 VGPRs, 10 % slower)
 #pragma unroll
             for (int j = 0; j < TZ + 2; ++j) { cm[j] = c0[j]; c0[j] = cp[j]; cp[j] = cn[j]; E0[j] = Ep[j]; Ep[j] = En[j]; }
+            PE0 = PEp; PEp = PEn; PC0 = PCp;
 #pragma unroll
             for (int j = 1; j <= TZ; ++j) Rm[j] = R0[j];
         }
