@@ -53,6 +53,25 @@ __device__ __forceinline__ void block_accumulate(double v, double *__restrict__ 
     if (threadIdx.x == 0) atomicAdd(&part[blockIdx.x & (NPART - 1)], red[0] + red[1] + red[2] + red[3]);
 }
 
+// Non-temporal access by experiment bit (make EXTRA=-DTOMO_NT=<mask>); bits that paid are folded into NT_DEFAULT.
+#ifndef TOMO_NT
+#define TOMO_NT 0
+#endif
+constexpr int NT_DEFAULT = 4 | 32 | 256;
+template <int BIT, typename T>
+__device__ __forceinline__ T nt_ld(const T *p)
+{
+    if constexpr (((TOMO_NT | NT_DEFAULT) & BIT) != 0) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int BIT, typename T>
+__device__ __forceinline__ void nt_st(T v, T *p)
+{
+    if constexpr (((TOMO_NT | NT_DEFAULT) & BIT) != 0) {
+        __builtin_nontemporal_store(v, p);
+    } else *p = v;
+}
+
 __global__ void k_finalize(double *__restrict__ part, double *__restrict__ dst)
 {
     double v = part[threadIdx.x];  // launched with NPART threads
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
         for (int k = 0; k < FT_PIX / 64; ++k) {
             int lp = (t >> 4) + 64 * k;
             int y = ty * FT_TY + lp / FT_TZ, z = tz * FT_TZ + lp % FT_TZ;
-            v[k] = (y < n && z < n) ? *reinterpret_cast<const V *>(x + ((size_t)y * n + z) * sx + (size_t)(chunk0 + c) * 64 + gl * 4)
+            v[k] = (y < n && z < n) ? nt_ld<16>(reinterpret_cast<const V *>(x + ((size_t)y * n + z) * sx + (size_t)(chunk0 + c) * 64 + gl * 4))
                                     : vzero<4>();
         }
 #pragma unroll
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
         E = ep[(size_t)(b + (I) + FT_PF) * FT_BATCH];                                                     \
         FT_FMA(0) FT_FMA(1) FT_FMA(2) FT_FMA(3) FT_FMA(4) FT_FMA(5) FT_FMA(6) FT_FMA(7)                   \
         if (last) {                                                                                       \
-            *reinterpret_cast<V *>(part + ((size_t)seg * ncp + c) * 64 + gl * 4) = acc;                   \
+            nt_st<32>(acc, reinterpret_cast<V *>(part + ((size_t)seg * ncp + c) * 64 + gl * 4));         \
             acc = vzero<4>();                                                                             \
             ++seg;                                                                                        \
         }                                                                                                 \
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(256) void k_fp_tile_reduce(const float *__restrict_
     for (uint32_t k = kb; __any(k < ke); k += U) {
         V pv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) pv[u] = (sidx[u] != 0xFFFFFFFFu) ? *reinterpret_cast<const V *>(pp + (size_t)sidx[u] * ncp * 64) : vzero<4>();
+        for (int u = 0; u < U; ++u) pv[u] = (sidx[u] != 0xFFFFFFFFu) ? nt_ld<32>(reinterpret_cast<const V *>(pp + (size_t)sidx[u] * ncp * 64)) : vzero<4>();
 #pragma unroll
         for (int u = 0; u < U; ++u) sn[u] = (k + U + u < ke) ? rsidx[k + U + u] : 0xFFFFFFFFu;
 #pragma unroll
@@ -490,10 +509,10 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
     for (int q = 0; q < PPW; ++q) {
         int p = min(p0 + q, npix - 1);
         c[q] = cell[p];
-        xv[q] = *reinterpret_cast<const V *>(x + (size_t)p * sx + off);
+        xv[q] = nt_ld<1>(reinterpret_cast<const V *>(x + (size_t)p * sx + off));
         r0[q] = *reinterpret_cast<const V *>(r + (size_t)c[q].r0 * sx + off);
         r1[q] = *reinterpret_cast<const V *>(r + (size_t)c[q].r1 * sx + off);
-        if (TRACK) tk[q] = *reinterpret_cast<const V *>(track + (size_t)p * sx + off);
+        if (TRACK) tk[q] = nt_ld<1>(reinterpret_cast<const V *>(track + (size_t)p * sx + off));
     }
     double local = 0.0;
 #pragma unroll
@@ -507,11 +526,11 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
             V nv = xv[q] + beta * upd;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
-            *reinterpret_cast<V *>(x + (size_t)p * sx + off) = nv;
+            nt_st<1>(nv, reinterpret_cast<V *>(x + (size_t)p * sx + off));
             if (TRACK) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { float d = velem<VEC>(nv, i) - velem<VEC>(tk[q], i); local += (double)(d * d); }
-                *reinterpret_cast<V *>(track + (size_t)p * sx + off) = nv;
+                nt_st<1>(nv, reinterpret_cast<V *>(track + (size_t)p * sx + off));
             }
         }
     }
@@ -638,7 +657,7 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
     for (uint32_t s = sb; s < se; s += RF_U) {        // RF_U independent loads per trip (one trip at the tile form's ~N/11
         V t[RF_U];                                    // partials per ray), summed in segment order
 #pragma unroll
-        for (int u = 0; u < RF_U; ++u) t[u] = (s + u < se) ? *reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx) : vzero<VEC>();
+        for (int u = 0; u < RF_U; ++u) t[u] = (s + u < se) ? nt_ld<2>(reinterpret_cast<const V *>(pp + (size_t)(s + u) * sx)) : vzero<VEC>();
 #pragma unroll
         for (int u = 0; u < RF_U; ++u) acc += t[u];
     }
@@ -762,7 +781,7 @@ struct StCoop {
 
 __device__ __forceinline__ void st_store_sc1(float *p, VecOf<4>::T v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");   // s_nop: see ST_XSTORE
 }
 __device__ __forceinline__ VecOf<4>::T st_load_sc1(const float *base, uint32_t byte_off)
 {
@@ -804,6 +823,16 @@ __device__ __forceinline__ VecOf<4>::T st_resid_row(const StCoop &co, int row, i
     return rs > 0.f ? (bv - acc) / rs : vzero<4>();
 }
 
+// The tile's voxels are read once and written once per launch: non-temporal loads and stores keep them from displacing the
+// residual rows, partial sums and tables the launch (and k_resid_finish after it) re-reads from L2.  Measured (512^3 x 90, a
+// sweep incl. k_resid_finish, same box): 222 us per angle plain, 211 nt loads only, 226 nt stores only, 202.5 both.
+#define ST_XLOAD(p) __builtin_nontemporal_load(p)
+// Stores: nt 202.8 us per angle, sc1 201.5, sc0 sc1 201.5, sc1 nt 199.5, sc0 sc1 nt 199.3 (write-through and not kept in L2);
+// loads: nt 200.5, sc1 205, nt sc1 200.6 (same run).  The store is inline asm (no builtin carries sc1 nt): 16 bytes per lane,
+// whole 256-byte pieces per 16-lane group.
+// (An inline-asm store is invisible to the compiler's hazard recogniser: a 128-bit store needs a wait state before its data
+// registers are written again -- the s_nop; without it a k_fp_tile trial of this store lost data.)
+#define ST_XSTORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory")
 template <bool FUSED, bool COOP = false>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
@@ -867,7 +896,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     V xv[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
-        xv[J] = (y < n && z0 + J < n && !ST_WI(16)) ? *reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off) : vzero<4>();
+        xv[J] = (y < n && z0 + J < n && !ST_WI(16)) ? ST_XLOAD(reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off)) : vzero<4>();
     uint2 eb[ST_SPG][ST_MAXB];
 #pragma unroll
     for (int q = 0; q < ST_SPG; ++q) {
@@ -927,7 +956,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             V nv = xv[J] + beta * upd;
             nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
             xv[J] = nv;
-            if (y < n && z0 + J < n && !ST_WI(1)) *reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off) = nv;
+            if (y < n && z0 + J < n && !ST_WI(1)) ST_XSTORE(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
         }
     }
     if (ST_WI(4)) {
@@ -969,7 +998,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
                 }
             }
         }
-        *reinterpret_cast<V *>(partial + (size_t)pid[q] * sx + off) = acc;
+        nt_st<128>(acc, reinterpret_cast<V *>(partial + (size_t)pid[q] * sx + off));
     }
 #undef ST_FMA
 #undef ST_LOAD
@@ -1088,9 +1117,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
             if (colsum) { float cs = colsum[p]; a = cs > 0.f ? a / cs : vzero<4>(); }
             float *xp = x + p * sx + off;
             V nv = beta * a;
-            if (alpha != 0.f) nv = alpha * (*reinterpret_cast<const V *>(xp)) + nv;
+            if (alpha != 0.f) nv = alpha * nt_ld<64>(reinterpret_cast<const V *>(xp)) + nv;
             if (clamp) { nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f); }
-            *reinterpret_cast<V *>(xp) = nv;
+            nt_st<64>(nv, reinterpret_cast<V *>(xp));
         }
     }
 }
@@ -1276,10 +1305,11 @@ __global__ __launch_bounds__(256) void k_momentum(f4 *__restrict__ recon, f4 *__
                                                    f4 *__restrict__ old, float beta, int64_t n4)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f4 r = yk[i], o = old[i];
-        recon[i] = r;
-        yk[i] = r + beta * (r - o);
-        old[i] = r;
+        typedef VecOf<4>::T V;
+        V r = nt_ld<512>(reinterpret_cast<const V *>(yk) + i), o = nt_ld<512>(reinterpret_cast<const V *>(old) + i);
+        nt_st<512>(r, reinterpret_cast<V *>(recon) + i);
+        nt_st<512>(r + beta * (r - o), reinterpret_cast<V *>(yk) + i);
+        nt_st<512>(r, reinterpret_cast<V *>(old) + i);
     }
 }
 
@@ -1786,8 +1816,8 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 #pragma unroll
                 for (int j = 0; j < TZ + 2; ++j) {
                     const float *rp = x + (size_t)(yy + zc[j]) * sx;   // wave-uniform; unsigned lane offsets -> saddr form
-                    c[j] = rp[(unsigned)s];
-                    E[j] = rp[(unsigned)se];
+                    c[j] = nt_ld<8>(rp + (unsigned)s);
+                    E[j] = nt_ld<8>(rp + (unsigned)se);
                 }
             } else {
 #pragma unroll
@@ -1875,16 +1905,16 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                         const size_t pix = (size_t)(y * n + z);
                         float v = __fsub_rn(c, __fdiv_rn(__fmul_rn(up.dPOCS, gv), nrm_));   // = k_tv_update's x - (dPOCS g)/||g||
                         if (up.clamp) v = fmaxf(v, 0.f);
-                        up.x_out[pix * sx + (unsigned)s] = v;
+                        nt_st<4>(v, up.x_out + pix * sx + (unsigned)s);
                         if (up.wrap_lo) {
                             if (s == 0) up.wrap_hi[pix] = v;
                             if (s == nx - 1) up.wrap_lo[pix] = v;
                         }
                         if (up.track) {
                             float *tr = up.track + pix * sx;
-                            float d = v - tr[(unsigned)s];
+                            float d = v - nt_ld<4>(tr + (unsigned)s);
                             acc += (double)(d * d);
-                            tr[(unsigned)s] = v;
+                            nt_st<4>(v, tr + (unsigned)s);
                         }
                     }
                 }
@@ -2134,7 +2164,7 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
                     a *= sq_; b *= sq_; c *= sq_;
                 }
                 size_t o = (size_t)(y * n + z) * sx + s;
-                P1o[o] = a; P2o[o] = b; P3o[o] = c;
+                nt_st<256>(a, P1o + o); nt_st<256>(b, P2o + o); nt_st<256>(c, P3o + o);
                 if (SHARDED) {
                     const size_t pix = (size_t)y * n + z;
                     if (s == 0) { ed.send_first[npix + pix] = a; ed.send_first[2 * npix + pix] = b; ed.send_first[3 * npix + pix] = c; }

@@ -15,7 +15,7 @@ typedef float V __attribute__((ext_vector_type(4)));
 constexpr int NWG = 256, NI = 48, NRAY = 2 * NWG, NCONTRIB = NI;   // rays 2m+b get a partial from workgroups (m - i) mod 256, i < 48
 constexpr int SPIN_MAX = 1 << 22;
 
-__device__ __forceinline__ void st_sc1(float *p, V v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_sc1(float *p, V v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ V ld_sc1(const float *base, uint32_t byte_off)
 {
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
