@@ -37,7 +37,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak
 LDS_PEAK_GBS = 256 * 256 * 2.4   # 256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz = 157 TB/s
-RMW_CEILING_GBS = 5300.0     # measured: tools/micro/copy_patterns.hip (read + write of the slab in place) -- informative
+RMW_CEILING_GBS = 5860.0     # measured: tools/micro/copy_patterns.hip (in-place read + write of the slab by 16x16x64 tiles, non-temporal
+                             # loads and stores; 5340 with plain ones) -- informative
 
 
 def asd_pocs_step(t, st):

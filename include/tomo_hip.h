@@ -240,6 +240,13 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     second chain enqueued by a second host thread (slices are independent; each stream fills the other's
  *                     launch gaps).  Measured: -2.4 % per sweep at 512 slices, +26 % at 1024 (the sub-slabs interleave inside
  *                     every pixel row), so the default is one chain on the engine's stream
+ *   "sart_nt" (-1):   cache policy of k_sart_tile's voxel accesses: 1 = streamed (non-temporal loads, write-through
+ *                     non-temporal stores: -9 % per sweep at 512^3), 0 = plain, -1 = streamed when the slab exceeds 192 MB
+ *                     (a slab that fits the Infinity Cache is faster with plain accesses)
+ *   "sart_coop" (0):  1 = the residual rows of an angle are formed inside the next tile step by its first workgroups
+ *                     instead of one k_resid_finish launch per angle (bit-identical; measured no faster);
+ *                     "sart_coop_spin" (4096): polls before a workgroup forms its rows itself (< 0: always, for tests)
+ *   "tv_yseg" (0):    rows a wave of the TV register march walks; 0 = 32, shortened on thin slabs until >= 8192 waves
  *   "fp_tile" (1):    all-angle forward projection from LDS-resident image tiles (k_fp_tile + k_fp_tile_reduce);
  *                     0 = ray-driven form selected by "fp_all_lpr"
  *   "fp_tile_scratch_mib" (8192): cap of the tile projector's partial-sum scratch; a larger volume is projected in

@@ -57,17 +57,20 @@ __device__ __forceinline__ void block_accumulate(double v, double *__restrict__ 
 #ifndef TOMO_NT
 #define TOMO_NT 0
 #endif
-constexpr int NT_DEFAULT = 4 | 32 | 256;
+#ifndef TOMO_NT_OFF   // experiment: bits of NT_DEFAULT switched off
+#define TOMO_NT_OFF 0
+#endif
+constexpr int NT_DEFAULT = 32 | 256;   // 32: k_fp_tile partial sums (SIRT iteration -5 %); 256: k_fgp_fused outputs (-4 %)
 template <int BIT, typename T>
 __device__ __forceinline__ T nt_ld(const T *p)
 {
-    if constexpr (((TOMO_NT | NT_DEFAULT) & BIT) != 0) return __builtin_nontemporal_load(p);
+    if constexpr (((TOMO_NT | NT_DEFAULT) & ~TOMO_NT_OFF & BIT) != 0) return __builtin_nontemporal_load(p);
     else return *p;
 }
 template <int BIT, typename T>
 __device__ __forceinline__ void nt_st(T v, T *p)
 {
-    if constexpr (((TOMO_NT | NT_DEFAULT) & BIT) != 0) {
+    if constexpr (((TOMO_NT | NT_DEFAULT) & ~TOMO_NT_OFF & BIT) != 0) {
         __builtin_nontemporal_store(v, p);
     } else *p = v;
 }
@@ -737,7 +740,8 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
 // Tile shape: ST_TY rows x ST_TZ columns, 8 pixels per 16-lane group.  Measured at 512^3 x 90 (MI355X, round 2):
 // 16 x 16 tiles, 512 threads, 75 KB of LDS (two workgroups per CU): 218-224 us per fused step; 16 x 8 tiles (tall: rays
 // of a -70..70 degree series run closer to the y axis), 256 threads, 40 KB (FOUR workgroups per CU): 231 us, the
-// per-angle FP 160 instead of 144 us -- more independent phases per CU did not pay for 40 % more partial sums.  The kernel
+// per-angle FP 160 instead of 144 us -- more independent phases per CU did not pay for 40 % more partial sums (again with the
+// non-temporal tile accesses below: 204.7 against 200.3 us per angle).  The kernel
 // is not HBM-bound either: a 128-slice slab that sits in the 256 MB Infinity Cache runs at the same rate per byte.
 constexpr int ST_TY = 16, ST_TZ = 16, ST_PIX = ST_TY * ST_TZ, ST_THREADS = 512, ST_MAXR = 26, ST_MAXSEG = 32;
 constexpr int ST_NG = ST_THREADS / 16, ST_SPG = ST_MAXSEG / ST_NG;   // 16-lane groups; ray segments per group
@@ -781,7 +785,7 @@ struct StCoop {
 
 __device__ __forceinline__ void st_store_sc1(float *p, VecOf<4>::T v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");   // s_nop: see ST_XSTORE
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");   // s_nop: see st_xstore
 }
 __device__ __forceinline__ VecOf<4>::T st_load_sc1(const float *base, uint32_t byte_off)
 {
@@ -826,14 +830,27 @@ __device__ __forceinline__ VecOf<4>::T st_resid_row(const StCoop &co, int row, i
 // The tile's voxels are read once and written once per launch: non-temporal loads and stores keep them from displacing the
 // residual rows, partial sums and tables the launch (and k_resid_finish after it) re-reads from L2.  Measured (512^3 x 90, a
 // sweep incl. k_resid_finish, same box): 222 us per angle plain, 211 nt loads only, 226 nt stores only, 202.5 both.
-#define ST_XLOAD(p) __builtin_nontemporal_load(p)
+// NT = false (slabs that fit the 256 MB Infinity Cache: the thin slabs of a multi-GPU run) keeps plain accesses -- there the
+// next angle's launch finds the slab cached and the streaming forms lose (64 slices: 33.5 against 30.8 us per step, 128: 57.6
+// against 53.2; 256 slices: 100.1 against 104).
 // Stores: nt 202.8 us per angle, sc1 201.5, sc0 sc1 201.5, sc1 nt 199.5, sc0 sc1 nt 199.3 (write-through and not kept in L2);
 // loads: nt 200.5, sc1 205, nt sc1 200.6 (same run).  The store is inline asm (no builtin carries sc1 nt): 16 bytes per lane,
-// whole 256-byte pieces per 16-lane group.
-// (An inline-asm store is invisible to the compiler's hazard recogniser: a 128-bit store needs a wait state before its data
-// registers are written again -- the s_nop; without it a k_fp_tile trial of this store lost data.)
-#define ST_XSTORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory")
-template <bool FUSED, bool COOP = false>
+// whole 256-byte pieces per 16-lane group.  (An inline-asm store is invisible to the compiler's hazard recogniser: a 128-bit
+// store needs a wait state before its data registers are written again -- the s_nop; without it a k_fp_tile trial of this
+// store lost data.)
+template <bool NT>
+__device__ __forceinline__ VecOf<4>::T st_xload(const VecOf<4>::T *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_xstore(VecOf<4>::T v, VecOf<4>::T *p)
+{
+    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+template <bool FUSED, bool COOP = false, bool NT = true>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
                                                            const float *__restrict__ r_prev, float beta,
@@ -896,7 +913,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     V xv[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
-        xv[J] = (y < n && z0 + J < n && !ST_WI(16)) ? ST_XLOAD(reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off)) : vzero<4>();
+        xv[J] = (y < n && z0 + J < n && !ST_WI(16)) ? st_xload<NT>(reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off)) : vzero<4>();
     uint2 eb[ST_SPG][ST_MAXB];
 #pragma unroll
     for (int q = 0; q < ST_SPG; ++q) {
@@ -956,7 +973,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             V nv = xv[J] + beta * upd;
             nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
             xv[J] = nv;
-            if (y < n && z0 + J < n && !ST_WI(1)) ST_XSTORE(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
+            if (y < n && z0 + J < n && !ST_WI(1)) st_xstore<NT>(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
         }
     }
     if (ST_WI(4)) {
@@ -1768,7 +1785,8 @@ inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
 //               k_tv_update.  One volume write per inner iteration instead of two, 8 instead of 12 bytes read.
 //   TVM_STORE   the round-1 form (g stored; k_tv_update applies it): kept for the A/B option and the other kernel forms.
 enum { TVM_STORE = 0, TVM_NORM = 1, TVM_UPDATE = 2 };
-struct TvUpd { float *x_out; const double *gnorm2; float dPOCS; int clamp; float *track; float *wrap_lo; float *wrap_hi; };
+struct TvUpd { float *x_out; const double *gnorm2; float dPOCS; int clamp; float *track; float *wrap_lo; float *wrap_hi;
+               int stream; };   // stream: non-temporal stores of x_new / the snapshot (slabs beyond the Infinity Cache: -3 %; thin slabs: +3 %)
 
 template <int TZ, bool WITH_TV, bool GRAD = true, int MODE = TVM_STORE>
 __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x, Halo h, float *__restrict__ g,
@@ -1905,16 +1923,18 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                         const size_t pix = (size_t)(y * n + z);
                         float v = __fsub_rn(c, __fdiv_rn(__fmul_rn(up.dPOCS, gv), nrm_));   // = k_tv_update's x - (dPOCS g)/||g||
                         if (up.clamp) v = fmaxf(v, 0.f);
-                        nt_st<4>(v, up.x_out + pix * sx + (unsigned)s);
+                        if (up.stream) __builtin_nontemporal_store(v, up.x_out + pix * sx + (unsigned)s);
+                        else up.x_out[pix * sx + (unsigned)s] = v;
                         if (up.wrap_lo) {
                             if (s == 0) up.wrap_hi[pix] = v;
                             if (s == nx - 1) up.wrap_lo[pix] = v;
                         }
                         if (up.track) {
                             float *tr = up.track + pix * sx;
-                            float d = v - nt_ld<4>(tr + (unsigned)s);
+                            float d = v - tr[(unsigned)s];
                             acc += (double)(d * d);
-                            nt_st<4>(v, tr + (unsigned)s);
+                            if (up.stream) __builtin_nontemporal_store(v, tr + (unsigned)s);
+                            else tr[(unsigned)s] = v;
                         }
                     }
                 }

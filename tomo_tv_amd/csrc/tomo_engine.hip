@@ -106,6 +106,7 @@ struct tomo_engine {
     // (64 slices: 37.0 vs 30.8 us, 5.25 vs 4.87 ms per step): the first workgroups cannot start their voxel update before
     // the rows exist, so the reduction is serial either way and only moves inside the launch.
     int sart_coop = 0, sart_coop_spin = 4096, st_resident = 0;
+    int sart_nt = -1;                              // tile accesses: -1 streaming form by slab size (slab_streams), 0 plain, 1 streaming
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
     bool fb_ok = false;
     uint4 *d_fb_cell = nullptr;
@@ -417,9 +418,10 @@ static int launch_sart_seg(tomo_engine *e, const float *x_old, float *x_new, int
 static int sart_tile_prepare(tomo_engine *e, bool coop)
 {
     if (!e->attr_st) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
-        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
-        HIPCHK(hipFuncSetAttribute((const void *)k_sart_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
+        const void *forms[] = {(const void *)k_sart_tile<true, false, true>, (const void *)k_sart_tile<true, false, false>,
+                               (const void *)k_sart_tile<false, false, true>, (const void *)k_sart_tile<false, false, false>,
+                               (const void *)k_sart_tile<true, true, true>, (const void *)k_sart_tile<true, true, false>};
+        for (const void *f : forms) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         e->attr_st = true;
     }
     const size_t pbytes = (size_t)std::max<uint32_t>(1, e->st_max_ids) * e->sx * sizeof(float);
@@ -435,10 +437,18 @@ static int sart_tile_prepare(tomo_engine *e, bool coop)
         int per_cu = 0;
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, e->device));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sart_tile<true, true>, ST_THREADS, ST_LDS_V * 16));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sart_tile<true, true, true>, ST_THREADS, ST_LDS_V * 16));
         e->st_resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
     }
     return TOMO_OK;
+}
+
+// A slab larger than the Infinity Cache is streamed (non-temporal tile accesses); a smaller one stays cached between the
+// launches of consecutive angles and keeps plain accesses (see st_xload / st_xstore).  "sart_nt": 0 never, 1 always, -1 by size.
+static bool slab_streams(const tomo_engine *e)
+{
+    if (e->sart_nt >= 0) return e->sart_nt != 0;
+    return (size_t)e->npix * e->sx * sizeof(float) >= ((size_t)192 << 20);
 }
 
 // residual rows of angle `next` from the tile partial sums in `partial` (k_resid_finish)
@@ -467,11 +477,14 @@ static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, i
     {
         ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE, sb.stream);
         dim3 grid((unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64)), block(ST_THREADS);
-        hipLaunchKernelGGL((k_sart_tile<FUSED>), grid, block, ST_LDS_V * 16, sb.stream, x, x,
-                           FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
-                           FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
-                           e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, partial,
-                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, StCoop{});
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, block, ST_LDS_V * 16, sb.stream, x, x,
+                               FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
+                               FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
+                               e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, partial,
+                               e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, StCoop{});
+        };
+        if (slab_streams(e)) go(k_sart_tile<FUSED, false, true>); else go(k_sart_tile<FUSED, false, false>);
         LAUNCHCHK();
     }
     return finish ? launch_resid_finish_tile(e, sb, partial, next, r) : TOMO_OK;
@@ -498,10 +511,13 @@ static int launch_sart_coop(tomo_engine *e, const Sub &sb, float *x, int prev, i
     co.nred = (int)std::min<unsigned>(nblocks, (unsigned)std::max(1, e->st_resident));
     co.nchunk_all = e->sxc / 64;
     co.spin = e->sart_coop_spin;
-    hipLaunchKernelGGL((k_sart_tile<true, true>), dim3(nblocks), dim3(ST_THREADS), ST_LDS_V * 16, sb.stream, x, x,
-                       e->d_st_cell + (size_t)prev * nt * ST_PIX, e->d_st_win + (size_t)prev * nt, r + (size_t)prev * e->n * e->sx, beta,
-                       e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, p_write,
-                       e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, co);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(ST_THREADS), ST_LDS_V * 16, sb.stream, x, x,
+                           e->d_st_cell + (size_t)prev * nt * ST_PIX, e->d_st_win + (size_t)prev * nt, r + (size_t)prev * e->n * e->sx, beta,
+                           e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, p_write,
+                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, co);
+    };
+    if (slab_streams(e)) go(k_sart_tile<true, true, true>); else go(k_sart_tile<true, true, false>);
     LAUNCHCHK();
     return TOMO_OK;
 }
@@ -1798,7 +1814,7 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
             wh = e->halo_hi == e->halo_hi_own ? e->halo_hi_alt : e->halo_hi_own;
         }
         Halo h{e->halo_lo, e->halo_hi};
-        TvUpd up{alt, e->d_scal + e->gnorm_slot, dPOCS, clamp, track, wl, wh};
+        TvUpd up{alt, e->d_scal + e->gnorm_slot, dPOCS, clamp, track, wl, wh, slab_streams(e) ? 1 : 0};
         {
             ProfScope ps(e, TOMO_K_TV_UPDATE);
             const int yseg = tv_rows_per_wave(e, e->tv_tz == 4 ? 4 : 8);
@@ -2034,6 +2050,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? 2 : 1; return TOMO_OK; }
+    if (std::strcmp(name, "sart_nt") == 0) { e->sart_nt = value < 0 ? -1 : (value ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "sart_coop") == 0) { e->sart_coop = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void k_linear(float *x, int npix, int sx)
 
 // B: workgroup = T x T pixel tile x (LPP*4) slices; LPP lanes per pixel; each thread owns PPT pixels.  XCD-aware: sibling
 // chunks of a tile consecutive on one XCD.  order=1: chunk-major instead
-template <int T, int LPP, int THREADS>
+// POL: 0 plain, 1 nt loads + nt stores, 2 nt loads + sc1 nt stores (inline asm), 3 plain loads + sc1 nt stores
+template <int T, int LPP, int THREADS, int POL = 0>
 __global__ __launch_bounds__(THREADS) void k_tile(float *x, int n, int sx, int tiles_z, int ntiles, int nchunk, int order)
 {
     constexpr int GROUPS = THREADS / LPP, PPT = T * T / GROUPS;
@@ -35,12 +36,17 @@ __global__ __launch_bounds__(THREADS) void k_tile(float *x, int n, int sx, int t
     for (int J = 0; J < PPT; ++J) {
         int lp = g * PPT + J;
         int y = ty * T + lp / T, z = tz * T + lp % T;
-        v[J] = *(const V *)(x + ((size_t)y * n + z) * sx + c * (LPP * 4) + gl * 4);
+        const V *p = (const V *)(x + ((size_t)y * n + z) * sx + c * (LPP * 4) + gl * 4);
+        v[J] = (POL == 1 || POL == 2) ? __builtin_nontemporal_load(p) : *p;
     }
     for (int J = 0; J < PPT; ++J) {
         int lp = g * PPT + J;
         int y = ty * T + lp / T, z = tz * T + lp % T;
-        *(V *)(x + ((size_t)y * n + z) * sx + c * (LPP * 4) + gl * 4) = v[J] + 1.0f;
+        V *p = (V *)(x + ((size_t)y * n + z) * sx + c * (LPP * 4) + gl * 4);
+        V w = v[J] + 1.0f;
+        if (POL == 1) __builtin_nontemporal_store(w, p);
+        else if (POL >= 2) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+        else *p = w;
     }
 }
 
@@ -60,6 +66,10 @@ int main(int argc, char **argv)
     };
     int npix = n * n;
     timeit("A linear 1 KiB/wave-instr", [&] { int waves = npix / 4 * (sx / 256); hipLaunchKernelGGL(k_linear, dim3((waves + 3) / 4), dim3(256), 0, 0, x, npix, sx); });
+    { int tz = n / 16, nt = tz * tz, nc = sx / 64;
+      timeit("B tile16x16 x 64 sl, 512 thr, nt ld + nt st", [&] { hipLaunchKernelGGL((k_tile<16, 16, 512, 1>), dim3(8 * ((nt + 7) / 8) * nc), dim3(512), 0, 0, x, n, sx, tz, nt, nc, 0); });
+      timeit("B tile16x16 x 64 sl, 512 thr, nt ld + sc1 nt st", [&] { hipLaunchKernelGGL((k_tile<16, 16, 512, 2>), dim3(8 * ((nt + 7) / 8) * nc), dim3(512), 0, 0, x, n, sx, tz, nt, nc, 0); });
+      timeit("B tile16x16 x 64 sl, 512 thr, plain ld + sc1 nt st", [&] { hipLaunchKernelGGL((k_tile<16, 16, 512, 3>), dim3(8 * ((nt + 7) / 8) * nc), dim3(512), 0, 0, x, n, sx, tz, nt, nc, 0); }); }
     for (int order = 0; order < 2; ++order) {
         char nm[96];
         { int tz = n / 16, nt = tz * tz, nc = sx / 64; snprintf(nm, 96, "B tile16x16 x 64 sl (256 B), 512 thr, order %d", order);
