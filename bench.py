@@ -524,7 +524,7 @@ def main():
     tile = not any(o.replace(" ", "") == "sart_tile=0" for o in args.opt)
     K_FUSED_NAME, K_FP_NAME = ("k_sart_tile<true>", "k_sart_tile<false>") if tile else ("k_sart_seg<4,8,true>", "k_sart_seg<4,8,false>")
     K_BP_NAME = "k_bp_angle<4,4,true>"   # the sweep's last back-projection, tracked form (also step norm + snapshot copy)
-    K_TVN_NAME, K_TVU_NAME = "k_tv_grad_reg<8,*,true,TVM_NORM>", "k_tv_grad_reg<8,false,true,TVM_UPDATE>"
+    K_TVN_NAME, K_TVU_NAME = "k_tv_march4<8,*,TVM_NORM>", "k_tv_march4<8,false,TVM_UPDATE>"
     log = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}) if on_gpu else None
     sync()
     t0 = time.perf_counter()

@@ -247,6 +247,8 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     instead of one k_resid_finish launch per angle (bit-identical; measured no faster);
  *                     "sart_coop_spin" (4096): polls before a workgroup forms its rows itself (< 0: always, for tests)
  *   "tv_yseg" (0):    rows a wave of the TV register march walks; 0 = 32, shortened on thin slabs until >= 8192 waves
+ *   "tv_march4" (1):  norm / update passes of tv_gd by k_tv_march4 (row slots renamed over a 4x unrolled loop, packed edge
+ *                     values: no register rotation; -10 % per inner iteration, bit-identical) instead of k_tv_grad_reg
  *   "fp_tile" (1):    all-angle forward projection from LDS-resident image tiles (k_fp_tile + k_fp_tile_reduce);
  *                     0 = ray-driven form selected by "fp_all_lpr"
  *   "fp_tile_scratch_mib" (8192): cap of the tile projector's partial-sum scratch; a larger volume is projected in

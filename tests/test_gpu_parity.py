@@ -704,18 +704,22 @@ def test_tile_forward_projection_in_chunk_passes(gpu, ncp):
 
 @pytest.mark.parametrize("N,Nx", [(40, 70), (64, 64), (33, 130), (100, 300), (7, 5), (3, 1)])
 def test_tv_gradient_kernels_are_bit_identical(gpu, N, Nx):
-    """Register march (k_tv_grad_reg, default), LDS march (k_tv_grad_lds) and the TV value they fold into the first pass:
-    the same arithmetic in the same order, so three descent steps leave the same bits; the direct-global stencil
-    (4 sqrt + 4 div per voxel) agrees to rounding."""
+    """Register march without row rotation (k_tv_march4, default), register march (k_tv_grad_reg), LDS march (k_tv_grad_lds)
+    and the TV value they fold into the first pass: the same arithmetic in the same order, so three descent steps leave the
+    same bits; the direct-global stencil (4 sqrt + 4 div per voxel) agrees to rounding."""
     x = np.random.default_rng(N + Nx).random((Nx, N, N), dtype=np.float32)
     out = {}
-    for opt in (1, 8, 0):
+    for opt in (1, "reg", 8, 0):
         t = tomoengine(Nx, N, np.array([10.0, 40.0]) * np.pi / 180)
-        t.set_option("tv_lds", opt)
+        if opt == "reg":
+            t.set_option("tv_march4", 0)
+        else:
+            t.set_option("tv_lds", opt)
         t.set_volume(x, VOL_RECON)
         tv = t.tv_gd(3, 0.05)
         out[opt] = (tv, t.get_volume(), t.tv())
     assert np.array_equal(out[1][1], out[8][1]) and out[1][0] == out[8][0] and out[1][2] == out[8][2]
+    assert np.array_equal(out[1][1], out["reg"][1]) and out[1][0] == out["reg"][0]
     assert np.abs(out[1][1] - out[0][1]).max() < 1e-6 and abs(out[1][0] - out[0][0]) <= 1e-6 * out[0][0]
 
 

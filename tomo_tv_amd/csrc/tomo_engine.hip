@@ -62,6 +62,7 @@ struct tomo_engine {
     // of "gradient pass (store g) + update pass": one volume write instead of two (HBM writes are the scarce resource)
     int tv_recompute = 1, tv_tz = 8;              // tv_tz: z-columns per wave of the register march (8 or 4)
     int tv_yseg = 0;                              // rows per wave of the register march; 0 = by slab size (tv_rows_per_wave)
+    int tv_march4 = 1;                            // norm / update passes by k_tv_march4 (no row rotation) instead of k_tv_grad_reg
     int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
     hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
     float tv_last_eps = 1e-6f;
@@ -1732,7 +1733,11 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
                 else hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
             } else {
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
-            if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
+            if (e->tv_march4) {
+                if (with_tv) hipLaunchKernelGGL((k_tv_march4<8, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
+                else hipLaunchKernelGGL((k_tv_march4<8, false, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
+            }
+            else if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
             else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
             }
         } else if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
@@ -1823,7 +1828,8 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
                 hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
             } else {
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
-            hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
+            if (e->tv_march4) hipLaunchKernelGGL((k_tv_march4<8, false, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
+            else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
             }
         }
         LAUNCHCHK();
@@ -2068,6 +2074,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         e->gnorm_slot = value; return TOMO_OK;
     }
     if (std::strcmp(name, "tv_tz") == 0) { e->tv_tz = value == 4 ? 4 : 8; return TOMO_OK; }
+    if (std::strcmp(name, "tv_march4") == 0) { e->tv_march4 = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_yseg") == 0) { e->tv_yseg = value < 0 ? 0 : value; return TOMO_OK; }
     if (std::strcmp(name, "tv_recompute") == 0) { e->tv_recompute = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_lds") == 0) { e->tv_lds = value; return TOMO_OK; }   // 1 register march, 8 / 16 LDS march (z-columns per workgroup), 0 direct
