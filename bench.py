@@ -150,13 +150,16 @@ class KernelLog:
     """The engine's HIP-event log of the named kernels.  A sub-slab group (tomoengine(..., sub_slabs=K)) logs per sub-slab
     engine; the launches of all of them are put on one time base (same device) and merged."""
 
-    def __init__(self, t, ids):
+    def __init__(self, t, ids, stride=None):
+        """stride: name -> N brackets every N-th launch of that kernel only (an event pair costs ~3 us of command-processor
+        time: with every launch of an ASD-POCS step bracketed the step is 0.7 ms = 3 % slower than unobserved)."""
         from tomo_tv_amd import _lib
         self._lib, self.ids = _lib, ids
+        self.stride = dict(stride or {})
         self.kids = list(getattr(t.be, "kids", [t.be]))
         for kid in self.kids:
-            for kid_id in ids.values():
-                _lib.check(kid.L.tomo_profile_enable(kid.h, kid_id, 1))
+            for name, kid_id in ids.items():
+                _lib.check(kid.L.tomo_profile_enable(kid.h, kid_id, max(1, int(self.stride.get(name, 1)))))
 
     def read(self):
         """name -> (launches, summed launch durations in ms, ms during which at least one launch was executing)."""
@@ -430,6 +433,7 @@ def main():
                     help="strong: ONE volume of --nslice slices sharded over the GPUs (BASELINE's metric); weak: --nslice per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline only: no secondary configs, no CPU baselines")
+    ap.add_argument("--no-kernel-log", action="store_true", help="experiment: time the steps without the per-launch HIP events (no roofline)")
     ap.add_argument("--force-dist", action="store_true", help="use the slab-sharded engine + its communicator even with one rank")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL); tests drive the launcher with gloo")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tomo_set_option), repeatable")
@@ -525,7 +529,10 @@ def main():
     K_FUSED_NAME, K_FP_NAME = ("k_sart_tile<true>", "k_sart_tile<false>") if tile else ("k_sart_seg<4,8,true>", "k_sart_seg<4,8,false>")
     K_BP_NAME = "k_bp_angle<4,4,true>"   # the sweep's last back-projection, tracked form (also step norm + snapshot copy)
     K_TVN_NAME, K_TVU_NAME = "k_tv_march4<8,*,TVM_NORM>", "k_tv_march4<8,false,TVM_UPDATE>"
-    log = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}) if on_gpu else None
+    # every 4th fused step (89 per sweep) and every 2nd TV pass (10 + 10 per step) are timed; the two single launches all
+    LOG_STRIDE = {K_FUSED_NAME: 4, K_TVN_NAME: 2, K_TVU_NAME: 2}
+    log = (KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}, LOG_STRIDE)
+           if on_gpu and not args.no_kernel_log else None)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -541,6 +548,19 @@ def main():
         asd_pocs_step(t, st)
         iso = log1.read()[K_FUSED_NAME]
         t.set_option("sart_streams", 2)
+    # Transparency: k_sart_tile stores only the 256-byte pieces whose bits changed (voxels held at zero by the positivity
+    # clamp, rays with a zero residual -- data-dependent).  The same step with every voxel stored, timed after the timed region:
+    el_all = None
+    if on_gpu and tile and not any(o.replace(" ", "").startswith("sart_skip_same=") for o in args.opt):
+        t.set_option("sart_skip_same", 0)
+        asd_pocs_step(t, st)
+        sync()
+        ta = time.perf_counter()
+        for _ in range(min(3, args.steps)):
+            asd_pocs_step(t, st)
+        sync()
+        el_all = (time.perf_counter() - ta) / min(3, args.steps)
+        t.set_option("sart_skip_same", 1)
     per_rank = None
     if comm is not None:
         tt = t.be.tensor([el])
@@ -571,11 +591,12 @@ def main():
             per = nsub if name in (K_BP_NAME, K_FUSED_NAME, K_FP_NAME) else max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)
             roofs[name] = roof(name, cnt, tot, alg_bytes[name] / per, busy_ms=busy)
             roofs[name]["sub_slabs"] = per
+            roofs[name]["sample_stride"] = LOG_STRIDE.get(name, 1)     # every N-th launch was timed: launches / total_ms count those
             # what an in-place read-modify-write pass over the slab reaches on this part in any access pattern
             # (tools/micro/copy_patterns.hip: 5.2-5.5 TB/s) -- informative, not the peak
             roofs[name]["frac_of_measured_rmw_ceiling"] = roofs[name]["achieved"] / RMW_CEILING_GBS
         attach_traffic(roofs, (nloc, n, nproj))
-        dominant = max(roofs.values(), key=lambda r: r["total_ms"]) if roofs else None
+        dominant = max(roofs.values(), key=lambda r: r["total_ms"] * r["sample_stride"]) if roofs else None
         if iso is not None and dominant is not None:
             r1 = roof(K_FUSED_NAME, iso[0], iso[1], alg_bytes[K_FUSED_NAME], busy_ms=iso[2])
             dominant = dict(dominant, isolated={k: r1[k] for k in ("achieved", "frac", "avg_ms", "launches", "algorithmic_bytes_per_launch")},
@@ -606,6 +627,10 @@ def main():
                        "sharding": f"tilt-axis slabs x{world} ({args.scaling} scaling)",
                        "sub_slabs_per_gpu": getattr(t, "sub_slabs", 1)},
             "final_dd": dd, "final_tv": tv,
+            "store_skipping": None if el_all is None else {
+                "ms_per_step_with_every_voxel_stored": el_all * 1e3,
+                "note": "k_sart_tile (in place) skips the store of 256-byte pieces whose bits did not change; bit-identical results; the "
+                        "gain depends on the data (zero background of the synthetic phantom); --opt sart_skip_same=0 times the other form"},
             "roofline": dominant,
             "roofline_bp_angle": roofs.get(K_BP_NAME),
             "roofline_fp_angle": roofs.get(K_FP_NAME),

@@ -240,6 +240,8 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     second chain enqueued by a second host thread (slices are independent; each stream fills the other's
  *                     launch gaps).  Measured: -2.4 % per sweep at 512 slices, +26 % at 1024 (the sub-slabs interleave inside
  *                     every pixel row), so the default is one chain on the engine's stream
+ *   "sart_skip_same" (1): k_sart_tile (in place) leaves out the store of a 256-byte piece (pixel x 64 slices) whose bits did
+ *                     not change (clamped zeros, zero residuals): same memory image, fewer HBM writes; gain depends on the data
  *   "sart_nt" (-1):   cache policy of k_sart_tile's voxel accesses: 1 = streamed (non-temporal loads, write-through
  *                     non-temporal stores: -9 % per sweep at 512^3), 0 = plain, -1 = streamed when the slab exceeds 192 MB
  *                     (a slab that fits the Infinity Cache is faster with plain accesses)
@@ -261,8 +263,10 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
 int tomo_set_option(tomo_engine *e, const char *name, int value);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------
- * While enabled, every launch of the named kernel is bracketed by HIP events on the engine's stream;
- * tomo_profile_read synchronises, returns launch count and summed device time, and resets the log. */
+ * While enabled, every launch of the named kernel is bracketed by HIP events on the engine's stream (on = N > 1: every N-th
+ * launch only -- an event pair costs about 3 us of command-processor time, 0.7 ms per ASD-POCS step when all ~210 launches of
+ * a step are bracketed); tomo_profile_read synchronises, returns the count and summed device time of the bracketed launches,
+ * and resets the log. */
 enum tomo_kernel_id { TOMO_K_BP_ANGLE = 0, TOMO_K_FP_ANGLE = 1, TOMO_K_TV_GRAD = 2, TOMO_K_TV_UPDATE = 3,
                       TOMO_K_FGP_OBJ = 4, TOMO_K_FGP_GRAD = 5 /* also the fused FGP iteration */, TOMO_K_SART_FUSED = 6,
                       TOMO_K_FP_TILE = 7, TOMO_K_BP_TILE = 8, TOMO_K_FP_REDUCE = 9 };

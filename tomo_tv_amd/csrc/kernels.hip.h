@@ -857,7 +857,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
                                                            const uint2 *__restrict__ segs, const uint32_t *__restrict__ segid,
                                                            const uint2 *__restrict__ ent, float *__restrict__ partial,
                                                            int n, int sx, int tiles_z, int ntiles, int nchunk, int chunk0,
-                                                           StCoop co)
+                                                           int skip_same, StCoop co)
 {
     typedef VecOf<4>::T V;
 #ifdef TOMO_WHATIF
@@ -970,10 +970,19 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             V num = w0 * a0;
             num += w1 * a1;
             V upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));
-            V nv = xv[J] + beta * upd;
+            const V ov = xv[J];
+            V nv = ov + beta * upd;
             nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
             xv[J] = nv;
-            if (y < n && z0 + J < n && !ST_WI(1)) st_xstore<NT>(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
+            // In place, a 256-byte piece (one pixel x 64 slices = one 16-lane group) whose bits did not change needs no store:
+            // voxels held at zero by the positivity clamp, pixels no ray of this angle crosses, rays with a zero residual.
+            bool wr = true;
+            if (skip_same) {
+                const bool mine = (__float_as_uint(nv[0]) != __float_as_uint(ov[0])) | (__float_as_uint(nv[1]) != __float_as_uint(ov[1])) |
+                                  (__float_as_uint(nv[2]) != __float_as_uint(ov[2])) | (__float_as_uint(nv[3]) != __float_as_uint(ov[3]));
+                wr = ((__ballot(mine) >> (t & 48)) & 0xFFFFull) != 0;
+            }
+            if (y < n && z0 + J < n && wr && !ST_WI(1)) st_xstore<NT>(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
         }
     }
     if (ST_WI(4)) {

@@ -36,6 +36,7 @@ enum { PROF_MAX_KERNELS = 12, PROF_MAX_EVENTS = 1 << 19 };   // 262144 launches 
 
 struct ProfSlot {
     bool on = false;
+    unsigned stride = 1, seen = 0;   // every stride-th launch is bracketed (an event pair costs ~3 us of command-processor time)
     std::vector<hipEvent_t> ev;  // pairs
     hipEvent_t ref = nullptr;    // recorded when the log is switched on: launches on different streams share this time base
     size_t used = 0, dropped = 0;   // dropped: launches that could not be recorded (tomo_profile_read reports them)
@@ -107,6 +108,7 @@ struct tomo_engine {
     // (64 slices: 37.0 vs 30.8 us, 5.25 vs 4.87 ms per step): the first workgroups cannot start their voxel update before
     // the rows exist, so the reduction is serial either way and only moves inside the launch.
     int sart_coop = 0, sart_coop_spin = 4096, st_resident = 0;
+    int sart_skip_same = 1;                        // k_sart_tile stores only the 256-byte pieces whose bits changed (in place)
     int sart_nt = -1;                              // tile accesses: -1 streaming form by slab size (slab_streams), 0 plain, 1 streaming
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
     bool fb_ok = false;
@@ -225,6 +227,7 @@ struct ProfScope {
         hipEvent_t start;
         {
             std::lock_guard<std::mutex> lk(e->prof_mu);       // two threads may log launches of one kernel
+            if (p.stride > 1 && (p.seen++ % p.stride) != 0) return;
             if (p.used + 2 > p.ev.size()) {
                 if (p.ev.size() >= PROF_MAX_EVENTS) { ++p.dropped; return; }
                 hipEvent_t a, b;
@@ -483,7 +486,7 @@ static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, i
                                FUSED ? e->d_st_cell + (size_t)prev * nt * ST_PIX : nullptr, FUSED ? e->d_st_win + (size_t)prev * nt : nullptr,
                                FUSED ? r + (size_t)prev * e->n * e->sx : nullptr, beta,
                                e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, partial,
-                               e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, StCoop{});
+                               e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, e->sart_skip_same, StCoop{});
         };
         if (slab_streams(e)) go(k_sart_tile<FUSED, false, true>); else go(k_sart_tile<FUSED, false, false>);
         LAUNCHCHK();
@@ -516,7 +519,7 @@ static int launch_sart_coop(tomo_engine *e, const Sub &sb, float *x, int prev, i
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(ST_THREADS), ST_LDS_V * 16, sb.stream, x, x,
                            e->d_st_cell + (size_t)prev * nt * ST_PIX, e->d_st_win + (size_t)prev * nt, r + (size_t)prev * e->n * e->sx, beta,
                            e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, p_write,
-                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, co);
+                           e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, e->sart_skip_same, co);
     };
     if (slab_streams(e)) go(k_sart_tile<true, true, true>); else go(k_sart_tile<true, true, false>);
     LAUNCHCHK();
@@ -2056,6 +2059,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? 2 : 1; return TOMO_OK; }
+    if (std::strcmp(name, "sart_skip_same") == 0) { e->sart_skip_same = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_nt") == 0) { e->sart_nt = value < 0 ? -1 : (value ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "sart_coop") == 0) { e->sart_coop = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
@@ -2088,6 +2092,8 @@ int tomo_profile_enable(tomo_engine *e, int kernel, int on)
     if (kernel < 0 || kernel >= PROF_MAX_KERNELS) return fail(TOMO_ERR_ARG, "bad kernel id");
     HIPCHK(hipStreamSynchronize(e->stream));
     e->prof[kernel].on = on != 0;
+    e->prof[kernel].stride = on > 1 ? (unsigned)on : 1u;     // on = N > 1: bracket every N-th launch only
+    e->prof[kernel].seen = 0;
     e->prof[kernel].used = 0;
     e->prof[kernel].dropped = 0;
     if (on) {
