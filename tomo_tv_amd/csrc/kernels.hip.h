@@ -529,11 +529,18 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
             V nv = xv[q] + beta * upd;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
-            nt_st<1>(nv, reinterpret_cast<V *>(x + (size_t)p * sx + off));
+            // in place: a pixel's 64*VEC-slice piece whose bits did not change is not stored (see k_sart_tile)
+            bool chx = false, cht = false;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                chx |= __float_as_uint(velem<VEC>(nv, i)) != __float_as_uint(velem<VEC>(xv[q], i));
+                if (TRACK) cht |= __float_as_uint(velem<VEC>(nv, i)) != __float_as_uint(velem<VEC>(tk[q], i));
+            }
+            if (__any(chx)) nt_st<1>(nv, reinterpret_cast<V *>(x + (size_t)p * sx + off));
             if (TRACK) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { float d = velem<VEC>(nv, i) - velem<VEC>(tk[q], i); local += (double)(d * d); }
-                nt_st<1>(nv, reinterpret_cast<V *>(track + (size_t)p * sx + off));
+                if (__any(cht)) nt_st<1>(nv, reinterpret_cast<V *>(track + (size_t)p * sx + off));
             }
         }
     }
