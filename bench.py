@@ -240,9 +240,18 @@ def attach_traffic(roofs, shape):
             continue
         if tuple(doc.get("shape", (512, 512, 90))) != tuple(shape):
             continue
+        def same_kernel(label, prof_name):
+            """bench label (k_name<a,b>: leading template arguments, * = any, TVM_NORM / TVM_UPDATE = 1 / 2) vs a profiler name"""
+            def split(nm):
+                nm = nm.split("::")[-1]
+                base, _, args = nm.partition("<")
+                return base.strip(), [a.strip() for a in args.rstrip(">").split(",")] if args else []
+            lb, la = split(label)
+            pb, pa = split(prof_name)
+            la = [{"TVM_NORM": "1", "TVM_UPDATE": "2"}.get(a, a) for a in la]
+            return lb == pb and len(la) <= len(pa) and all(a == "*" or a == b for a, b in zip(la, pa))
         for r in roofs.values():
-            key = r["kernel"].replace(",", ", ")
-            hit = [v for k, v in doc.get("kernels", {}).items() if key in k or r["kernel"] in k]
+            hit = [v for k, v in doc.get("kernels", {}).items() if same_kernel(r["kernel"], k)]
             if hit and r.get("traffic") is None:
                 r["traffic"] = hit[0]["hbm_bytes_per_launch"]
                 r["traffic_source"] = f"profiles/{fn} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
