@@ -1672,6 +1672,23 @@ __device__ __forceinline__ float tv_gval(float c, float xip, float xjp, float xk
     return gv;
 }
 
+// R = 1/sqrt(q) for the TV gradient: the hardware estimate v_rsq_f32 (1 ulp).  TV_RSQ_NEWTON adds one Newton step
+// (y (1.5 - 0.5 q y^2), 4 more instructions per voxel = 12 % of the march's vector work) -- round 1 carried it; the estimate
+// alone keeps every parity figure (the gradient is v * R with v a difference of voxels: its relative error stays ~1e-7).
+// One definition for every form of the march, so they stay bit-identical.
+#ifndef TV_RSQ_NEWTON
+#define TV_RSQ_NEWTON 0
+#endif
+__device__ __forceinline__ float tv_rsqrt(float q)
+{
+    float y = __frsqrt_rn(q);
+#if TV_RSQ_NEWTON
+    float e = __fmaf_rn(-__fmul_rn(q, y), __fmul_rn(0.5f, y), 0.5f);   // 0.5 - 0.5 q y^2
+    y = __fmaf_rn(y, e, y);
+#endif
+    return y;
+}
+
 constexpr int TVL_TZ = 8;          // z-columns per workgroup of the FGP kernel (2 per wave)
 constexpr int TVL_PITCH = 66;      // 64 slices + halo each side
 
@@ -1741,9 +1758,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_lds(const float *__restrict__ x
             // IEEE division costs 10 % of the whole pass.  D = q R is the TV integrand.
             // (explicit fma/mul intrinsics: the sequence must round identically in every instantiation of this kernel)
             float q_ = __fmaf_rn(d3, d3, __fmaf_rn(d2, d2, __fmaf_rn(d1, d1, eps)));
-            float y_ = __frsqrt_rn(q_);
-            float e_ = __fmaf_rn(-__fmul_rn(q_, y_), __fmul_rn(0.5f, y_), 0.5f);   // 0.5 - 0.5 q y^2
-            float rr_ = __fmaf_rn(y_, e_, y_);                                      // y (1.5 - 0.5 q y^2)
+            float rr_ = tv_rsqrt(q_);
             float D = __fmul_rn(q_, rr_);
             rinv[rslot][zi][si] = rr_;
             if (WITH_TV && own_plane && zi >= 1 && si >= 1 && z0 + zi - 1 < n && s0 + si - 1 < nx) tvacc += (double)D;
@@ -1894,9 +1909,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
         {                                                                                                 \
             float d1_ = (C) - (IP), d2_ = (C) - (JP), d3_ = (C) - (KP);                                   \
             float q_ = __fmaf_rn(d3_, d3_, __fmaf_rn(d2_, d2_, __fmaf_rn(d1_, d1_, eps)));                \
-            float y_ = __frsqrt_rn(q_);                                                                   \
-            float e_ = __fmaf_rn(-__fmul_rn(q_, y_), __fmul_rn(0.5f, y_), 0.5f);                          \
-            RR = __fmaf_rn(y_, e_, y_);                                                                   \
+            RR = tv_rsqrt(q_);                                                                            \
             DD = __fmul_rn(q_, RR);                                                                       \
         }
         auto shr = [&](float old, float v) {                    // lane l <- lane l-1 ; lane 0 keeps `old`
@@ -2057,9 +2070,7 @@ __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, 
         {                                                                                                 \
             float d1_ = (C) - (IP), d2_ = (C) - (JP), d3_ = (C) - (KP);                                   \
             float q_ = __fmaf_rn(d3_, d3_, __fmaf_rn(d2_, d2_, __fmaf_rn(d1_, d1_, eps)));                \
-            float y_ = __frsqrt_rn(q_);                                                                   \
-            float e_ = __fmaf_rn(-__fmul_rn(q_, y_), __fmul_rn(0.5f, y_), 0.5f);                          \
-            RR = __fmaf_rn(y_, e_, y_);                                                                   \
+            RR = tv_rsqrt(q_);                                                                            \
             DD = __fmul_rn(q_, RR);                                                                       \
         }
         auto shr = [&](float old, float v) {                    // lane l <- lane l-1 ; lane 0 keeps `old`
