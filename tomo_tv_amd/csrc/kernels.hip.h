@@ -2022,6 +2022,9 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 // Same arithmetic, operand order and rounding sequence as k_tv_grad_reg (bit-identical); gradient modes only.
 // 92-98 VGPRs (5 waves per SIMD; k_tv_grad_reg: 112-121, 4 waves).  Measured, same box: a TV-GD inner iteration 496 -> 446 us at
 // 512 slices, 86 -> 76 us at 64.  16 z-columns per wave (18 loaded for 16 outputs instead of 10 for 8; 150 VGPRs): 481-496 us.
+// Overlapping chunks (a wave loads 64 slices and owns the 62 in the middle, so every slice shift is a plain DPP: no packed edge
+// values, no readlane fix-ups, no phantom R; 71-78 VGPRs): fewer instructions but 475 against 429 us at 512 slices and 103 against
+// 76 at 64 -- the misaligned 248-byte rows and the extra chunk cost more than the ~20 % of vector instructions they save.
 template <int TZ, bool WITH_TV, int MODE>
 __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, Halo h, double *__restrict__ part, float eps,
                                                     int n, int nx, int sx, int yseg, double *__restrict__ part_tv, TvUpd up)
