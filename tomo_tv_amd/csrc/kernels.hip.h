@@ -1013,8 +1013,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             // voxels held at zero by the positivity clamp, pixels no ray of this angle crosses, rays with a zero residual.
             bool wr = true;
             if (skip_same) {
-                const bool mine = (__float_as_uint(nv[0]) != __float_as_uint(ov[0])) | (__float_as_uint(nv[1]) != __float_as_uint(ov[1])) |
-                                  (__float_as_uint(nv[2]) != __float_as_uint(ov[2])) | (__float_as_uint(nv[3]) != __float_as_uint(ov[3]));
+                const bool mine = ((__float_as_uint(nv[0]) ^ __float_as_uint(ov[0])) | (__float_as_uint(nv[1]) ^ __float_as_uint(ov[1])) |
+                                   (__float_as_uint(nv[2]) ^ __float_as_uint(ov[2])) | (__float_as_uint(nv[3]) ^ __float_as_uint(ov[3]))) != 0u;
                 wr = ((__ballot(mine) >> (t & 48)) & 0xFFFFull) != 0;
             }
             if (y < n && z0 + J < n && wr && !ST_WI(1)) st_xstore<NT>(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
