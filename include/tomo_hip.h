@@ -152,6 +152,12 @@ int tomo_sino_proj_max(tomo_engine *e, int sino, float *out_host);      /* multi
 int tomo_sino_proj_scale(tomo_engine *e, int sino, const float *div_host, const float *mul_host); /* b <- b/div[p]*mul[p] */
 int tomo_l1_norm(tomo_engine *e, int vol);                              /* :436 l1_norm -> TOMO_S_L1 */
 int tomo_read_scalars(tomo_engine *e, double *out, int count);          /* synchronises the stream */
+/* the same without a pipeline bubble: _snapshot enqueues the copy of all slots behind the kernels that produce them (and behind
+ * an evaluation in flight on the second stream) and returns; _read waits for that copy only.  The ASD-POCS drivers enqueue the
+ * next SART sweep in between (the scalars of iteration i decide nothing before the TV steps of iteration i+1:
+ * examples/sim_ASD.py:90-94). */
+int tomo_scalars_snapshot(tomo_engine *e);
+int tomo_scalars_snapshot_read(tomo_engine *e, double *out, int count);
 int tomo_bind_scalar_buffer(tomo_engine *e, void *device_doubles);      /* >= TOMO_S_COUNT doubles, e.g. a torch tensor */
 
 /* ---- 3-D total variation ---------------------------------------------------------------------------- */

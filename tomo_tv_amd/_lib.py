@@ -62,6 +62,8 @@ SIGNATURES = {
     "tomo_async_wait": [_p],
     "tomo_l1_norm": [_p, _i],
     "tomo_read_scalars": [_p, _p, _i],
+    "tomo_scalars_snapshot": [_p],
+    "tomo_scalars_snapshot_read": [_p, _p, _i],
     "tomo_bind_scalar_buffer": [_p, _p],
     "tomo_bind_halo": [_p, _p, _p],
     "tomo_halo_pack": [_p, _i, _i, _p],

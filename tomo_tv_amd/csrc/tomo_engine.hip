@@ -133,6 +133,9 @@ struct tomo_engine {
     size_t stage_bytes = 0;
     // scalars
     double *d_scal = nullptr, *d_scal_own = nullptr, *d_part = nullptr, *d_part_aux = nullptr, *d_part_tv = nullptr;
+    double *h_snap = nullptr;          // pinned: tomo_scalars_snapshot
+    hipEvent_t ev_snap = nullptr;
+    bool snap_pending = false;
     bool part_open[3] = {false, false, false};   // main / aux / tv partial sums: a reduction is in flight (see part_begin)
     hipStream_t aux = nullptr;                    // second stream for work that is independent of the main sequence
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -794,6 +797,8 @@ int tomo_destroy(tomo_engine *e)
     for (int u = 0; u < 2; ++u) if (e->sub_stream[u]) { (void)hipStreamSynchronize(e->sub_stream[u]); (void)hipStreamDestroy(e->sub_stream[u]); (void)hipEventDestroy(e->ev_sjoin[u]); }
     if (e->ev_sfork) (void)hipEventDestroy(e->ev_sfork);
     if (e->ev_peer) (void)hipEventDestroy(e->ev_peer);
+    if (e->ev_snap) (void)hipEventDestroy(e->ev_snap);
+    if (e->h_snap) (void)hipHostFree(e->h_snap);
     free_geometry(e);
     void *ptrs[] = {e->tv_alt, e->halo_lo_alt, e->halo_hi_alt, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_coef, e->sart_alt,
                     e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
@@ -1555,6 +1560,33 @@ int tomo_read_scalars(tomo_engine *e, double *out, int count)
     { int rc = tomo_async_wait(e); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(out, e->d_scal, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+// The scalars of an iteration without a pipeline bubble: the copy is enqueued behind the kernels that produce them, the host
+// goes on enqueueing (the next SART sweep) and collects the values later (tomo_scalars_snapshot_read waits on the event only).
+int tomo_scalars_snapshot(tomo_engine *e)
+{
+    NEED(e);
+    { int rc = tomo_async_wait(e); if (rc) return rc; }        // device-side ordering behind the second stream's evaluation
+    if (!e->h_snap) {
+        HIPCHK(hipHostMalloc((void **)&e->h_snap, TOMO_S_COUNT * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_snap, hipEventDisableTiming));
+    }
+    HIPCHK(hipMemcpyAsync(e->h_snap, e->d_scal, TOMO_S_COUNT * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(e->ev_snap, e->stream));
+    e->snap_pending = true;
+    return TOMO_OK;
+}
+
+int tomo_scalars_snapshot_read(tomo_engine *e, double *out, int count)
+{
+    NEED(e);
+    if (!out || count < 0 || count > TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar count");
+    if (!e->snap_pending) return fail(TOMO_ERR_STATE, "no scalar snapshot in flight");
+    HIPCHK(hipEventSynchronize(e->ev_snap));
+    std::memcpy(out, e->h_snap, count * sizeof(double));
+    e->snap_pending = false;
     return TOMO_OK;
 }
 

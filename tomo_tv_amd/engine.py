@@ -67,6 +67,15 @@ class _SlabBackend:
         self.c("read_scalars", _ptr(out), S_COUNT)
         return out
 
+    def scalars_snapshot(self):
+        """Enqueue the read-back of all scalar slots; ``scalars_snapshot_read`` collects it (no host wait in between)."""
+        self.c("scalars_snapshot")
+
+    def scalars_snapshot_read(self):
+        out = np.zeros(S_COUNT, np.float64)
+        self.c("scalars_snapshot_read", _ptr(out), S_COUNT)
+        return out
+
     # ---- torch plumbing for the distributed path (device tensors the collectives operate on) ----------
     def enable_torch(self):
         """Device tensors the collectives operate on, bound into the engine; the engine runs on torch's current stream
@@ -420,6 +429,36 @@ class _EngineBase:
         t = self.be.scalar_gather(slots)
         self.comm.allreduce_sum(t)
         return [float(v) for v in t.tolist()]
+
+    def _scalars_begin(self, slots):
+        """``_scalars`` in two halves: this one enqueues the all-reduce / read-back and returns a token at once, so the caller
+        can go on enqueueing work (the next SART sweep) before ``_scalars_end(token)`` waits for the values."""
+        slots = tuple(slots)
+        if self.comm is None:
+            if hasattr(self.be, "scalars_snapshot"):
+                self.be.scalars_snapshot()
+                return ("snapshot", slots)
+            return ("values", self._scalars(slots))              # sub-slab group: immediate
+        t = self.be.scalar_gather(slots)
+        self.comm.allreduce_sum(t)
+        if t.is_cuda:
+            import torch
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(t.device))
+            return ("torch", host, ev)
+        return ("values", [float(v) for v in t.tolist()])
+
+    def _scalars_end(self, token):
+        kind = token[0]
+        if kind == "snapshot":
+            v = self.be.scalars_snapshot_read()
+            return [float(v[k]) for k in token[1]]
+        if kind == "torch":
+            token[2].synchronize()
+            return [float(v) for v in token[1].tolist()]
+        return list(token[1])
 
     def _exchange(self, field, planes=None):
         """Ring exchange of the field's boundary planes (``planes``: already packed by the producing kernel)."""
@@ -829,19 +868,26 @@ class tomoengine(_EngineBase):
                   VOL_TEMP, S_DIFF2 if defer else S_DIFF)
         return None if defer else float(np.sqrt(self._scalar(S_DIFF)))
 
-    def tv_gd_tracked(self, ng, dPOCS, extra=()):
+    def tv_gd_tracked(self, ng, dPOCS, extra=(), defer=False):
         """``tv_gd(ng, dPOCS)`` followed by ``matrix_2norm()`` and ``copy_recon()`` in one call (the last descent step
         also forms the norm and refreshes the snapshot).  Returns (TV before descent, step norm) + the raw values of
         the ``extra`` scalar slots, all from ONE all-reduce / read-back (``S_DD`` waits for the asynchronous data
-        distance first)."""
+        distance first).  ``defer=True`` returns a zero-argument callable instead that delivers that tuple: the read-back
+        is enqueued, the caller may enqueue more work (the next iteration's SART sweep, which these values do not steer)
+        and call it afterwards -- no idle device between two iterations."""
         ng = int(ng)
         extra = tuple(extra)
+
+        def finish(v):
+            return (v[0], float(np.sqrt(v[1]))) + tuple(v[2:])
 
         def read():
             if S_DD in extra:
                 self.be.c("async_wait")
-            v = self._scalars((S_TV, S_DIFF) + extra)
-            return (v[0], float(np.sqrt(v[1]))) + tuple(v[2:])
+            if defer:
+                token = self._scalars_begin((S_TV, S_DIFF) + extra)
+                return lambda: finish(self._scalars_end(token))
+            return finish(self._scalars((S_TV, S_DIFF) + extra))
         if self.comm is None:
             self.be.c("tv_gd_tracked", ng, float(dPOCS), self.tv_eps, VOL_TEMP, S_DIFF)
             return read()
@@ -849,7 +895,8 @@ class tomoengine(_EngineBase):
             tv0 = self.tv_gd(ng, dPOCS)
             nrm = self.matrix_2norm()
             self.copy_recon()
-            return (tv0, nrm) + tuple(self._scalars(extra)) if extra else (tv0, nrm)
+            out = (tv0, nrm) + tuple(self._scalars(extra)) if extra else (tv0, nrm)
+            return (lambda: out) if defer else out
         planes = None
         for g in range(ng):
             self._exchange(VOL_RECON, planes)

@@ -129,29 +129,42 @@ class TomoGPU:
         dPOCS = 0.0
         norm = float(t.Nslice_ * t.Nrow) if normalize_dd else 1.0
         t.copy_recon()
+        pending = None              # (iteration, its SART step norm or None, the deferred read of its scalars)
+
+        def collect(dPOCS):
+            """The scalars of the iteration whose read-back is in flight, and the step-length rule they feed (sim_ASD.py:90-94)."""
+            j, dp, get = pending
+            if dp is None:
+                self.tv_vec[j], dg, dd2, dp2 = get()
+                dp = float(np.sqrt(dp2))
+            else:
+                self.tv_vec[j], dg, dd2 = get()
+            self.dd_vec[j] = float(np.sqrt(dd2)) / norm
+            if dg > dp * r_max and self.dd_vec[j] > eps:
+                dPOCS *= alpha_reduce
+            return dPOCS
         for i in range(Niter):
             # sim_ASD.py:68-78: copy_recon; SART; dp = matrix_2norm; copy_recon -- the step norm and the new snapshot
             # (TEMP) come out of the sweep's last back-projection pass; TEMP == recon holds on entry.  Only the first
             # iteration needs dp at once (it sets the TV step length); later ones leave it on the device until the
-            # iteration's scalars are read together: one all-reduce and one host synchronisation per iteration.
+            # iteration's scalars are read together: one all-reduce and one read-back per iteration -- and that read-back
+            # is collected only AFTER the next sweep has been enqueued (the scalars of iteration i steer nothing before the
+            # TV steps of iteration i+1), so the device never waits for the host between two iterations.
             if i == 0:
-                dp = t.SART_tracked(beta)
-                dPOCS = dp * alpha
+                dp0 = t.SART_tracked(beta)
+                dPOCS = dp0 * alpha
             else:
+                dp0 = None
                 t.SART_tracked(beta, defer=True)
+                dPOCS = collect(dPOCS)
             beta *= beta_reduce
             # the residual of the SART result is independent of the TV descent: evaluate it on the snapshot (TEMP)
             # on the engine's second stream while the TV steps run
             t.data_distance_begin()
             # sim_ASD.py:84-88: tv_gd; dg = matrix_2norm (and the copy_recon that opens the next iteration)
-            if i == 0:
-                self.tv_vec[i], dg, dd2 = t.tv_gd_tracked(nTViter, dPOCS, extra=(S_DD,))
-            else:
-                self.tv_vec[i], dg, dd2, dp2 = t.tv_gd_tracked(nTViter, dPOCS, extra=(S_DD, S_DIFF2))
-                dp = float(np.sqrt(dp2))
-            self.dd_vec[i] = float(np.sqrt(dd2)) / norm
-            if dg > dp * r_max and self.dd_vec[i] > eps:
-                dPOCS *= alpha_reduce
+            pending = (i, dp0, t.tv_gd_tracked(nTViter, dPOCS, extra=(S_DD,) if i == 0 else (S_DD, S_DIFF2), defer=True))
+        if pending is not None:
+            collect(dPOCS)
         return self.dd_vec, self.tv_vec
 
     def get_recon(self):
