@@ -193,6 +193,11 @@ int tomo_tv_update(tomo_engine *e, float dPOCS, int clamp);             /* ctvli
 /* the same step, also leaving the new first and last slice in two device planes (N*N floats each): what the ring
  * exchange of the slab-sharded descent sends before the next gradient pass, without a gather launch */
 int tomo_tv_update_planes(tomo_engine *e, float dPOCS, int clamp, void *first_plane, void *last_plane);
+/* one communication round per inner iteration instead of two (mpi_ctvlib.cpp:400-422 exchanges the slices, :455 reduces the
+ * norm): the norm pass also leaves the gradient's first / last slice in device buffers; they travel with the all-reduce of
+ * sum g^2, and every rank advances its halo planes itself (same expression as the update pass, same bits) */
+int tomo_tv_grad_planes(tomo_engine *e, float eps, int with_tv, void *g_first, void *g_last);
+int tomo_tv_halo_apply(tomo_engine *e, float dPOCS, int clamp, const void *g_lo, const void *g_hi);
 /* the same step, also ||recon_new - track_vol||^2 -> scalar `slot` and track_vol = recon_new (sim_ASD.py:86-88) */
 int tomo_tv_update_tracked(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot);
 int tomo_fgp_begin(tomo_engine *e);                                     /* tv_fgp.cu:216-227 */

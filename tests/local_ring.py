@@ -101,6 +101,11 @@ class RingComm:
         halo_hi.copy_(parts[self.next][0])
         self.ring.bar.wait()            # nobody overwrites its send planes before the neighbours have copied them
 
+    def allreduce_with_planes(self, t, first_planes, last_planes, recv_lo, recv_hi):
+        self.allreduce_sum(t)
+        self.exchange_planes(first_planes, last_planes, recv_lo, recv_hi)
+        return t
+
     def gather_slabs(self, local, counts, device=None, dst=None):
         parts = self._all(local)
         out = np.concatenate(parts, axis=0) if (dst is None or dst == self.rank) else None

@@ -96,6 +96,27 @@ class OracleSlabBackend:
     def halo_tensors(self):
         return self.halo_lo, self.halo_hi
 
+    # one-round TV descent (tomo_tv_grad_planes / tomo_tv_halo_apply)
+    def tv_grad_planes(self, eps, with_tv):
+        if with_tv:
+            self.c_tv_grad_tv(eps)
+        else:
+            self.c_tv_grad(eps)
+        return torch.from_numpy(self.g[0].ravel().copy()), torch.from_numpy(self.g[-1].ravel().copy())
+
+    def g_halo_tensors(self):
+        if not hasattr(self, "g_lo"):
+            self.g_lo, self.g_hi = self.new_plane(), self.new_plane()
+        return self.g_lo, self.g_hi
+
+    def tv_halo_apply(self, dPOCS, clamp):
+        nrm = np.float32(np.sqrt(float(self.scal[S_GNORM])))
+        for h, g in ((self.halo_lo, self.g_lo), (self.halo_hi, self.g_hi)):
+            v = h.numpy() - (np.float32(dPOCS) * g.numpy()) / nrm
+            if clamp:
+                np.maximum(v, 0, out=v)
+            h.copy_(torch.from_numpy(v.astype(np.float32)))
+
     def new_plane(self):
         return torch.zeros(self.nray * self.nray)
 

@@ -87,6 +87,31 @@ def test_sharded_tv_and_fgp_equal_whole_slab_and_oracle(gpu, world, nx, fused):
     assert rel_l2(got["fgp1"], ref.recon) < 1e-5
 
 
+@pytest.mark.parametrize("world,nx", [(2, 11), (3, 150)])
+def test_one_round_tv_descent_equals_two_rounds(gpu, world, nx):
+    """TV descent on slabs with ONE communication round per inner iteration (gradient planes travel with the all-reduce,
+    every rank advances its halo planes itself: tomo_tv_grad_planes / tomo_tv_halo_apply) against the two-round form
+    (slice exchange, then all-reduce): the halo planes are the neighbours' slices bit for bit, so are the volumes."""
+    n = 32
+    ang = np.deg2rad(np.linspace(-60, 60, 5))
+    x = noisy_phantom(nx, n, 5)
+
+    def script(one_round):
+        def run(t):
+            t.tv_one_round = one_round
+            t.tv_eps = 1e-6
+            tv0 = t.tv_gd(5, 0.3)
+            a = t.get_volume()
+            t.copy_recon()
+            tv1, dg = t.tv_gd_tracked(3, 0.2)
+            return tv0, a, tv1, dg, t.get_volume(), t.get_volume(VOL_TEMP)
+        return run
+    one = run_sharded(world, nx, n, ang, x, script(True))
+    two = run_sharded(world, nx, n, ang, x, script(False))
+    assert np.array_equal(one[1], two[1]) and np.array_equal(one[4], two[4]) and np.array_equal(one[5], two[5])
+    assert one[0] == two[0] and one[2] == two[2] and abs(one[3] - two[3]) <= 1e-12 * two[3]
+
+
 def asd_script(niter):
     """The loop of TomoGPU.asd_pocs with its batched scalar read (one all-reduce per iteration)."""
     def script(t):
@@ -106,8 +131,8 @@ def asd_script(niter):
             t.data_distance_begin()
             if i == 0:
                 tv, dg, dd2 = t.tv_gd_tracked(4, dPOCS, extra=(S_DD,))
-            else:
-                tv, dg, dd2, dp2 = t.tv_gd_tracked(4, dPOCS, extra=(S_DD, S_DIFF2))
+            else:       # the deferred form of the read-back (what TomoGPU.asd_pocs uses), collected at once here
+                tv, dg, dd2, dp2 = t.tv_gd_tracked(4, dPOCS, extra=(S_DD, S_DIFF2), defer=True)()
                 dp = float(np.sqrt(dp2))
             dd = float(np.sqrt(dd2)) / norm
             if dg > dp * 0.95 and dd > 0.0:

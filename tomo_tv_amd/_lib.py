@@ -95,6 +95,8 @@ SIGNATURES = {
     "tomo_sart_tracked": [_p, _i, _i, _f, _i, _p, _i, _i],
     "tomo_tv_update_tracked": [_p, _f, _i, _i, _i],
     "tomo_tv_update_planes": [_p, _f, _i, _p, _p],
+    "tomo_tv_grad_planes": [_p, _f, _i, _p, _p],
+    "tomo_tv_halo_apply": [_p, _f, _i, _p, _p],
     "tomo_tv_gd_tracked": [_p, _i, _f, _f, _i, _i],
     "tomo_poisson_residual": [_p, _i, _i, _i],
     "tomo_scale_volume": [_p, _i, _f],

@@ -1976,6 +1976,11 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                         acc += (double)(gv * gv);
                     } else if (MODE == TVM_NORM) {
                         acc += (double)(gv * gv);
+                        if (up.wrap_lo) {      // slab-sharded descent: the gradient's first / last slice for the neighbours
+                            const size_t pix = (size_t)(y * n + z);
+                            if (s == 0) up.wrap_hi[pix] = gv;
+                            if (s == nx - 1) up.wrap_lo[pix] = gv;
+                        }
                     } else {   // TVM_UPDATE: the expression of k_tv_update
                         const size_t pix = (size_t)(y * n + z);
                         float v = __fsub_rn(c, __fdiv_rn(__fmul_rn(up.dPOCS, gv), nrm_));   // = k_tv_update's x - (dPOCS g)/||g||
@@ -2113,6 +2118,11 @@ __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, 
                 if (z < n && s < nx) {
                     if (MODE == TVM_NORM) {
                         acc += (double)(gv * gv);
+                        if (up.wrap_lo) {      // slab-sharded descent: the gradient's first / last slice for the neighbours
+                            const size_t pix = (size_t)(y * n + z);
+                            if (s == 0) up.wrap_hi[pix] = gv;
+                            if (s == nx - 1) up.wrap_lo[pix] = gv;
+                        }
                     } else {   // TVM_UPDATE: the expression of k_tv_update
                         const size_t pix = (size_t)(y * n + z);
                         float v = __fsub_rn(c, __fdiv_rn(__fmul_rn(up.dPOCS, gv), nrm_));
@@ -2159,6 +2169,23 @@ __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, 
         __syncthreads();
         block_accumulate(tvacc, part_tv);
     }
+}
+
+// Slab-sharded TV descent with ONE communication round per inner iteration: a rank receives the gradient's boundary slices
+// of its neighbours (with the global sum g^2) and advances its halo planes itself -- the neighbour's update of those slices,
+// same expression, same bits -- instead of receiving the updated slices in a second round.
+__global__ __launch_bounds__(256) void k_halo_apply(float *__restrict__ halo_lo, float *__restrict__ halo_hi,
+                                                     const float *__restrict__ g_lo, const float *__restrict__ g_hi,
+                                                     const double *__restrict__ gnorm2, float dPOCS, int clamp, int npix)
+{
+    const float nrm = (float)sqrt(*gnorm2);
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    float a = __fsub_rn(halo_lo[p], __fdiv_rn(__fmul_rn(dPOCS, g_lo[p]), nrm));
+    float b = __fsub_rn(halo_hi[p], __fdiv_rn(__fmul_rn(dPOCS, g_hi[p]), nrm));
+    if (clamp) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+    halo_lo[p] = a;
+    halo_hi[p] = b;
 }
 
 // x -= dPOCS * g / ||g||   (ctvlib.cpp:452-458); gnorm2 = global sum g^2 on the device; optional clamp (:461)

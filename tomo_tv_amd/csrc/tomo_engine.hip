@@ -1744,7 +1744,7 @@ static int tv_rows_per_wave(const tomo_engine *e, int tz)
     return yseg;
 }
 
-static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
+static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv, float *g_first = nullptr, float *g_last = nullptr)
 {
     NEED(e);
     float *x, *g; int rc;
@@ -1752,6 +1752,7 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
     if ((rc = get_scratch(e, &e->tvg, &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     Halo h{e->halo_lo, e->halo_hi};
+    if ((g_first || g_last) && !(e->tv_lds == 1 && e->tv_recompute)) return fail(TOMO_ERR_STATE, "gradient planes need the recompute form of the TV march (tv_lds = 1, tv_recompute = 1)");
     if (with_tv && e->tv_lds != 8 && e->tv_lds != 1) with_tv = false;
     if (with_tv) {
         if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
@@ -1761,19 +1762,21 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv)
         ProfScope ps(e, TOMO_K_TV_GRAD);
         e->tv_last_eps = eps;
         if (e->tv_lds == 1 && e->tv_recompute) {   // sum g^2 (and TV) only: the update pass re-evaluates g (TVM_UPDATE)
+            TvUpd gp{};
+            gp.wrap_lo = g_last; gp.wrap_hi = g_first;      // g's last / first slice (slab-sharded descent), or null
             const int yseg = tv_rows_per_wave(e, e->tv_tz == 4 ? 4 : 8);
             if (e->tv_tz == 4) {
                 dim3 grid(tv_march_grid(e->n, 4, e->sxc / 64, (e->n + yseg - 1) / yseg));
-                if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<4, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
-                else hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
+                if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<4, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, gp);
+                else hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, gp);
             } else {
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
             if (e->tv_march4) {
-                if (with_tv) hipLaunchKernelGGL((k_tv_march4<8, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
-                else hipLaunchKernelGGL((k_tv_march4<8, false, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
+                if (with_tv) hipLaunchKernelGGL((k_tv_march4<8, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, gp);
+                else hipLaunchKernelGGL((k_tv_march4<8, false, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, gp);
             }
-            else if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
-            else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, TvUpd{});
+            else if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, gp);
+            else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, gp);
             }
         } else if (e->tv_lds == 1) {   // register march (k_tv_grad_reg): one wave per (z block, chunk, y segment)
             int yseg = 32;   // 8 .. 64 rows per wave measured the same; longer segments leave too few waves
@@ -1817,6 +1820,27 @@ int tomo_tv_grad_tv(tomo_engine *e, float eps)
         return rc ? rc : tv_grad_impl(e, eps, false);
     }
     return tv_grad_impl(e, eps, true);
+}
+
+// Slab-sharded descent, one communication round per inner iteration: the norm pass also leaves the gradient's first and last
+// slice in caller buffers (what the neighbours need to advance their halo planes themselves: tomo_tv_halo_apply).
+int tomo_tv_grad_planes(tomo_engine *e, float eps, int with_tv, void *g_first, void *g_last)
+{
+    if (!g_first || !g_last) return fail(TOMO_ERR_ARG, "null plane buffer");
+    return tv_grad_impl(e, eps, with_tv != 0, (float *)g_first, (float *)g_last);
+}
+
+// halo planes <- the neighbours' update of those slices: halo - (dPOCS g)/||g|| (clamped), with the received gradient planes
+// g_lo (the lower neighbour's last slice) and g_hi (the upper neighbour's first slice).  Call it AFTER the update pass (which
+// still reads the old planes).
+int tomo_tv_halo_apply(tomo_engine *e, float dPOCS, int clamp, const void *g_lo, const void *g_hi)
+{
+    NEED(e);
+    if (!g_lo || !g_hi) return fail(TOMO_ERR_ARG, "null plane buffer");
+    hipLaunchKernelGGL(k_halo_apply, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, e->halo_lo, e->halo_hi,
+                       (const float *)g_lo, (const float *)g_hi, e->d_scal + e->gnorm_slot, dPOCS, clamp, (int)e->npix);
+    LAUNCHCHK();
+    return TOMO_OK;
 }
 
 // wrap: also write the new last / first slice into the engine's halo planes (single slab, periodic); plane_last /

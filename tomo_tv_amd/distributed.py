@@ -94,6 +94,24 @@ class SlabComm:
         for req in d.batch_isend_irecv(ops):
             req.wait()
 
+    def allreduce_with_planes(self, t, first_planes, last_planes, recv_lo, recv_hi):
+        """One communication round: sum ``t`` over the ranks AND ring-exchange the planes (as ``exchange_planes``), issued
+        together so that the two do not wait for each other (TV descent: sum g^2 and the gradient's boundary slices)."""
+        d = self.dist
+        if self.world == 1 and not self.force:
+            recv_lo.copy_(last_planes)
+            recv_hi.copy_(first_planes)
+            return t
+        work = d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group, async_op=True)
+        nxt, prv = self.global_rank(self.next), self.global_rank(self.prev)
+        ops = [d.P2POp(d.isend, last_planes, nxt, self.group, 1), d.P2POp(d.isend, first_planes, prv, self.group, 2),
+               d.P2POp(d.irecv, recv_lo, prv, self.group, 1), d.P2POp(d.irecv, recv_hi, nxt, self.group, 2)]
+        reqs = d.batch_isend_irecv(ops)
+        work.wait()
+        for req in reqs:
+            req.wait()
+        return t
+
     def gather_slabs(self, local, counts, device=None, dst=None):
         """Concatenate the ranks' slabs along axis 0.  ``local``: this rank's (counts[rank], ...) float32 array.
         ``dst=None``: every rank returns the whole array (all_gather); ``dst=r``: only rank r does, the others

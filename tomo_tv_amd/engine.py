@@ -88,6 +88,7 @@ class _SlabBackend:
         npix = self.nray * self.nray
         z = lambda k=1: torch.zeros(k * npix, dtype=torch.float32, device=dev)  # noqa: E731
         self._halo_lo, self._halo_hi, self._send_lo, self._send_hi = z(), z(), z(), z()
+        self._g_lo, self._g_hi = z(), z()          # received gradient planes (one-round TV descent)
         # planes of the fused FGP iteration: lo = P1 below, hi = {A, P1, P2, P3} above, and what this slab sends
         self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last = z(), z(4), z(4), z()
         self.c("bind_scalar_buffer", ctypes.c_void_p(self._scal_t.data_ptr()))
@@ -118,6 +119,20 @@ class _SlabBackend:
 
     def halo_tensors(self):
         return self._halo_lo, self._halo_hi
+
+    def tv_grad_planes(self, eps, with_tv):
+        """Norm pass of a TV descent step that also leaves the gradient's first / last slice in the send planes."""
+        self.c("tv_grad_planes", float(eps), int(with_tv), ctypes.c_void_p(self._send_lo.data_ptr()),
+               ctypes.c_void_p(self._send_hi.data_ptr()))
+        return self._send_lo, self._send_hi
+
+    def g_halo_tensors(self):
+        return self._g_lo, self._g_hi
+
+    def tv_halo_apply(self, dPOCS, clamp):
+        """Advance the halo planes by the neighbours' update of those slices (received gradient planes, global norm)."""
+        self.c("tv_halo_apply", float(dPOCS), int(clamp), ctypes.c_void_p(self._g_lo.data_ptr()),
+               ctypes.c_void_p(self._g_hi.data_ptr()))
 
     def fgp_planes(self):
         """(send_first, send_last, lo, hi) of the fused FGP iteration."""
@@ -662,6 +677,9 @@ class _EngineBase:
             tv0 = self._tv_of(vol, self.tv_eps)
             self.be.c("positivity", vol)
             return tv0
+        if self.tv_one_round and hasattr(self.be, "tv_grad_planes"):
+            self._tv_descent_one_round(ng, dPOCS, vol, lambda: self.be.c("tv_update", float(dPOCS), 1))
+            return self._scalar(S_TV)
         planes = None
         for g in range(ng):
             self._exchange(vol, planes)
@@ -673,6 +691,25 @@ class _EngineBase:
             else:                                                     # the step packs the planes the next exchange sends
                 planes = self.be.tv_update_planes(dPOCS, 0)
         return self._scalar(S_TV)
+
+    tv_one_round = True   # sharded TV descent: one communication round per inner iteration (False: exchange + all-reduce)
+
+    def _tv_descent_one_round(self, ng, dPOCS, vol, last_update):
+        """``ng`` descent steps on a slab with ONE communication round each (the reference needs two: the slice exchange
+        mpi_ctvlib.cpp:400-422 and the norm's all-reduce :455).  The halo planes are exchanged once; after that every norm
+        pass also leaves the gradient's first / last slice, those planes travel together with the all-reduce of sum g^2,
+        and every rank advances its halo planes itself: halo - (dPOCS g)/||g|| is exactly the neighbour's update of that
+        slice (same expression, same operands, same bits)."""
+        self._exchange(vol)
+        g_lo, g_hi = self.be.g_halo_tensors()
+        for g in range(ng):
+            first, last = self.be.tv_grad_planes(self.tv_eps, g == 0)   # + the slab's share of sum g^2 (first pass: of TV)
+            self.comm.allreduce_with_planes(self.be.scalar_tensor(S_GNORM), first, last, g_lo, g_hi)
+            if g == ng - 1:
+                last_update()                                          # clamped; tracked form where the caller wants it
+            else:
+                self.be.c("tv_update", float(dPOCS), 0)                # reads the old halo planes ...
+                self.be.tv_halo_apply(dPOCS, 0)                        # ... which then follow the neighbours' slices
 
     fgp_fused = True   # sharded FGP: one fused kernel + one ring exchange per iteration (False: Obj / Grad pair, two)
 
@@ -897,6 +934,10 @@ class tomoengine(_EngineBase):
             self.copy_recon()
             out = (tv0, nrm) + tuple(self._scalars(extra)) if extra else (tv0, nrm)
             return (lambda: out) if defer else out
+        if self.tv_one_round and hasattr(self.be, "tv_grad_planes"):
+            self._tv_descent_one_round(ng, dPOCS, VOL_RECON,
+                                       lambda: self.be.c("tv_update_tracked", float(dPOCS), 1, VOL_TEMP, S_DIFF))
+            return read()
         planes = None
         for g in range(ng):
             self._exchange(VOL_RECON, planes)
