@@ -242,9 +242,14 @@ def roof(name, cnt, tot_ms, alg_bytes, flops=None, lds_bytes=None, busy_ms=None)
 def sart_sub_slabs(nloc, opts=()):
     """How many sub-slabs (streams) the engine runs a SART sweep of ``nloc`` slices on (tomo_engine.hip: sart_impl)."""
     sxc = (nloc + 63) // 64 * 64
-    vec = 4 if sxc % 256 == 0 else 2 if sxc % 128 == 0 else 1
-    on = any(o.replace(" ", "") == "sart_streams=2" for o in opts)        # the engine's default is one chain
-    return 2 if (sxc // (64 * vec) >= 2 and on) else 1
+    units = sxc // 64
+    mode = 0                                                              # the engine's default: automatic
+    for o in opts:
+        k, _, v = o.replace(" ", "").partition("=")
+        if k == "sart_streams":
+            mode = 2 if int(v) >= 2 else (1 if int(v) == 1 else 0)
+    two = mode == 2 or (mode == 0 and units % 2 == 0 and (sxc * 4) % 4096 != 0)
+    return 2 if (two and units >= 2) else 1
 
 
 def attach_traffic(roofs, shape):
@@ -558,7 +563,10 @@ def main():
     K_BP_NAME = "k_bp_angle<4,4,true>"   # the sweep's last back-projection, tracked form (also step norm + snapshot copy)
     K_TVN_NAME, K_TVU_NAME = "k_tv_march4<8,*,TVM_NORM>", "k_tv_march4<8,false,TVM_UPDATE>"
     # every 4th fused step (89 per sweep) and every 2nd TV pass (10 + 10 per step) are timed; the two single launches all
-    LOG_STRIDE = {K_FUSED_NAME: 4, K_TVN_NAME: 2, K_TVU_NAME: 2}
+    # (two sub-slab chains: every fused step is timed -- "achieved" is all launches' bytes over the time at least one of them was
+    # executing, which needs them all; the pairs cost less there because the other stream's kernel fills the gap: 0.2 ms per step)
+    two_chains = sart_sub_slabs(slab_partition(nglobal, world, rank)[1] if comm is not None else nglobal, args.opt) > 1
+    LOG_STRIDE = {K_FUSED_NAME: 1 if two_chains else 4, K_TVN_NAME: 2, K_TVU_NAME: 2}
     log = (KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}, LOG_STRIDE)
            if on_gpu and not args.no_kernel_log else None)
     sync()
@@ -576,7 +584,12 @@ def main():
         log1 = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED})
         asd_pocs_step(t, st)
         iso = log1.read()[K_FUSED_NAME]
-        t.set_option("sart_streams", 2)
+        mode = 0
+        for o in args.opt:
+            k, _, v = o.replace(" ", "").partition("=")
+            if k == "sart_streams":
+                mode = int(v)
+        t.set_option("sart_streams", mode)
     # Transparency: k_sart_tile stores only the 256-byte pieces whose bits changed (voxels held at zero by the positivity
     # clamp, rays with a zero residual -- data-dependent).  The same step with every voxel stored, timed after the timed region:
     el_all = None

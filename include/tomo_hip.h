@@ -247,10 +247,13 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     row-by-row steps (k_art, which still serves tomo_art_order with a permutation)
  *   "sart_tile" (1):  fused SART steps on image tiles streamed through LDS (k_sart_tile, in place) instead of the ray-walk
  *                     form (k_sart_seg); equal at 512 slices per GPU, 14-18 % faster on slabs of <= 128 slices
- *   "sart_streams" (1): 2 = the SART sweep of a slab of >= 2 x 64*vec slices runs as two sub-slabs on two streams, the
- *                     second chain enqueued by a second host thread (slices are independent; each stream fills the other's
- *                     launch gaps).  Measured: -2.4 % per sweep at 512 slices, +26 % at 1024 (the sub-slabs interleave inside
- *                     every pixel row), so the default is one chain on the engine's stream
+ *   "sart_streams" (0): the SART sweep of a slab as two sub-slabs (64-slice chunks, equal halves) on two streams, the second
+ *                     chain enqueued by a second host thread: slices are independent, each stream fills the other's launch
+ *                     boundaries and residual-row kernels.  2 = whenever the slab has two chunks, 1 = never, 0 = automatic:
+ *                     equal halves and not when a pixel's row of slices is a multiple of 4 KB (measured per ASD-POCS step:
+ *                     -2.6 / -3.3 / -5.5 / -5.3 % at 128 / 256 / 512 / 768 slices, +13 % at 1024).  A sub-slab runs its per-row
+ *                     kernels at the widest vector that fits its chunks; where that differs from the whole slab's the results
+ *                     differ by an ulp from the one-chain sweep
  *   "sart_skip_same" (1): k_sart_tile (in place) leaves out the store of a 256-byte piece (pixel x 64 slices) whose bits did
  *                     not change (clamped zeros, zero residuals): same memory image, fewer HBM writes; gain depends on the data
  *   "sart_nt" (-1):   cache policy of k_sart_tile's voxel accesses: 1 = streamed (non-temporal loads, write-through

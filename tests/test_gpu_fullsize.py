@@ -159,7 +159,8 @@ def test_fgp_fused_equals_two_kernel_form_at_full_size(tvbig):
 
 def test_sart_two_stream_sub_slabs_equal_one_chain(big):
     """"sart_streams" = 2 (two sub-slabs of the slab on two streams, second chain enqueued by a second host thread) changes
-    only the launch structure: every voxel and the tracked step norm are bit-identical to the single chain."""
+    only the launch structure: every voxel is bit-identical to the single chain where the sub-slabs run their per-row kernels
+    at the slab's vector width (512 slices: 256 + 256), and within an ulp where they cannot (128 slices: 64 + 64)."""
     t, x, (nx, n, p), ang = big
     res = {}
     for ns in (1, 2):
@@ -170,8 +171,12 @@ def test_sart_two_stream_sub_slabs_equal_one_chain(big):
         t.SART(0.6, 1)
         res[ns] = (dp, t.get_volume())
     t.set_option("sart_streams", 1)
-    assert res[1][0] == res[2][0] or abs(res[1][0] - res[2][0]) <= 1e-12 * res[1][0]   # fp64 partial sums, atomics in any order
-    assert np.array_equal(res[1][1], res[2][1])
+    # fp64 partial sums: atomics in any order, and a sub-slab may run its per-row kernels at another vector width
+    assert res[1][0] == res[2][0] or abs(res[1][0] - res[2][0]) <= 1e-10 * res[1][0]
+    if nx % 512 == 0:
+        assert np.array_equal(res[1][1], res[2][1])
+    else:
+        assert rel_l2(res[2][1], res[1][1]) < 1e-6           # 240 per-angle steps, an ulp each where the widths differ
 
 
 def test_config4_whole_volume_on_one_gpu(gpu):

@@ -86,10 +86,13 @@ struct tomo_engine {
     // idle chip after each and a tail of partly filled CUs at the end of each.  Slices are independent, so the sweep CAN run as
     // two sub-slabs on two streams, each filling the other's gaps ("sart_streams" = 2).  Measured (round 2, per sweep): two
     // separate 256-slice engines side by side 18.0 ms against 20.7 for one 512-slice engine -- but two sub-slabs of ONE slab
-    // interleave inside every pixel row (1 KB of every 2 KB) and reach only 19.4 ms at 512 slices and 51.3 against 40.6 ms
-    // at 1024: two kernels striding over alternate halves of the same rows collide in the memory system.  Default 1.
+    // interleave inside every pixel row (1 KB of every 2 KB) and reached only 19.4 ms at 512 slices and 51.3 against 40.6 ms
+    // at 1024: two kernels striding over alternate halves of the same rows collide in the memory system.  With the streamed tile
+    // accesses and the skipped stores of round 2 the gain at 512 slices grew to 5.5 % of the ASD-POCS step (23.4 -> 22.1 ms),
+    // so the default is now 0 = automatic (the rule is in sart_impl); the sub-slabs split at 64-slice chunks and run their
+    // per-row kernels at the widest vector that fits (which can differ from the whole slab's: results then differ by an ulp).
     // sub_c0 / sub_nc: the 64-slice chunk range the launch helpers address (0 / 0 = whole slab).
-    int sart_streams = 1, sub_c0 = 0, sub_nc = 0;
+    int sart_streams = 0, sub_c0 = 0, sub_nc = 0;
     hipStream_t sub_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_sfork = nullptr, ev_sjoin[2] = {nullptr, nullptr};
     int sart_tile = 1;                            // fused SART step on streamed image tiles (k_sart_tile) when the geometry allows it
@@ -218,19 +221,23 @@ static int ensure_stage(tomo_engine *e, size_t bytes)
 // stream.  Passed explicitly so that two host threads can enqueue the two sub-slab chains of a SART sweep side by side.
 struct Sub {
     hipStream_t stream; int c0 = 0, nc = 0;
+    int vec = 0;       // vector width of the per-row kernels on this sub-slab (0: the engine's); divides c0 and nc
 };
+static int sub_vec(const tomo_engine *e, const Sub &sb) { return sb.nc && sb.vec ? sb.vec : e->vec; }
 static Sub whole(const tomo_engine *e) { return Sub{e->stream, e->sub_c0, e->sub_nc}; }
 
 struct ProfScope {
     tomo_engine *e; int k; hipEvent_t stop = nullptr; hipStream_t st;
-    ProfScope(tomo_engine *e_, int k_, hipStream_t st_ = nullptr) : e(e_), k(k_), st(st_ ? st_ : e_->stream)
+    // key >= 0: the launch's position in its chain (the two sub-slab chains of a SART sweep then bracket the SAME links, so
+    // that the overlap of sibling launches can be seen); key < 0: every stride-th launch in arrival order
+    ProfScope(tomo_engine *e_, int k_, hipStream_t st_ = nullptr, int64_t key = -1) : e(e_), k(k_), st(st_ ? st_ : e_->stream)
     {
         ProfSlot &p = e->prof[k];
         if (!p.on) return;
         hipEvent_t start;
         {
             std::lock_guard<std::mutex> lk(e->prof_mu);       // two threads may log launches of one kernel
-            if (p.stride > 1 && (p.seen++ % p.stride) != 0) return;
+            if (p.stride > 1 && ((key >= 0 ? (uint64_t)key : (uint64_t)p.seen++) % p.stride) != 0) return;
             if (p.used + 2 > p.ev.size()) {
                 if (p.ev.size() >= PROF_MAX_EVENTS) { ++p.dropped; return; }
                 hipEvent_t a, b;
@@ -354,14 +361,15 @@ constexpr int BP_PPW = 4;
 static int launch_bp_angle(tomo_engine *e, const Sub &sb, float *x, int angle, const float *r_angle, float beta, float *track = nullptr)
 {
     ProfScope ps(e, TOMO_K_BP_ANGLE, sb.stream);
-    int nchunk = e->sxc / (64 * e->vec), chunk0 = 0;
-    if (sb.nc) { nchunk = sb.nc / e->vec; chunk0 = sb.c0 / e->vec; }   // sub-slab (whole multiples of 64*vec slices)
+    const int vec = sub_vec(e, sb);
+    int nchunk = e->sxc / (64 * vec), chunk0 = 0;
+    if (sb.nc) { nchunk = sb.nc / vec; chunk0 = sb.c0 / vec; }   // sub-slab (whole multiples of 64*vec slices)
     int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
     int64_t waves = (int64_t)ngroups * nchunk;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const CellD *cell = e->d_cell + (size_t)angle * e->npix;
     if (track) {   // caller brackets with reduce_begin / reduce_end
-        switch (e->vec) {
+        switch (vec) {
         case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, true>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part, chunk0); break;
         case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, true>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part, chunk0); break;
         default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, true>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, track, e->d_part, chunk0); break;
@@ -369,7 +377,7 @@ static int launch_bp_angle(tomo_engine *e, const Sub &sb, float *x, int angle, c
         LAUNCHCHK();
         return TOMO_OK;
     }
-    switch (e->vec) {
+    switch (vec) {
     case 4: hipLaunchKernelGGL((k_bp_angle<4, BP_PPW, false>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr, chunk0); break;
     case 2: hipLaunchKernelGGL((k_bp_angle<2, BP_PPW, false>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr, chunk0); break;
     default: hipLaunchKernelGGL((k_bp_angle<1, BP_PPW, false>), grid, block, 0, sb.stream, x, cell, r_angle, beta, (int)e->npix, e->sx, ngroups, nchunk, (float *)nullptr, (double *)nullptr, chunk0); break;
@@ -462,9 +470,10 @@ static bool slab_streams(const tomo_engine *e)
 static int launch_resid_finish_tile(tomo_engine *e, const Sub &sb, const float *partial, int next, float *r)
 {
     const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
-    int nchunk = nchunk64 / e->vec, chunk0 = c64 / e->vec;
+    const int vec = sub_vec(e, sb);
+    int nchunk = nchunk64 / vec, chunk0 = c64 / vec;
     dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
-    switch (e->vec) {
+    switch (vec) {
     case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
     case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
     default: hipLaunchKernelGGL((k_resid_finish<1>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
@@ -476,13 +485,13 @@ static int launch_resid_finish_tile(tomo_engine *e, const Sub &sb, const float *
 // finish = false leaves the partial sums of `next` in `partial` for the next link's reducer duty (cooperative chain)
 template <bool FUSED>
 static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, int next, float *r, float beta,
-                            float *partial = nullptr, bool finish = true)
+                            float *partial = nullptr, bool finish = true, int64_t key = -1)
 {
     const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
     const size_t nt = (size_t)e->st_ntiles;
     if (!partial) partial = e->st_partial;
     {
-        ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE, sb.stream);
+        ProfScope ps(e, FUSED ? TOMO_K_SART_FUSED : TOMO_K_FP_ANGLE, sb.stream, key);
         dim3 grid((unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64)), block(ST_THREADS);
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, grid, block, ST_LDS_V * 16, sb.stream, x, x,
@@ -499,11 +508,11 @@ static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, i
 
 // cooperative link: residual rows of `prev` from p_read (reducer duty of the first workgroups), BP(prev) + FP(next) -> p_write
 static int launch_sart_coop(tomo_engine *e, const Sub &sb, float *x, int prev, int next, float *r, float beta,
-                            const float *p_read, float *p_write, uint32_t epoch)
+                            const float *p_read, float *p_write, uint32_t epoch, int64_t key = -1)
 {
     const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
     const size_t nt = (size_t)e->st_ntiles;
-    ProfScope ps(e, TOMO_K_SART_FUSED, sb.stream);
+    ProfScope ps(e, TOMO_K_SART_FUSED, sb.stream, key);
     const unsigned nblocks = (unsigned)(8 * ((e->st_ntiles + 7) / 8) * nchunk64);
     StCoop co;
     co.p_read = p_read;
@@ -1104,7 +1113,7 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
                     if ((rc2 = launch_resid_finish_tile(e, sb, pk1, last, r))) return rc2;
                     return launch_bp_angle(e, sb, x, last, r + (size_t)last * e->n * e->sx, beta, track);
                 }
-                return launch_sart_coop(e, sb, x, angle_at(k - 1), angle_at(k), r, beta, pk1, pk, epoch0 + (uint32_t)k);
+                return launch_sart_coop(e, sb, x, angle_at(k - 1), angle_at(k), r, beta, pk1, pk, epoch0 + (uint32_t)k, k);
             }
             if (k == 0) return launch_sart_tile<false>(e, sb, x, 0, angle_at(0), r, beta);
             if (k == steps) { int last = angle_at(steps - 1); return launch_bp_angle(e, sb, x, last, r + (size_t)last * e->n * e->sx, beta, track); }
@@ -1113,7 +1122,7 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
                 if ((rc2 = launch_bp_angle(e, sb, x, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc2;
                 return launch_sart_tile<false>(e, sb, x, 0, next, r, beta);
             }
-            return launch_sart_tile<true>(e, sb, x, prev, next, r, beta);
+            return launch_sart_tile<true>(e, sb, x, prev, next, r, beta, nullptr, true, k);
         };
         auto chain = [&](const Sub &sb) -> int {
             for (int64_t k = 0; k <= steps; ++k) { int rc2 = link(k, sb); if (rc2) return rc2; }
@@ -1123,8 +1132,13 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
         // is then 2 x 180 launches of ~100 us kernels: one host thread cannot enqueue both chains fast enough to keep both
         // streams fed (measured: 19.4 ms per sweep against 19.9 on one stream), so the second chain is enqueued by a second
         // host thread (18.0 ms: what two independent engines on two Python threads reach).
-        const int units = e->sxc / (64 * e->vec);
-        if (e->sart_streams >= 2 && units >= 2) {
+        const int units = e->sxc / 64;                       // 64-slice chunks; a sub-slab's per-row kernels use the widest
+        auto vec_of = [](int c0, int nc) { return (c0 % 4 == 0 && nc % 4 == 0) ? 4 : (c0 % 2 == 0 && nc % 2 == 0) ? 2 : 1; };   // vector that fits
+        // "sart_streams": 2 = always (when the slab has two chunks), 1 = never, 0 = auto: equal halves, and not when a pixel's
+        // row of slices is a multiple of 4 KB -- the two halves of such rows land on the same memory channels (1024 slices:
+        // 48.5 against 42.9 ms per ASD-POCS step; 128 / 256 / 512 / 768 slices: -2.6 / -3.3 / -5.5 / -5.3 %).
+        const bool two = e->sart_streams >= 2 || (e->sart_streams == 0 && units % 2 == 0 && (e->sx * sizeof(float)) % 4096 != 0);
+        if (two && units >= 2) {
             if (!e->sub_stream[0]) {
                 for (int u = 0; u < 2; ++u) {
                     HIPCHK(hipStreamCreateWithFlags(&e->sub_stream[u], hipStreamNonBlocking));
@@ -1134,7 +1148,7 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
             }
             HIPCHK(hipEventRecord(e->ev_sfork, e->stream));
             const int u_lo = units / 2;
-            Sub sbs[2] = {Sub{e->sub_stream[0], 0, u_lo * e->vec}, Sub{e->sub_stream[1], u_lo * e->vec, (units - u_lo) * e->vec}};
+            Sub sbs[2] = {Sub{e->sub_stream[0], 0, u_lo, vec_of(0, u_lo)}, Sub{e->sub_stream[1], u_lo, units - u_lo, vec_of(u_lo, units - u_lo)}};
             for (int u = 0; u < 2; ++u) HIPCHK(hipStreamWaitEvent(e->sub_stream[u], e->ev_sfork, 0));
             int rcs[2] = {TOMO_OK, TOMO_OK};
             std::string err1;
@@ -2114,7 +2128,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
 #ifdef TOMO_WHATIF
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
-    if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? 2 : 1; return TOMO_OK; }
+    if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? 2 : (value == 1 ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "sart_skip_same") == 0) { e->sart_skip_same = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_nt") == 0) { e->sart_nt = value < 0 ? -1 : (value ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "sart_coop") == 0) { e->sart_coop = value ? 1 : 0; return TOMO_OK; }
