@@ -252,8 +252,7 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     boundaries and residual-row kernels.  2 = whenever the slab has two chunks, 1 = never, 0 = automatic:
  *                     equal halves and not when a pixel's row of slices is a multiple of 4 KB (measured per ASD-POCS step:
  *                     -2.6 / -3.3 / -5.5 / -5.3 % at 128 / 256 / 512 / 768 slices, +13 % at 1024).  A sub-slab runs its per-row
- *                     kernels at the widest vector that fits its chunks; where that differs from the whole slab's the results
- *                     differ by an ulp from the one-chain sweep
+ *                     kernels at the widest vector that fits its chunks; results are bit-identical to the one-chain sweep
  *   "sart_skip_same" (1): k_sart_tile (in place) leaves out the store of a 256-byte piece (pixel x 64 slices) whose bits did
  *                     not change (clamped zeros, zero residuals): same memory image, fewer HBM writes; gain depends on the data
  *   "sart_nt" (-1):   cache policy of k_sart_tile's voxel accesses: 1 = streamed (non-temporal loads, write-through

@@ -551,12 +551,16 @@ __global__ __launch_bounds__(256) void k_bp_angle(float *__restrict__ x, const C
         int p = p0 + q;
         if (p < npix) {
             float cs = c[q].w0 + c[q].w1;
-            V num = c[q].w0 * r0[q];
-            num += c[q].w1 * r1[q];
-            V upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));   // cs == 0 means w0 == w1 == 0, so num == 0; the formula of k_sart_tile
-            V nv = xv[q] + beta * upd;
+            const float inv = 1.0f / (cs > 0.f ? cs : 1.0f);   // cs == 0 means w0 == w1 == 0, so num == 0; the formula of k_sart_tile
+            // every rounding written out (mul, fma, mul, fma -- what the float4 code of k_sart_tile compiles to): the compiler's
+            // contraction choices differ between vector widths, and a sub-slab of a two-chain sweep may run at another width
+            V nv;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
+            for (int i = 0; i < VEC; ++i) {
+                float num = __fmaf_rn(c[q].w1, velem<VEC>(r1[q], i), __fmul_rn(c[q].w0, velem<VEC>(r0[q], i)));
+                float v = __fmaf_rn(beta, __fmul_rn(num, inv), velem<VEC>(xv[q], i));
+                vset<VEC>(nv, i, fmaxf(v, 0.f));
+            }
             // in place: a pixel's 64*VEC-slice piece whose bits did not change is not stored (see k_sart_tile)
             bool chx = false, cht = false;
 #pragma unroll

@@ -90,7 +90,7 @@ struct tomo_engine {
     // at 1024: two kernels striding over alternate halves of the same rows collide in the memory system.  With the streamed tile
     // accesses and the skipped stores of round 2 the gain at 512 slices grew to 5.5 % of the ASD-POCS step (23.4 -> 22.1 ms),
     // so the default is now 0 = automatic (the rule is in sart_impl); the sub-slabs split at 64-slice chunks and run their
-    // per-row kernels at the widest vector that fits (which can differ from the whole slab's: results then differ by an ulp).
+    // per-row kernels at the widest vector that fits (k_bp_angle writes its roundings out, so every width gives the same bits).
     // sub_c0 / sub_nc: the 64-slice chunk range the launch helpers address (0 / 0 = whole slab).
     int sart_streams = 0, sub_c0 = 0, sub_nc = 0;
     hipStream_t sub_stream[2] = {nullptr, nullptr};
