@@ -245,6 +245,9 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "fgp_fused" (1):  one fused kernel per FGP iteration (single slab)
  *   "art_chain" (1):  tomo_art in natural row order as per-angle FP + ray recurrence + BP (k_art_chain) instead of
  *                     row-by-row steps (k_art, which still serves tomo_art_order with a permutation)
+ *   "art_tile" (1):   the chained ART sweep as fused tile steps (BP of the previous angle + FP of the next in k_sart_tile's ART
+ *                     form, k_art_chain between them) instead of k_fp_rows + k_art_chain + k_bp_art per angle: 19.2 against
+ *                     26.0 ms per sweep at 512^3 x 90
  *   "sart_tile" (1):  fused SART steps on image tiles streamed through LDS (k_sart_tile, in place) instead of the ray-walk
  *                     form (k_sart_seg); equal at 512 slices per GPU, 14-18 % faster on slabs of <= 128 slices
  *   "sart_streams" (0): the SART sweep of a slab as two sub-slabs (64-slice chunks, equal halves) on two streams, the second

@@ -725,21 +725,25 @@ def test_tv_gradient_kernels_are_bit_identical(gpu, N, Nx):
 
 @pytest.mark.parametrize("N,P,Nx", [(48, 7, 70), (33, 5, 130), (16, 1, 3)])
 def test_chained_art_equals_row_sequential_art(gpu, N, P, Nx):
-    """tomo_art in natural order: per-angle FP + recurrence along the rays + BP (k_art_chain) against the row-by-row
-    kernel (k_art) and the oracle; two sweeps."""
+    """tomo_art in natural order: fused tile steps (BP_art(prev) + FP(next), k_sart_tile ART) with the recurrence along the
+    rays (k_art_chain) in between -- and its unfused form, per-angle FP + recurrence + BP -- against the row-by-row kernel
+    (k_art) and the oracle; two sweeps."""
     ang = np.linspace(-75, 72, P) if P > 1 else np.array([33.0])
     A = oracle.parallel_ray(N, ang)
     x = ellipsoids(Nx, N, seed=6)
     ref = oracle.ctvlib(Nx, N, P); ref.load_A(A); ref.original_volume = x.copy(); ref.create_projections()
     ref.row_inner_product()
     vols = {}
-    for chain in (1, 0):
+    for chain in (1, "rows", 0):
         dev = ctvlib(Nx, N, P); dev.load_A(A)
-        dev.set_option("art_chain", chain)
+        if chain == "rows":
+            dev.set_option("art_tile", 0)
+        else:
+            dev.set_option("art_chain", chain)
         dev.set_tilt_series(ref.b)
         dev.row_inner_product()
         dev.ART(0.8); dev.ART(0.8)
         vols[chain] = dev.get_volume()
     ref.ART(0.8); ref.ART(0.8)
-    assert rel_l2(vols[1], vols[0]) < 2e-6
-    assert rel_l2(vols[1], ref.recon) < 1e-5 and rel_l2(vols[0], ref.recon) < 1e-5
+    assert rel_l2(vols[1], vols[0]) < 2e-6 and rel_l2(vols["rows"], vols[0]) < 2e-6
+    assert rel_l2(vols[1], ref.recon) < 1e-5 and rel_l2(vols[0], ref.recon) < 1e-5 and rel_l2(vols["rows"], ref.recon) < 1e-5

@@ -671,7 +671,8 @@ __global__ __launch_bounds__(64) void k_sart_seg(const float *__restrict__ x_old
 // One workgroup per (row, chunk): its four waves each add a quarter of the list (the tile form leaves ~N/11 partials
 // per ray), the quarters are combined in fixed order through LDS.
 constexpr int RF_U = 12;
-template <int VEC>
+// SUM: r_out = the plain row sum (the forward projection itself; b and rowsum unused) -- the chained ART sweep
+template <int VEC, bool SUM = false>
 __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ partial,
                                                        const uint32_t *__restrict__ row_first,
                                                        const uint32_t *__restrict__ row_nseg,
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
     size_t o = (size_t)row * sx + off;
     V bv = vzero<VEC>();
     float rs = 0.f;
-    if (wave == 0) { bv = *reinterpret_cast<const V *>(b + o); rs = rowsum[row]; }
+    if (wave == 0 && !SUM) { bv = *reinterpret_cast<const V *>(b + o); rs = rowsum[row]; }
     uint32_t q = (ns + 3u) >> 2;
     uint32_t sb = min(wave * q, ns), se = min(sb + q, ns);
     V acc = vzero<VEC>();
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
     __syncthreads();
     if (wave != 0) return;
     acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
-    V r = rs > 0.f ? (bv - acc) / rs : vzero<VEC>();
+    V r = SUM ? acc : (rs > 0.f ? (bv - acc) / rs : vzero<VEC>());
     *reinterpret_cast<V *>(r_out + o) = r;
 }
 
@@ -889,7 +890,10 @@ __device__ __forceinline__ void st_xstore(VecOf<4>::T v, VecOf<4>::T *p)
     if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else *p = v;
 }
-template <bool FUSED, bool COOP = false, bool NT = true>
+// ART = true: the pending voxel update is the Kaczmarz one of k_bp_art (x += (w a) beta per ray in ascending ray order, no
+// normalisation, no clamp: ctvlib.cpp:137-155 keeps the clamp for the end of the sweep) -- the chained ART sweep then runs as
+// the same fused steps as SART, with k_art_chain in the place of the residual normalisation.
+template <bool FUSED, bool COOP = false, bool NT = true, bool ART = false>
 __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, float *x_new,
                                                            const uint4 *__restrict__ cells, const uint32_t *__restrict__ wins,
                                                            const float *__restrict__ r_prev, float beta,
@@ -1005,13 +1009,29 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
             uint4 ce = cel[g * 8 + J];
             V a0 = *reinterpret_cast<const V *>(wb + ce.x), a1 = *reinterpret_cast<const V *>(wb + ce.z);
             float w0 = __uint_as_float(ce.y), w1 = __uint_as_float(ce.w);
-            float cs = w0 + w1;
-            V num = w0 * a0;
-            num += w1 * a1;
-            V upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));
             const V ov = xv[J];
-            V nv = ov + beta * upd;
-            nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
+            V nv;
+            if constexpr (ART) {
+                // k_bp_art's expression: ascending ray order (window offsets order like ray indices), each term (w a) beta,
+                // zero weights skipped
+                uint32_t oa = ce.x, ob = ce.z;
+                if (w1 != 0.f && (w0 == 0.f || ob < oa)) { V tv = a0; a0 = a1; a1 = tv; float tw = w0; w0 = w1; w1 = tw; }
+                nv = ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = nv[i];
+                    if (w0 != 0.f) v = __fadd_rn(v, __fmul_rn(__fmul_rn(w0, a0[i]), beta));
+                    if (w1 != 0.f) v = __fadd_rn(v, __fmul_rn(__fmul_rn(w1, a1[i]), beta));
+                    nv[i] = v;
+                }
+            } else {
+                float cs = w0 + w1;
+                V num = w0 * a0;
+                num += w1 * a1;
+                V upd = num * (1.0f / (cs > 0.f ? cs : 1.0f));
+                nv = ov + beta * upd;
+                nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f);
+            }
             xv[J] = nv;
             // In place, a 256-byte piece (one pixel x 64 slices = one 16-lane group) whose bits did not change needs no store:
             // voxels held at zero by the positivity clamp, pixels no ray of this angle crosses, rays with a zero residual.
@@ -1309,9 +1329,10 @@ __global__ __launch_bounds__(64 * ART_CW) void k_art_chain(const float *__restri
 }
 
 template <int VEC, int PPW>
+// stream: non-temporal voxel accesses (slabs beyond the Infinity Cache, like k_sart_tile: the chained ART sweep 29.3 -> 26.0 ms)
 __global__ __launch_bounds__(256) void k_bp_art(float *__restrict__ x, const CellD *__restrict__ cell,
                                                  const float *__restrict__ a, float beta, int npix, int sx,
-                                                 int ngroups, int nchunk)
+                                                 int ngroups, int nchunk, int stream)
 {
     typedef typename VecOf<VEC>::T V;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1328,13 +1349,23 @@ __global__ __launch_bounds__(256) void k_bp_art(float *__restrict__ x, const Cel
         if (p >= npix) break;
         CellD c = cell[p];
         if (c.w0 == 0.f && c.w1 == 0.f) continue;
-        V xv = *reinterpret_cast<const V *>(x + (size_t)p * sx + off);
+        const V *xp = reinterpret_cast<const V *>(x + (size_t)p * sx + off);
+        V xv = stream ? __builtin_nontemporal_load(xp) : *xp;
         // ascending ray order, each term rounded like `val * a * beta`
         uint32_t ra = c.r0, rb = c.r1; float wa = c.w0, wb = c.w1;
         if (wb != 0.f && (wa == 0.f || rb < ra)) { uint32_t tr = ra; ra = rb; rb = tr; float tw = wa; wa = wb; wb = tw; }
-        if (wa != 0.f) xv += (wa * *reinterpret_cast<const V *>(a + (size_t)ra * sx + off)) * beta;
-        if (wb != 0.f) xv += (wb * *reinterpret_cast<const V *>(a + (size_t)rb * sx + off)) * beta;
-        *reinterpret_cast<V *>(x + (size_t)p * sx + off) = xv;
+        if (wa != 0.f) {
+            V av = *reinterpret_cast<const V *>(a + (size_t)ra * sx + off);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) vset<VEC>(xv, i, __fadd_rn(velem<VEC>(xv, i), __fmul_rn(__fmul_rn(wa, velem<VEC>(av, i)), beta)));
+        }
+        if (wb != 0.f) {
+            V bv = *reinterpret_cast<const V *>(a + (size_t)rb * sx + off);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) vset<VEC>(xv, i, __fadd_rn(velem<VEC>(xv, i), __fmul_rn(__fmul_rn(wb, velem<VEC>(bv, i)), beta)));
+        }
+        if (stream) __builtin_nontemporal_store(xv, reinterpret_cast<V *>(x + (size_t)p * sx + off));
+        else *reinterpret_cast<V *>(x + (size_t)p * sx + off) = xv;
     }
 }
 

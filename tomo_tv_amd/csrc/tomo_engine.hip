@@ -111,6 +111,7 @@ struct tomo_engine {
     // (64 slices: 37.0 vs 30.8 us, 5.25 vs 4.87 ms per step): the first workgroups cannot start their voxel update before
     // the rows exist, so the reduction is serial either way and only moves inside the launch.
     int sart_coop = 0, sart_coop_spin = 4096, st_resident = 0;
+    int art_tile = 1;                              // chained ART sweep as fused tile steps (k_sart_tile ART) instead of k_fp_rows + k_bp_art per angle
     int sart_skip_same = 1;                        // k_sart_tile stores only the 256-byte pieces whose bits changed (in place)
     int sart_nt = -1;                              // tile accesses: -1 streaming form by slab size (slab_streams), 0 plain, 1 streaming
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
@@ -435,7 +436,8 @@ static int sart_tile_prepare(tomo_engine *e, bool coop)
     if (!e->attr_st) {
         const void *forms[] = {(const void *)k_sart_tile<true, false, true>, (const void *)k_sart_tile<true, false, false>,
                                (const void *)k_sart_tile<false, false, true>, (const void *)k_sart_tile<false, false, false>,
-                               (const void *)k_sart_tile<true, true, true>, (const void *)k_sart_tile<true, true, false>};
+                               (const void *)k_sart_tile<true, true, true>, (const void *)k_sart_tile<true, true, false>,
+                               (const void *)k_sart_tile<true, false, true, true>, (const void *)k_sart_tile<true, false, false, true>};
         for (const void *f : forms) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_V * 16));
         e->attr_st = true;
     }
@@ -467,12 +469,21 @@ static bool slab_streams(const tomo_engine *e)
 }
 
 // residual rows of angle `next` from the tile partial sums in `partial` (k_resid_finish)
-static int launch_resid_finish_tile(tomo_engine *e, const Sub &sb, const float *partial, int next, float *r)
+static int launch_resid_finish_tile(tomo_engine *e, const Sub &sb, const float *partial, int next, float *r, bool sum = false)
 {
     const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
     const int vec = sub_vec(e, sb);
     int nchunk = nchunk64 / vec, chunk0 = c64 / vec;
     dim3 grid((unsigned)((int64_t)e->n * nchunk)), block(256);
+    if (sum) {      // plain row sums (chained ART: k_art_chain forms the residuals)
+        switch (vec) {
+        case 4: hipLaunchKernelGGL((k_resid_finish<4, true>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+        case 2: hipLaunchKernelGGL((k_resid_finish<2, true>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+        default: hipLaunchKernelGGL((k_resid_finish<1, true>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
+        }
+        LAUNCHCHK();
+        return TOMO_OK;
+    }
     switch (vec) {
     case 4: hipLaunchKernelGGL((k_resid_finish<4>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
     case 2: hipLaunchKernelGGL((k_resid_finish<2>), grid, block, 0, sb.stream, partial, e->d_st_row_first, e->d_st_row_nseg, e->cur_b, e->d_rowsum, r, next * e->n, e->n, nchunk, e->sx, chunk0); break;
@@ -483,9 +494,11 @@ static int launch_resid_finish_tile(tomo_engine *e, const Sub &sb, const float *
 }
 
 // finish = false leaves the partial sums of `next` in `partial` for the next link's reducer duty (cooperative chain)
-template <bool FUSED>
+// ART: the fused step of the chained ART sweep (r = the rows k_art_chain left for `prev`; the finish stores plain row sums into
+// fp_out, from which k_art_chain forms the rows of `next`)
+template <bool FUSED, bool ART = false>
 static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, int next, float *r, float beta,
-                            float *partial = nullptr, bool finish = true, int64_t key = -1)
+                            float *partial = nullptr, bool finish = true, int64_t key = -1, float *fp_out = nullptr)
 {
     const int nchunk64 = sb.nc ? sb.nc : e->sxc / 64, c64 = sb.nc ? sb.c0 : 0;
     const size_t nt = (size_t)e->st_ntiles;
@@ -500,9 +513,10 @@ static int launch_sart_tile(tomo_engine *e, const Sub &sb, float *x, int prev, i
                                e->d_st_seg + (size_t)next * nt * ST_MAXSEG, e->d_st_segid + (size_t)next * nt * ST_MAXSEG, e->d_st_ent, partial,
                                e->n, e->sx, e->st_tiles_z, e->st_ntiles, nchunk64, c64, e->sart_skip_same, StCoop{});
         };
-        if (slab_streams(e)) go(k_sart_tile<FUSED, false, true>); else go(k_sart_tile<FUSED, false, false>);
+        if (slab_streams(e)) go(k_sart_tile<FUSED, false, true, ART && FUSED>); else go(k_sart_tile<FUSED, false, false, ART && FUSED>);
         LAUNCHCHK();
     }
+    if (ART) return launch_resid_finish_tile(e, sb, partial, next, fp_out, true);
     return finish ? launch_resid_finish_tile(e, sb, partial, next, r) : TOMO_OK;
 }
 
@@ -1225,6 +1239,30 @@ int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
         int nchunk = e->sxc / (64 * e->vec);
         int ngroups = (int)((e->npix + BP_PPW - 1) / BP_PPW);
         dim3 bgrid((unsigned)(((int64_t)ngroups * nchunk + 3) / 4));
+        if (e->art_tile && e->sart_tile && e->st_ok && e->np >= 1) {
+            // the same fused steps as the SART sweep: FP(a0); [BP_art(a_k-1) + FP(a_k)] ...; BP_art(a_last), the residual rows of
+            // each angle formed by k_art_chain from the tile step's row sums.  Per angle 228 instead of 323 us at 512^3.
+            if ((rc = sart_tile_prepare(e, false))) return rc;
+            e->cur_b = const_cast<float *>(b);
+            const Sub sbw = whole(e);
+            for (int i = 0; i < e->np; ++i) {
+                if (i == 0) rc = launch_sart_tile<false, true>(e, sbw, x, 0, 0, a, beta, nullptr, true, -1, d);
+                else rc = launch_sart_tile<true, true>(e, sbw, x, i - 1, i, a, beta, nullptr, true, i, d);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_art_chain, dim3((unsigned)(e->sx / 64)), dim3(64 * ART_CW), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx);
+                LAUNCHCHK();
+            }
+            const int last = e->np - 1;
+            const CellD *cell = e->d_cell + (size_t)last * e->npix;
+            const float *ai = a + (size_t)last * e->n * e->sx;
+            switch (e->vec) {
+            case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
+            case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
+            default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
+            }
+            LAUNCHCHK();
+            return tomo_positivity(e, TOMO_VOL_RECON);
+        }
         for (int i = 0; i < e->np; ++i) {
             if ((rc = launch_fp<FP_STORE>(e, x, i * e->n, e->n, nullptr, d))) return rc;
             hipLaunchKernelGGL(k_art_chain, dim3((unsigned)(e->sx / 64)), dim3(64 * ART_CW), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx);
@@ -1232,9 +1270,9 @@ int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
             const CellD *cell = e->d_cell + (size_t)i * e->npix;
             const float *ai = a + (size_t)i * e->n * e->sx;
             switch (e->vec) {
-            case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
-            case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
-            default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk); break;
+            case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
+            case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
+            default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
             }
             LAUNCHCHK();
         }
@@ -2129,6 +2167,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? 2 : (value == 1 ? 1 : 0); return TOMO_OK; }
+    if (std::strcmp(name, "art_tile") == 0) { e->art_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_skip_same") == 0) { e->sart_skip_same = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_nt") == 0) { e->sart_nt = value < 0 ? -1 : (value ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "sart_coop") == 0) { e->sart_coop = value ? 1 : 0; return TOMO_OK; }
