@@ -1274,11 +1274,12 @@ constexpr int ART_CW = 16;
 
 __global__ __launch_bounds__(64 * ART_CW) void k_art_chain(const float *__restrict__ d, const float *__restrict__ b,
                                                             const float *__restrict__ inner, const float *__restrict__ cross,
-                                                            float *__restrict__ a_out, float beta, int row0, int nray, int sx)
+                                                            float *__restrict__ a_out, float beta, int row0, int nray, int sx,
+                                                            int chunk0)
 {
     __shared__ float su[ART_CW][64], sv[ART_CW][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = blockIdx.x * 64 + lane;                    // sx is a multiple of 64
+    const int s = (chunk0 + blockIdx.x) * 64 + lane;         // sx is a multiple of 64; chunk0: first chunk of a sub-slab
     const int L = (nray + ART_CW - 1) / ART_CW;
     const int j0 = min(wave * L, nray), j1 = min(j0 + L, nray);
     constexpr int U = 8;                                     // the loads of U rays are independent of the chain: issue them together
@@ -1332,7 +1333,7 @@ template <int VEC, int PPW>
 // stream: non-temporal voxel accesses (slabs beyond the Infinity Cache, like k_sart_tile: the chained ART sweep 29.3 -> 26.0 ms)
 __global__ __launch_bounds__(256) void k_bp_art(float *__restrict__ x, const CellD *__restrict__ cell,
                                                  const float *__restrict__ a, float beta, int npix, int sx,
-                                                 int ngroups, int nchunk, int stream)
+                                                 int ngroups, int nchunk, int stream, int chunk0)
 {
     typedef typename VecOf<VEC>::T V;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1342,7 +1343,7 @@ __global__ __launch_bounds__(256) void k_bp_art(float *__restrict__ x, const Cel
     int grp = gw - chunk * ngroups;
     int p0 = grp * PPW;
     if (p0 >= npix || chunk >= nchunk) return;   // grid is rounded up to whole workgroups
-    int off = chunk * (64 * VEC) + lane * VEC;
+    int off = (chunk0 + chunk) * (64 * VEC) + lane * VEC;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         int p = p0 + q;

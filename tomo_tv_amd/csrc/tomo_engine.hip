@@ -741,6 +741,49 @@ static int check_dims(int nslice, int nray, int nproj)
     return TOMO_OK;
 }
 
+// A sweep over a slab as one chain of launches on the engine's stream, or as two chains over two sub-slabs (64-slice chunks,
+// equal halves) on two streams: slices are independent, and each stream's short kernels and launch boundaries disappear under
+// the other stream's tile step.  A sweep is then 2 x ~180 launches of ~100 us kernels: one host thread cannot enqueue both chains
+// fast enough to keep both streams fed (measured: 19.4 ms per sweep against 19.9 on one stream), so the second chain is enqueued
+// by a second host thread (18.0 ms: what two independent engines on two Python threads reach).
+// "sart_streams": 2 = always (when the slab has two chunks), 1 = never, 0 = auto: equal halves, and not when a pixel's row of
+// slices is a multiple of 4 KB -- the two halves of such rows land on the same memory channels (1024 slices: 48.5 against 42.9 ms
+// per ASD-POCS step; 128 / 256 / 512 / 768 slices: -2.6 / -3.3 / -5.5 / -5.3 %).
+template <class Chain>
+static int run_chains(tomo_engine *e, const Chain &chain)
+{
+    const int units = e->sxc / 64;                       // 64-slice chunks; a sub-slab's per-row kernels use the widest vector that fits
+    auto vec_of = [](int c0, int nc) { return (c0 % 4 == 0 && nc % 4 == 0) ? 4 : (c0 % 2 == 0 && nc % 2 == 0) ? 2 : 1; };
+    const bool two = e->sart_streams >= 2 || (e->sart_streams == 0 && units % 2 == 0 && (e->sx * sizeof(float)) % 4096 != 0);
+    if (!(two && units >= 2)) return chain(whole(e));
+    if (!e->sub_stream[0]) {
+        for (int u = 0; u < 2; ++u) {
+            HIPCHK(hipStreamCreateWithFlags(&e->sub_stream[u], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_sjoin[u], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&e->ev_sfork, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(e->ev_sfork, e->stream));
+    const int u_lo = units / 2;
+    Sub sbs[2] = {Sub{e->sub_stream[0], 0, u_lo, vec_of(0, u_lo)}, Sub{e->sub_stream[1], u_lo, units - u_lo, vec_of(u_lo, units - u_lo)}};
+    for (int u = 0; u < 2; ++u) HIPCHK(hipStreamWaitEvent(e->sub_stream[u], e->ev_sfork, 0));
+    int rcs[2] = {TOMO_OK, TOMO_OK};
+    std::string err1;
+    const int dev = e->device;
+    std::thread second([&]() {
+        if (hipSetDevice(dev) != hipSuccess) { rcs[1] = TOMO_ERR_HIP; err1 = "hipSetDevice (second enqueue thread)"; return; }
+        rcs[1] = chain(sbs[1]);
+        if (rcs[1]) err1 = g_err;                       // the error text is thread-local
+    });
+    rcs[0] = chain(sbs[0]);
+    second.join();
+    if (rcs[1] && !rcs[0]) { rcs[0] = rcs[1]; g_err = err1; }
+    for (int u = 0; u < 2; ++u)
+        if (hipEventRecord(e->ev_sjoin[u], e->sub_stream[u]) != hipSuccess && !rcs[0]) rcs[0] = fail(TOMO_ERR_HIP, "hipEventRecord(sub-slab join)");
+    for (int u = 0; u < 2; ++u) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_sjoin[u], 0));
+    return rcs[0];
+}
+
 extern "C" {
 
 const char *tomo_last_error(void) { return g_err.c_str(); }
@@ -1142,46 +1185,7 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
             for (int64_t k = 0; k <= steps; ++k) { int rc2 = link(k, sb); if (rc2) return rc2; }
             return TOMO_OK;
         };
-        // Two sub-slabs on two streams when the slab splits into whole 64*vec-slice units (see sart_streams above).  A sweep
-        // is then 2 x 180 launches of ~100 us kernels: one host thread cannot enqueue both chains fast enough to keep both
-        // streams fed (measured: 19.4 ms per sweep against 19.9 on one stream), so the second chain is enqueued by a second
-        // host thread (18.0 ms: what two independent engines on two Python threads reach).
-        const int units = e->sxc / 64;                       // 64-slice chunks; a sub-slab's per-row kernels use the widest
-        auto vec_of = [](int c0, int nc) { return (c0 % 4 == 0 && nc % 4 == 0) ? 4 : (c0 % 2 == 0 && nc % 2 == 0) ? 2 : 1; };   // vector that fits
-        // "sart_streams": 2 = always (when the slab has two chunks), 1 = never, 0 = auto: equal halves, and not when a pixel's
-        // row of slices is a multiple of 4 KB -- the two halves of such rows land on the same memory channels (1024 slices:
-        // 48.5 against 42.9 ms per ASD-POCS step; 128 / 256 / 512 / 768 slices: -2.6 / -3.3 / -5.5 / -5.3 %).
-        const bool two = e->sart_streams >= 2 || (e->sart_streams == 0 && units % 2 == 0 && (e->sx * sizeof(float)) % 4096 != 0);
-        if (two && units >= 2) {
-            if (!e->sub_stream[0]) {
-                for (int u = 0; u < 2; ++u) {
-                    HIPCHK(hipStreamCreateWithFlags(&e->sub_stream[u], hipStreamNonBlocking));
-                    HIPCHK(hipEventCreateWithFlags(&e->ev_sjoin[u], hipEventDisableTiming));
-                }
-                HIPCHK(hipEventCreateWithFlags(&e->ev_sfork, hipEventDisableTiming));
-            }
-            HIPCHK(hipEventRecord(e->ev_sfork, e->stream));
-            const int u_lo = units / 2;
-            Sub sbs[2] = {Sub{e->sub_stream[0], 0, u_lo, vec_of(0, u_lo)}, Sub{e->sub_stream[1], u_lo, units - u_lo, vec_of(u_lo, units - u_lo)}};
-            for (int u = 0; u < 2; ++u) HIPCHK(hipStreamWaitEvent(e->sub_stream[u], e->ev_sfork, 0));
-            int rcs[2] = {TOMO_OK, TOMO_OK};
-            std::string err1;
-            const int dev = e->device;
-            std::thread second([&]() {
-                if (hipSetDevice(dev) != hipSuccess) { rcs[1] = TOMO_ERR_HIP; err1 = "hipSetDevice (second enqueue thread)"; return; }
-                rcs[1] = chain(sbs[1]);
-                if (rcs[1]) err1 = g_err;                       // the error text is thread-local
-            });
-            rcs[0] = chain(sbs[0]);
-            second.join();
-            if (rcs[1] && !rcs[0]) { rcs[0] = rcs[1]; g_err = err1; }
-            for (int u = 0; u < 2; ++u)
-                if (hipEventRecord(e->ev_sjoin[u], e->sub_stream[u]) != hipSuccess && !rcs[0]) rcs[0] = fail(TOMO_ERR_HIP, "hipEventRecord(sub-slab join)");
-            for (int u = 0; u < 2; ++u) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_sjoin[u], 0));
-            if (rcs[0]) return rcs[0];
-            return finish();
-        }
-        if ((rc = chain(whole(e)))) return rc;
+        if ((rc = run_chains(e, chain))) return rc;
         return finish();
     }
     float *alt;
@@ -1244,35 +1248,42 @@ int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
             // each angle formed by k_art_chain from the tile step's row sums.  Per angle 228 instead of 323 us at 512^3.
             if ((rc = sart_tile_prepare(e, false))) return rc;
             e->cur_b = const_cast<float *>(b);
-            const Sub sbw = whole(e);
-            for (int i = 0; i < e->np; ++i) {
-                if (i == 0) rc = launch_sart_tile<false, true>(e, sbw, x, 0, 0, a, beta, nullptr, true, -1, d);
-                else rc = launch_sart_tile<true, true>(e, sbw, x, i - 1, i, a, beta, nullptr, true, i, d);
-                if (rc) return rc;
-                hipLaunchKernelGGL(k_art_chain, dim3((unsigned)(e->sx / 64)), dim3(64 * ART_CW), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx);
+            const int np = e->np, strm = slab_streams(e) ? 1 : 0;
+            auto chain = [&](const Sub &sb) -> int {        // one sub-slab's (or the whole slab's) chain of launches
+                const int c64 = sb.nc ? sb.c0 : 0, nc64 = sb.nc ? sb.nc : e->sxc / 64;
+                for (int i = 0; i < np; ++i) {
+                    int rc2 = i == 0 ? launch_sart_tile<false, true>(e, sb, x, 0, 0, a, beta, nullptr, true, -1, d)
+                                     : launch_sart_tile<true, true>(e, sb, x, i - 1, i, a, beta, nullptr, true, i, d);
+                    if (rc2) return rc2;
+                    hipLaunchKernelGGL(k_art_chain, dim3((unsigned)nc64), dim3(64 * ART_CW), 0, sb.stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx, c64);
+                    LAUNCHCHK();
+                }
+                const int last = np - 1, vec = sub_vec(e, sb);
+                const CellD *cell = e->d_cell + (size_t)last * e->npix;
+                const float *ai = a + (size_t)last * e->n * e->sx;
+                const int nch = nc64 / vec, ch0 = c64 / vec;
+                dim3 grid((unsigned)(((int64_t)ngroups * nch + 3) / 4));
+                switch (vec) {
+                case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), grid, dim3(256), 0, sb.stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nch, strm, ch0); break;
+                case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), grid, dim3(256), 0, sb.stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nch, strm, ch0); break;
+                default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), grid, dim3(256), 0, sb.stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nch, strm, ch0); break;
+                }
                 LAUNCHCHK();
-            }
-            const int last = e->np - 1;
-            const CellD *cell = e->d_cell + (size_t)last * e->npix;
-            const float *ai = a + (size_t)last * e->n * e->sx;
-            switch (e->vec) {
-            case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
-            case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
-            default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
-            }
-            LAUNCHCHK();
+                return TOMO_OK;
+            };
+            if ((rc = run_chains(e, chain))) return rc;
             return tomo_positivity(e, TOMO_VOL_RECON);
         }
         for (int i = 0; i < e->np; ++i) {
             if ((rc = launch_fp<FP_STORE>(e, x, i * e->n, e->n, nullptr, d))) return rc;
-            hipLaunchKernelGGL(k_art_chain, dim3((unsigned)(e->sx / 64)), dim3(64 * ART_CW), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx);
+            hipLaunchKernelGGL(k_art_chain, dim3((unsigned)(e->sx / 64)), dim3(64 * ART_CW), 0, e->stream, d, b, e->d_rowinner, e->d_rowcross, a, beta, i * e->n, e->n, e->sx, 0);
             LAUNCHCHK();
             const CellD *cell = e->d_cell + (size_t)i * e->npix;
             const float *ai = a + (size_t)i * e->n * e->sx;
             switch (e->vec) {
-            case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
-            case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
-            default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0); break;
+            case 4: hipLaunchKernelGGL((k_bp_art<4, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0, 0); break;
+            case 2: hipLaunchKernelGGL((k_bp_art<2, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0, 0); break;
+            default: hipLaunchKernelGGL((k_bp_art<1, BP_PPW>), bgrid, dim3(256), 0, e->stream, x, cell, ai, beta, (int)e->npix, e->sx, ngroups, nchunk, slab_streams(e) ? 1 : 0, 0); break;
             }
             LAUNCHCHK();
         }
