@@ -1518,9 +1518,14 @@ __global__ __launch_bounds__(256) void k_slice_sumsq(const float *__restrict__ v
     const f4 *p = reinterpret_cast<const f4 *>(v) + s4;
     const int64_t pitch4 = sx / 4;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int64_t r = m0; r < m1; ++r) {
-        f4 a = p[r * pitch4];
-        a0 += (double)(a.x * a.x); a1 += (double)(a.y * a.y); a2 += (double)(a.z * a.z); a3 += (double)(a.w * a.w);
+    for (int64_t r = m0; r < m1; r += 8) {            // 8 independent loads per trip (one per trip left the pass latency-bound:
+        f4 a[8];                                      // 459 us for a 537 MB volume); added in row order as before
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = (r + u < m1) ? p[(r + u) * pitch4] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 += (double)(a[u].x * a[u].x); a1 += (double)(a[u].y * a[u].y); a2 += (double)(a[u].z * a[u].z); a3 += (double)(a[u].w * a[u].w);
+        }
     }
     atomicAdd(&sums[4 * s4], a0); atomicAdd(&sums[4 * s4 + 1], a1); atomicAdd(&sums[4 * s4 + 2], a2); atomicAdd(&sums[4 * s4 + 3], a3);
 }
