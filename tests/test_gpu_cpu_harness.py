@@ -140,7 +140,7 @@ def _asd_setup(golden, N, P, Nx, eps):
     return tomo, g, p
 
 
-# Measured on MI355X (tools/measure_asd_parity.py, table in DESIGN.md section 5).  The loop is chaotic: a normalised TV
+# Measured on MI355X (tests/measure_asd_parity.py, table in DESIGN.md section 5).  The loop is chaotic: a normalised TV
 # step of fixed length on a gradient made of v / sqrt(eps + ...) terms flips sign-like entries, so ANY rounding
 # difference is amplified once the iterate is piecewise flat.  The ORACLE ITSELF, fed a tilt series moved by one
 # float32 ulp, ends 20 iterations 1e-2 (eps = 1e-6) to 2e-2 (eps = 1e-8) away from its own unperturbed run -- and the

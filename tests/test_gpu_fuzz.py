@@ -15,7 +15,7 @@ TOL = 1e-5
 _rng = np.random.default_rng(20260101)
 CASES = [(int(_rng.integers(5, 49)), int(_rng.integers(1, 14)), int(_rng.integers(1, 200)), int(_rng.integers(0, 10 ** 6)))
          for _ in range(12)]
-# found by tools/fuzz_more.py: a one-tile image whose tables are small enough for an over-read to leave the allocation
+# found by tests/fuzz_more.py: a one-tile image whose tables are small enough for an over-read to leave the allocation
 CASES += [(4, 6, 170, 170069), (3, 5, 64, 1), (2, 3, 70, 5), (33, 9, 65, 3)]   # (a 2 x 2 x 1 volume makes the normalised TV step ill-conditioned: not used)
 
 
