@@ -723,6 +723,20 @@ def test_tv_gradient_kernels_are_bit_identical(gpu, N, Nx):
     assert np.abs(out[1][1] - out[0][1]).max() < 1e-6 and abs(out[1][0] - out[0][0]) <= 1e-6 * out[0][0]
 
 
+@pytest.mark.parametrize("N,Nx", [(40, 70), (64, 256)])
+def test_tv_march_segment_length_does_not_change_a_bit(gpu, N, Nx):
+    """"tv_yseg" (rows a wave of the TV march walks; chosen by slab size) only changes the work partition."""
+    x = np.random.default_rng(N * Nx).random((Nx, N, N), dtype=np.float32)
+    out = {}
+    for yseg in (0, 32, 8, 4):
+        t = tomoengine(Nx, N, np.array([10.0, 40.0]) * np.pi / 180)
+        t.set_option("tv_yseg", yseg)
+        t.set_volume(x, VOL_RECON)
+        t.tv_gd(3, 0.05)
+        out[yseg] = t.get_volume()
+    assert all(np.array_equal(out[0], v) for v in out.values())
+
+
 @pytest.mark.parametrize("N,P,Nx", [(48, 7, 70), (33, 5, 130), (16, 1, 3)])
 def test_chained_art_equals_row_sequential_art(gpu, N, P, Nx):
     """tomo_art in natural order: fused tile steps (BP_art(prev) + FP(next), k_sart_tile ART) with the recurrence along the

@@ -62,6 +62,26 @@ def test_skipping_unchanged_stores_is_bit_identical(gpu, ns, n, nproj):
     assert (ref == 0).mean() > 0.05           # the phantom has a background the clamp holds at zero: pieces are skipped
 
 
+@pytest.mark.parametrize("ns,n,nproj", [(64, 64, 9), (200, 48, 7)])
+def test_cache_policy_and_chain_count_do_not_change_a_bit(gpu, ns, n, nproj):
+    """The streamed form of the tile accesses ("sart_nt": non-temporal loads, write-through stores) and the number of
+    sub-slab chains ("sart_streams") only change how the same values travel."""
+    ref, _ = _sweep(ns, n, nproj, {"sart_nt": 0, "sart_streams": 1}, niter=2)
+    for opts in ({"sart_nt": 1, "sart_streams": 1}, {"sart_nt": 1, "sart_streams": 2}, {"sart_nt": 0, "sart_streams": 2}, {}):
+        got, _ = _sweep(ns, n, nproj, opts, niter=2)
+        assert ref.tobytes() == got.tobytes(), opts
+
+
+def test_scalar_snapshot_needs_a_snapshot(gpu):
+    """tomo_scalars_snapshot_read without a snapshot in flight is an error, not stale values."""
+    from tomo_tv_amd._lib import TomoError
+    t = tomoengine(8, 16, np.deg2rad(tilt_angles(3)))
+    with pytest.raises(TomoError):
+        t.be.scalars_snapshot_read()
+    t.be.scalars_snapshot()
+    assert t.be.scalars_snapshot_read().shape[0] >= 8
+
+
 def test_coop_needs_two_angles(gpu):
     """One tilt: consecutive links would read and write the same residual rows; the engine keeps the plain chain."""
     ref, _ = _sweep(64, 32, 1, {"sart_coop": 0}, niter=3)
