@@ -239,17 +239,18 @@ def roof(name, cnt, tot_ms, alg_bytes, flops=None, lds_bytes=None, busy_ms=None)
     return r
 
 
-def sart_sub_slabs(nloc, opts=()):
-    """How many sub-slabs (streams) the engine runs a SART sweep of ``nloc`` slices on (tomo_engine.hip: sart_impl)."""
-    sxc = (nloc + 63) // 64 * 64
-    units = sxc // 64
-    mode = 0                                                              # the engine's default: automatic
-    for o in opts:
-        k, _, v = o.replace(" ", "").partition("=")
-        if k == "sart_streams":
-            mode = 2 if int(v) >= 2 else (1 if int(v) == 1 else 0)
-    two = mode == 2 or (mode == 0 and units % 2 == 0 and (sxc * 4) % 4096 != 0)
-    return 2 if (two and units >= 2) else 1
+def sart_chains(t):
+    """Launch chains a SART sweep of this engine's slab runs as -- asked of the engine (tomo_sart_chain_count: the rule lives in
+    tomo_engine.hip: chain_count, under the options in force), not restated here.  A sub-slab group answers per sub-slab engine."""
+    import ctypes
+    kid = list(getattr(t.be, "kids", [t.be]))[0]
+    L = getattr(kid, "L", None)
+    if L is None or not hasattr(L, "tomo_sart_chain_count"):      # the numpy slab double of the launcher test
+        return 1
+    n = ctypes.c_int(0)
+    from tomo_tv_amd import _lib
+    _lib.check(L.tomo_sart_chain_count(kid.h, ctypes.byref(n)))
+    return int(n.value)
 
 
 def attach_traffic(roofs, shape):
@@ -319,7 +320,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     ms = _time_steps(t, lambda: (t.SART(1.0, 1), t.data_distance()), 5)
     cnt, tot, busy = log.read()["k_sart_tile<true>"]
     V = 256.0 ** 3
-    ns = sart_sub_slabs(256)
+    ns = sart_chains(t)
     out["config2_sart_256cube_x60tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
                                             "roofline": roof("k_sart_tile<true>", cnt, tot, (8 * V + 12 * 256 * 256) / ns, busy_ms=busy)}
     del t
@@ -395,7 +396,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     ms = _time_steps(t, lambda: asd_pocs_step(t, st4), 3, warmup=0)
     cnt, tot, busy = log.read()["k_sart_tile<true>"]
     V4 = 128.0 * 1024 * 1024
-    ns = sart_sub_slabs(128)
+    ns = sart_chains(t)
     out["config4_shard_asd_pocs_128x1024sq_x120tilts"] = {
         "ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V4 / ms / 1e6,
         "roofline": roof("k_sart_tile<true>", cnt, tot, (8 * V4 + 12 * 128 * 1024) / ns, busy_ms=busy)}
@@ -437,7 +438,9 @@ def _free_port():
 
 
 def spawn_ranks(n, argv):
-    """N fresh child processes (this parent never touches the GPU), rank 0's stdout passed through."""
+    """N fresh child processes (this parent never touches the GPU), rank 0's stdout passed through, every rank's stderr kept.
+    The children are polled: when one exits non-zero the others -- which would sit in a collective until the process group's
+    timeout -- are terminated at once and the launcher exits non-zero."""
     port = _free_port()
     procs = []
     for r in range(n):
@@ -448,9 +451,27 @@ def spawn_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    live = dict(enumerate(procs))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    while live:
+        for r, p in list(live.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del live[r]
+            if code != 0:
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                rc = max(rc, abs(code))
+                for q in live.values():
+                    q.terminate()
+                t_end = time.time() + 10
+                for q in live.values():
+                    try:
+                        q.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                return rc
+        time.sleep(0.05)
     return rc
 
 
@@ -532,7 +553,7 @@ def main():
     first, nloc = slab_partition(nglobal, world, rank) if comm is not None else (0, nglobal)
     # synthetic data: strong scaling -> this rank's slab of ONE seeded phantom; weak -> the same phantom on every rank
     if args.scaling == "strong":
-        vol = np.ascontiguousarray(ellipsoids(nglobal, n)[first:first + nloc])
+        vol = ellipsoids(nglobal, n, first=first, count=nloc)      # only this rank's slab is ever generated
     else:
         vol = ellipsoids(nloc, n)
     t.be.c("set_volume", VOL_ORIGINAL, vol.ctypes.data_as(ctypes.c_void_p))
@@ -565,7 +586,7 @@ def main():
     # every 4th fused step (89 per sweep) and every 2nd TV pass (10 + 10 per step) are timed; the two single launches all
     # (two sub-slab chains: every fused step is timed -- "achieved" is all launches' bytes over the time at least one of them was
     # executing, which needs them all; the pairs cost less there because the other stream's kernel fills the gap: 0.2 ms per step)
-    two_chains = sart_sub_slabs(slab_partition(nglobal, world, rank)[1] if comm is not None else nglobal, args.opt) > 1
+    two_chains = sart_chains(t) > 1
     LOG_STRIDE = {K_FUSED_NAME: 1 if two_chains else 4, K_TVN_NAME: 2, K_TVU_NAME: 2}
     log = (KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}, LOG_STRIDE)
            if on_gpu and not args.no_kernel_log else None)
@@ -578,7 +599,8 @@ def main():
     el = time.perf_counter() - t0
     prof = log.read() if log else {}
     iso = None
-    if on_gpu and getattr(t, "sub_slabs", 1) == 1 and sart_sub_slabs(slab_partition(nglobal, world, rank)[1] if comm is not None else nglobal, args.opt) > 1:
+    chains = sart_chains(t)          # launch chains per sweep of this rank's slab, as the engine runs them now
+    if on_gpu and getattr(t, "sub_slabs", 1) == 1 and chains > 1:
         # the dominant kernel alone on the chip (one chain, one stream), one untimed step: the kernel's own rate
         t.set_option("sart_streams", 1)
         log1 = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED})
@@ -628,11 +650,11 @@ def main():
         alg_bytes = {K_BP_NAME: 16.0 * V + 4.0 * nloc * n, K_FUSED_NAME: 8.0 * V + 12.0 * nloc * n,
                      K_FP_NAME: 4.0 * V + 8.0 * nloc * n, K_TVN_NAME: 4.0 * V, K_TVU_NAME: (9 * 8.0 + 16.0) / 10 * V}
         roofs = {}
-        nsub = sart_sub_slabs(nloc, args.opt) * max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)   # launches per angle
+        nsub = chains * max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)   # launches per angle
         for name, (cnt, tot, busy) in prof.items():
             per = nsub if name in (K_BP_NAME, K_FUSED_NAME, K_FP_NAME) else max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)
             roofs[name] = roof(name, cnt, tot, alg_bytes[name] / per, busy_ms=busy)
-            roofs[name]["sub_slabs"] = per
+            roofs[name]["launches_per_angle"] = per    # sweep chains x sub-slab engines: one launch covers 1/per of the slab
             roofs[name]["sample_stride"] = LOG_STRIDE.get(name, 1)     # every N-th launch was timed: launches / total_ms count those
             # what an in-place read-modify-write pass over the slab reaches on this part in any access pattern
             # (tools/micro/copy_patterns.hip: 5.2-5.5 TB/s) -- informative, not the peak
@@ -648,7 +670,7 @@ def main():
             dominant = dict(dominant, avg_ms_per_rank=per_rank)
         shape = f"{nglobal}x{n}x{n}"
         out = {
-            "metric": "SART+TV Gvoxel-updates/s (ASD-POCS outer iterations x voxels, 512^3 x 90 tilts, at 1/2/4/8 GPU)",
+            "metric": f"SART+TV Gvoxel-updates/s (ASD-POCS outer iterations x voxels, {shape} x {nproj} tilts, at 1/2/4/8 GPU)",
             "value": vox_total * args.steps / el / 1e9,
             "unit": "Gvoxel-updates/s",
             "n_gpus": world,
@@ -664,10 +686,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"ASD-POCS iteration (SART sweep beta0=0.25 + 10 TV-GD steps) on ONE {shape} volume, {nproj} tilts "
-                                   f"-70..70 deg (headline SART+TV 512^3x90 = BASELINE configs[2] shape), {nloc} slices on rank 0",
+                                   f"-70..70 deg" + (" (headline SART+TV 512^3x90 = BASELINE configs[2] shape)" if (nglobal, n, nproj) == (512, 512, 90) else "")
+                                   + f", {nloc} slices on rank 0",
                        "volume": shape, "slices_per_gpu": nloc, "nray": n, "nproj": nproj,
                        "sharding": f"tilt-axis slabs x{world} ({args.scaling} scaling)",
-                       "sub_slabs_per_gpu": getattr(t, "sub_slabs", 1)},
+                       "sub_slab_engines_per_gpu": getattr(t, "sub_slabs", 1), "sart_chains_per_engine": chains},
+            # the data-INDEPENDENT figure (k_sart_tile storing every voxel; the headline skips stores of unchanged 256-byte pieces,
+            # which the zero background of the synthetic phantom favours): null when the option was forced on the command line
+            "ms_per_step_every_voxel_stored": None if el_all is None else el_all * 1e3,
             "final_dd": dd, "final_tv": tv,
             "store_skipping": None if el_all is None else {
                 "ms_per_step_with_every_voxel_stored": el_all * 1e3,

@@ -277,6 +277,10 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "fp_all_lpr" (16): ray-driven all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks
  *                     (0 = wide form) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
+/* launch chains a SART / ART sweep of this engine's slab runs as under the current "sart_streams" (1 = one chain on the
+ * engine's stream; 2..4 = that many sub-slabs of 64-slice chunks on their own streams).  What the reference hides inside
+ * ASTRA's run(Nproj*nIter) (tomoengine.cpp:162-179); bench.py derives the bytes one launch moves from it. */
+int tomo_sart_chain_count(tomo_engine *e, int *count);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------
  * While enabled, every launch of the named kernel is bracketed by HIP events on the engine's stream (on = N > 1: every N-th

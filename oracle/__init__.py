@@ -87,6 +87,8 @@ def lib():
         L.orc_tv.argtypes = [i32, i32, i32, P, f32]
         L.orc_tv_gd.restype = f64
         L.orc_tv_gd.argtypes = [i32, i32, i32, P, P, i32, f32, f32]
+        L.orc_tv_gd_f64.restype = None
+        L.orc_tv_gd_f64.argtypes = [i32, i32, i32, P, P, P, i32, f64, f64]
         L.orc_tv_fgp.restype = f64
         L.orc_tv_fgp.argtypes = [i32, i32, i32, P, P, i32, f32]
         L.orc_fista_momentum.restype = None
@@ -338,6 +340,15 @@ class ctvlib:
         scratch = np.empty_like(self.recon)
         return float(lib().orc_tv_gd(self.Nslice_, self.Ny, self.Nz, _p(self.recon), _p(scratch), ng, dPOCS,
                                      self.tv_eps))
+
+    def tv_gd_f64(self, ng, dPOCS, start=None):
+        """``tv_gd`` from ``start`` (default: recon) evaluated in binary64 (orc_tv_gd_f64): the exact-arithmetic yardstick of
+        an ill-conditioned descent, returned as float32; ``recon`` is left alone."""
+        start = _f32(self.recon if start is None else start)
+        work = np.empty((2,) + start.shape, np.float64)
+        out = np.empty_like(start)
+        lib().orc_tv_gd_f64(self.Nslice_, self.Ny, self.Nz, _p(start), _p(work), _p(out), ng, float(dPOCS), float(self.tv_eps))
+        return out
 
     def tv_fgp(self, ng, lam):
         work = np.empty((4,) + self.recon.shape, np.float32)

@@ -562,6 +562,50 @@ double orc_tv_gd(int nx, int ny, int nz, float *vol, float *scratch, int ng, flo
 }
 #undef V
 
+/* tv_gd_3D (ctvlib.cpp:406-462) evaluated in binary64 from a float32 start: NOT the reference's arithmetic, but the
+ * yardstick for it.  Ten fixed-length steps along g/|g| are ill-conditioned (one ulp on the start moves the fp32 result by
+ * ~5e-5 at 512^3), so two fp32 implementations cannot be held to 1e-5 of each other there; what CAN be asked is that the
+ * HIP path is no further from this exact-arithmetic trajectory than the reference's own fp32 evaluation (orc_tv_gd) is.
+ * work: 2 volumes of doubles.  out: the result rounded to float32 once, after the clamp. */
+void orc_tv_gd_f64(int nx, int ny, int nz, const float *vol_in, double *work, float *out, int ng, double dPOCS, double eps)
+{
+    size_t n = (size_t)nx * ny * nz;
+    double *vol = work, *g = work + n;
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)n; i++) vol[i] = (double)vol_in[i];
+#define W(i, j, k) vol[((size_t)(i) * ny + (j)) * nz + (k)]
+#define DD(i, j, k, ip, jp, kp) sqrt(eps + (W(i, j, k) - W(ip, j, k)) * (W(i, j, k) - W(ip, j, k)) \
+                                         + (W(i, j, k) - W(i, jp, k)) * (W(i, j, k) - W(i, jp, k)) \
+                                         + (W(i, j, k) - W(i, j, kp)) * (W(i, j, k) - W(i, j, kp)))
+    for (int it = 0; it < ng; it++) {
+        double nrm = 0.0;
+#pragma omp parallel for reduction(+ : nrm)
+        for (int i = 0; i < nx; i++) {
+            int ip = (i + 1) % nx, im = (i - 1 + nx) % nx;
+            for (int j = 0; j < ny; j++) {
+                int jp = (j + 1) % ny, jm = (j - 1 + ny) % ny;
+                for (int k = 0; k < nz; k++) {
+                    int kp = (k + 1) % nz, km = (k - 1 + nz) % nz;
+                    double c = W(i, j, k);
+                    double gv = (3.0 * c - W(ip, j, k) - W(i, jp, k) - W(i, j, kp)) / DD(i, j, k, ip, jp, kp)
+                              + (c - W(im, j, k)) / DD(im, j, k, i, jp, kp)
+                              + (c - W(i, jm, k)) / DD(i, jm, k, ip, j, kp)
+                              + (c - W(i, j, km)) / DD(i, j, km, ip, jp, k);
+                    g[((size_t)i * ny + j) * nz + k] = gv;
+                    nrm += gv * gv;
+                }
+            }
+        }
+        double inv = dPOCS / sqrt(nrm);
+#pragma omp parallel for
+        for (int64_t i = 0; i < (int64_t)n; i++) vol[i] -= inv * g[i];
+    }
+#undef DD
+#undef W
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)n; i++) out[i] = (float)(vol[i] < 0.0 ? 0.0 : vol[i]);
+}
+
 /* ------------------------------------------------------------------------------------------
  * FGP-TV (tv_fgp.cu:192-281, methodTV = 0 isotropic, nonneg = 1).  Volume [N][M][Z].
  * Returns TV(input) with eps 1e-6 (tv_fgp.cu:170-189,231-238).

@@ -76,6 +76,19 @@ def test_system_matrix_digest_config1():
         assert hashlib.sha256(np.ascontiguousarray(A).tobytes()).hexdigest() == dig[key]["sha256"]
 
 
+@pytest.mark.parametrize("N,P", [(256, 60), (512, 90), (512, 70), (1024, 120)])
+def test_system_matrix_digest_baseline_geometries(N, P):
+    """The product's builder at the BASELINE.json geometries (configs 2, 3, 5, 4) against sha256 digests of the IMPORTED
+    reference's parallelRay output (tools/gen_golden.py --only-baseline-digests; cpu/utils/pytvlib.py:8-121): bit for bit."""
+    import hashlib
+    import json
+    from tomo_tv_amd.engine import system_matrix
+    d = json.load(open(os.path.join(GOLDEN, "A_digest.json")))[f"N{N}_P{P}_lin70"]
+    A = system_matrix(N, np.linspace(-70, 70, P))
+    assert A.shape[1] == d["nnz"]
+    assert hashlib.sha256(np.ascontiguousarray(A).tobytes()).hexdigest() == d["sha256"]
+
+
 def test_engine_creation_without_gpu_fails_loudly():
     """No CPU fallback anywhere: on a box without a HIP device the engine refuses to exist."""
     from tomo_tv_amd import _lib

@@ -572,6 +572,54 @@ def test_update_projection_angles_and_poisson_noise(gpu):
     assert np.array_equal(dev.get_projections(), b1)            # reproducible
 
 
+def test_failed_geometry_rebuild_leaves_the_engine_whole(gpu):
+    """update_proj_angles / update_projection_angles with a matrix the engine rejects must raise AND leave the
+    engine exactly as it was -- same geometry, same volumes, still usable (ctvlib.cpp:317-333 keeps recon across the swap)."""
+    N, Nx = 16, 3
+    a1, a2 = np.linspace(-60, 60, 5), np.linspace(-60, 60, 7)
+    x = ellipsoids(Nx, N, seed=2)
+    dev = ctvlib(Nx, N, 5)
+    dev.load_A(oracle.parallel_ray(N, a1))
+    dev.set_volume(x, VOL_ORIGINAL)
+    dev.create_projections()
+    dev.SIRT(0.01)
+    before, b = dev.get_volume(), dev.get_projections()
+    bad = oracle.parallel_ray(N, a2)
+    bad[1, 3] = N * N                                   # column index out of range
+    with pytest.raises(TomoError):
+        dev.update_proj_angles(bad, 7)
+    assert (dev.Nproj, dev.Nrow) == (5, 5 * N)
+    assert np.array_equal(dev.get_volume(), before) and np.array_equal(dev.get_projections(), b)
+    dev.SIRT(0.01)                                      # still a working engine on the old geometry
+    ref = oracle.ctvlib(Nx, N, 5)
+    ref.load_A(oracle.parallel_ray(N, a1))
+    ref.set_tilt_series(b)
+    ref.recon[:] = before
+    ref.SIRT(0.01)
+    assert rel_l2(dev.get_volume(), ref.recon) < TOL
+    dev.update_proj_angles(oracle.parallel_ray(N, a2), 7)      # and a good matrix still goes in
+    assert dev.Nproj == 7 and np.array_equal(dev.get_volume(), dev.get_volume())
+
+
+def test_rebuilding_the_stream_owner_of_a_multimodal_pair(gpu):
+    """the HAADF engine of `multimodal` runs on the chemical engine's stream; rebuilding the chemical engine's
+    geometry must hand the HAADF engine the new stream before the old one is destroyed."""
+    from tomo_tv_amd.chemistry import multimodal
+    N, Nx = 16, 4
+    mm = multimodal(Nx, N, 1, np.deg2rad(np.linspace(-60, 60, 5)), np.deg2rad(np.linspace(-50, 50, 4)))
+    x = ellipsoids(Nx, N, seed=4)
+    mm.he.set_volume(x, VOL_ORIGINAL)
+    mm.he.create_projections()
+    want = mm.he.get_projections()
+    mm.ce.update_projection_angles(np.deg2rad(np.linspace(-50, 50, 6)))
+    mm.he.create_projections()                          # would run on a destroyed stream without the hand-over
+    mm.he.synchronize()
+    assert np.array_equal(mm.he.get_projections(), want)
+    mm.he.update_projection_angles(np.deg2rad(np.linspace(-60, 60, 7)))
+    mm.he.create_projections()
+    assert mm.he.get_projections().shape == (Nx, 7 * N)
+
+
 @pytest.mark.parametrize("N,P,Nx", [(40, 7, 70), (96, 13, 128), (33, 5, 256)])
 def test_tile_projectors_match_row_and_pixel_driven_forms(gpu, N, P, Nx):
     """k_fp_tile/k_fp_tile_reduce and k_bp_tile against the ray-driven FP and the pixel-driven BP they replace:

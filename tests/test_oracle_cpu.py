@@ -24,6 +24,15 @@ def test_parallel_ray_digests():
     assert hashlib.sha256(A.tobytes()).hexdigest() == dig["N128_P31_lin70"]["sha256"]
 
 
+@pytest.mark.parametrize("N,P", [(256, 60), (512, 90), (512, 70), (1024, 120)])
+def test_parallel_ray_digests_baseline_geometries(N, P):
+    """The oracle's builder at the BASELINE.json geometries against the imported reference's digests (round 3): the oracle
+    the full-size GPU parity tests compare with starts from the reference's own matrix, bit for bit."""
+    d = json.load(open(os.path.join(GOLDEN, "A_digest.json")))[f"N{N}_P{P}_lin70"]
+    A = oracle.parallel_ray(N, np.linspace(-70, 70, P))
+    assert A.shape[1] == d["nnz"] and hashlib.sha256(A.tobytes()).hexdigest() == d["sha256"]
+
+
 def test_geometry_conventions():
     """theta=0 -> ray j is image column j with weight 1; +90 -> ray 0 is the last row."""
     A = oracle.parallel_ray(8, np.array([0.0, 90.0]))

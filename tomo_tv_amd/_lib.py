@@ -112,6 +112,7 @@ SIGNATURES = {
     "tomo_get_stream": [_p, _pp],
     "tomo_mm_model": [_p, _p, _i, _p, _f, _p, _i],
     "tomo_mm_update": [_p, _p, _p, _i, _p, _f, _f, _f, _p, _i, _i],
+    "tomo_sart_chain_count": [_p, ctypes.POINTER(_i)],
     "tomo_profile_enable": [_p, _i, _i],
     "tomo_profile_read": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
     "tomo_profile_read2": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

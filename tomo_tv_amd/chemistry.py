@@ -62,7 +62,8 @@ class multimodal:
         self.he = self._engine_cls(Nslice, Nray, haadfAngles, device=device, comm=comm)
         self.ce = self._engine_cls(Nslice, Nray, chemAngles, device=device, comm=comm)
         self.ce.be.share_stream_with(self.he.be)
-        self.he._stream_peer = self.ce        # a rebuilt HAADF engine (update_projection_angles) rejoins this stream
+        self.he._stream_peer = self.ce        # a rebuilt HAADF engine (update_projection_angles) rejoins this stream ...
+        self.ce._stream_borrowers.append(self.he)   # ... and a rebuilt chemical engine hands the HAADF engine its new one
         self.comm = comm
         self.NprojHaadf, self.NprojChem = self.he.Nproj, self.ce.Nproj
         self.NrowHaadf, self.NrowChem = self.he.Nrow, self.ce.Nrow

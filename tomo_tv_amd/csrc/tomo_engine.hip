@@ -10,6 +10,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +43,55 @@ struct ProfSlot {
     std::vector<hipEvent_t> ev;  // pairs
     hipEvent_t ref = nullptr;    // recorded when the log is switched on: launches on different streams share this time base
     size_t used = 0, dropped = 0;   // dropped: launches that could not be recorded (tomo_profile_read reports them)
+};
+
+// A persistent host thread that enqueues the launch chain of one sub-slab (run_chains).  Round 2 started and joined a std::thread
+// per sweep (50-100 us of host time on the path of a 4 ms step of a 64-slice slab); this one is started once per
+// engine and sleeps on a condition variable between sweeps.
+struct ChainHelper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, stop = false;
+    void start(int device)
+    {
+        th = std::thread([this, device]() {
+            (void)hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this] { return has_job || stop; });
+                if (stop) return;
+                has_job = false;
+                lk.unlock();
+                job();
+                lk.lock();
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<void()> f)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return done; });
+    }
+    ~ChainHelper()
+    {
+        if (th.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            th.join();
+        }
+    }
 };
 
 struct tomo_engine {
@@ -96,6 +148,7 @@ struct tomo_engine {
     static constexpr int MAX_CHAINS = 4;
     hipStream_t sub_stream[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_sfork = nullptr, ev_sjoin[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+    std::unique_ptr<ChainHelper> chain_helper[MAX_CHAINS];   // [u]: the thread that enqueues chain u (u >= 1), started on first use
     int sart_tile = 1;                            // fused SART step on streamed image tiles (k_sart_tile) when the geometry allows it
     bool st_ok = false;
     int st_ntiles = 0, st_tiles_z = 0;
@@ -750,15 +803,23 @@ static int check_dims(int nslice, int nray, int nproj)
 // "sart_streams": 2 = always (when the slab has two chunks), 1 = never, 0 = auto: equal halves, and not when a pixel's row of
 // slices is a multiple of 4 KB -- the two halves of such rows land on the same memory channels (1024 slices: 48.5 against 42.9 ms
 // per ASD-POCS step; 128 / 256 / 512 / 768 slices: -2.6 / -3.3 / -5.5 / -5.3 %).
+// chains a sweep of this engine's slab runs as, under the current "sart_streams" (also what tomo_sart_chain_count reports)
+static int chain_count(const tomo_engine *e)
+{
+    const int units = e->sxc / 64;
+    const bool two = e->sart_streams >= 2 || (e->sart_streams == 0 && units % 2 == 0 && (e->sx * sizeof(float)) % 4096 != 0);
+    if (!(two && units >= 2)) return 1;
+    if (e->sart_streams > 2) return std::min(std::min(e->sart_streams, (int)tomo_engine::MAX_CHAINS), units);
+    return 2;   // "sart_streams" = 3 / 4: that many chains (measured at 512 slices: 2 chains 22.4 ms per step, 3: 24.1, 4: 22.7)
+}
+
 template <class Chain>
 static int run_chains(tomo_engine *e, const Chain &chain)
 {
     const int units = e->sxc / 64;                       // 64-slice chunks; a sub-slab's per-row kernels use the widest vector that fits
     auto vec_of = [](int c0, int nc) { return (c0 % 4 == 0 && nc % 4 == 0) ? 4 : (c0 % 2 == 0 && nc % 2 == 0) ? 2 : 1; };
-    const bool two = e->sart_streams >= 2 || (e->sart_streams == 0 && units % 2 == 0 && (e->sx * sizeof(float)) % 4096 != 0);
-    if (!(two && units >= 2)) return chain(whole(e));
-    int nch = 2;   // "sart_streams" = 3 / 4: that many chains (measured at 512 slices: 2 chains 22.4 ms per step, 3: 24.1, 4: 22.7)
-    if (e->sart_streams > 2) nch = std::min(std::min(e->sart_streams, (int)tomo_engine::MAX_CHAINS), units);
+    const int nch = chain_count(e);
+    if (nch < 2) return chain(whole(e));
     if (!e->ev_sfork) HIPCHK(hipEventCreateWithFlags(&e->ev_sfork, hipEventDisableTiming));
     for (int u = 0; u < nch; ++u)
         if (!e->sub_stream[u]) {
@@ -775,16 +836,18 @@ static int run_chains(tomo_engine *e, const Chain &chain)
     for (int u = 0; u < nch; ++u) HIPCHK(hipStreamWaitEvent(e->sub_stream[u], e->ev_sfork, 0));
     int rcs[tomo_engine::MAX_CHAINS] = {TOMO_OK, TOMO_OK, TOMO_OK, TOMO_OK};
     std::string errs[tomo_engine::MAX_CHAINS];
-    const int dev = e->device;
-    std::vector<std::thread> helpers;
-    for (int u = 1; u < nch; ++u)
-        helpers.emplace_back([&, u]() {
-            if (hipSetDevice(dev) != hipSuccess) { rcs[u] = TOMO_ERR_HIP; errs[u] = "hipSetDevice (chain enqueue thread)"; return; }
+    for (int u = 1; u < nch; ++u) {                        // chains 1.. are enqueued by the engine's persistent helper threads
+        if (!e->chain_helper[u]) {
+            e->chain_helper[u].reset(new ChainHelper());
+            e->chain_helper[u]->start(e->device);
+        }
+        e->chain_helper[u]->submit([&, u]() {
             rcs[u] = chain(sbs[u]);
             if (rcs[u]) errs[u] = g_err;                  // the error text is thread-local
         });
+    }
     rcs[0] = chain(sbs[0]);
-    for (auto &t : helpers) t.join();
+    for (int u = 1; u < nch; ++u) e->chain_helper[u]->wait();
     for (int u = 1; u < nch; ++u) if (rcs[u] && !rcs[0]) { rcs[0] = rcs[u]; g_err = errs[u]; }
     for (int u = 0; u < nch; ++u)
         if (hipEventRecord(e->ev_sjoin[u], e->sub_stream[u]) != hipSuccess && !rcs[0]) rcs[0] = fail(TOMO_ERR_HIP, "hipEventRecord(sub-slab join)");
@@ -904,6 +967,9 @@ int tomo_adopt_volumes(tomo_engine *dst, tomo_engine *src)
     if (dst->nx != src->nx || dst->n != src->n || dst->sx != src->sx || dst->device != src->device) return fail(TOMO_ERR_ARG, "engines differ in slab shape or device");
     HIPCHK(hipSetDevice(dst->device));
     HIPCHK(hipStreamSynchronize(src->stream));
+    if (src->aux) HIPCHK(hipStreamSynchronize(src->aux));       // nothing of src may still be reading the volumes that move
+    for (int u = 0; u < tomo_engine::MAX_CHAINS; ++u) if (src->sub_stream[u]) HIPCHK(hipStreamSynchronize(src->sub_stream[u]));
+    src->async_pending = false;
     HIPCHK(hipStreamSynchronize(dst->stream));
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) {
         if (!src->vol[i]) continue;
@@ -932,6 +998,13 @@ int tomo_get_dims(tomo_engine *e, int *nslice, int *nray, int *nproj, int64_t *n
     if (nray) *nray = e->n;
     if (nproj) *nproj = e->np;
     if (nnz) *nnz = e->nnz;
+    return TOMO_OK;
+}
+
+int tomo_sart_chain_count(tomo_engine *e, int *count)
+{
+    if (!e || !count) return fail(TOMO_ERR_ARG, "null");
+    *count = chain_count(e);
     return TOMO_OK;
 }
 

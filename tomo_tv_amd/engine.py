@@ -264,6 +264,12 @@ class _GroupBackend:
             for o in {id(lo): lo, id(hi): hi}.values():
                 check(self.L.tomo_wait_for(kid.h, o.h))
             check(self.L.tomo_halo_from(kid.h, int(field), lo.h, hi.h))
+        # ... and the other direction (write after read): a neighbour's NEXT write of its boundary slice -- the clamp of
+        # tv_gd(0), the in-place SART sweep after tv() / tv_fgp -- must not overtake the copy that reads it on the reader's stream
+        for k, kid in enumerate(self.kids):
+            for r in {id(self.kids[(k - 1) % K]): self.kids[(k - 1) % K], id(self.kids[(k + 1) % K]): self.kids[(k + 1) % K]}.values():
+                if r is not kid:
+                    check(self.L.tomo_wait_for(kid.h, r.h))
 
     def _sum_gnorm(self):
         """||grad TV||^2 over the sub-slabs, left in S_GNORM_ALL of every sub-slab (the update kernels read it there)."""
@@ -404,7 +410,8 @@ class _EngineBase:
         self.gpuID = int(device)
         self._ctor_kw = dict(angles_rad=angles_rad, A=A)
         self._options = {}
-        self._stream_peer = None
+        self._stream_peer = None          # the engine whose stream this one runs on (multimodal)
+        self._stream_borrowers = []       # engines that run on THIS engine's stream
         self._make_backend(angles_rad=angles_rad, A=A)
         self.momentum = False
         self.tv_eps = 1e-6          # tv_gd.cu:29,54 (GPU path); ctvlib facade overrides to 1e-8
@@ -788,21 +795,36 @@ class _EngineBase:
         self._set_sino_local(noisy / (Nc * count) * total)
 
     def _rebuild(self, Nproj, angles_rad=None, A=None):
-        """New tilt geometry with the reconstruction kept (tomoengine.cpp:128-149, ctvlib.cpp:317-333): the old tables
-        are released BEFORE the new ones are built (one set in memory), the new engine adopts the volumes (no copy),
-        the stored options and the shared stream are re-applied, the Lipschitz constants refreshed."""
+        """New tilt geometry with the reconstruction kept (tomoengine.cpp:128-149, ctvlib.cpp:317-333).
+
+        Failure-atomic: the new backend is built FIRST (the matrix is validated and the tables are built and uploaded while
+        the old engine is still whole -- two sets of tables are in HBM for that moment, ~2 x 12 GB at 1024^2 x 120 of 288 GB),
+        and only then do the volumes move over (no copy) and the old engine go.  If the build raises (bad A, wrong Nproj,
+        out of memory) this engine is exactly what it was before the call.  Streams: an engine that borrows its peer's
+        stream (multimodal: the HAADF engine runs on the chemical engine's) rejoins it, and an engine whose stream others
+        borrow hands them the new one before the old stream is destroyed."""
         if self.sub_slabs > 1:
             raise _lib.TomoError("changing the tilt geometry of a sub-slab group is not supported: build a new engine")
-        old = self.be
-        old.c("release_geometry")          # tables and sinograms go, the volumes stay on the device
+        old, old_nproj, old_nrow = self.be, self.Nproj, self.Nrow
         self.Nproj = int(Nproj)
         self.Nrow = self.Ny * self.Nproj
-        self._make_backend(angles_rad=angles_rad, A=A)
-        for name, value in self._options.items():
-            self.be.c("set_option", name.encode(), value)
-        if self._stream_peer is not None:
-            self._stream_peer.be.share_stream_with(self.be)
-        check(self.be.L.tomo_adopt_volumes(self.be.h, old.h))
+        try:
+            self._make_backend(angles_rad=angles_rad, A=A)
+            for name, value in self._options.items():
+                self.be.c("set_option", name.encode(), value)
+            if self._stream_peer is not None:
+                self._stream_peer.be.share_stream_with(self.be)
+            for borrower in self._stream_borrowers:
+                self.be.share_stream_with(borrower.be)
+            check(self.be.L.tomo_adopt_volumes(self.be.h, old.h))
+        except BaseException:
+            new = self.be
+            self.be, self.Nproj, self.Nrow = old, old_nproj, old_nrow
+            if new is not old and new is not None:
+                for borrower in self._stream_borrowers:        # whoever was already moved to the new stream goes back
+                    old.share_stream_with(borrower.be)
+                new.close()
+            raise
         old.close()
         if self.L_A is not None:
             self.L_A = self.get_lipschitz()

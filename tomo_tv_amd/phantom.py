@@ -2,11 +2,13 @@
 import numpy as np
 
 
-def ellipsoids(nx, n, seed=1234, k=20, dtype=np.float32):
+def ellipsoids(nx, n, seed=1234, k=20, dtype=np.float32, first=0, count=None):
     """Sum of ``k`` random axis-aligned ellipsoids in a ``(nx, n, n)`` volume (axis 0 = tilt axis).
 
     Centres U(-0.6, 0.6)^3, semi-axes U(0.05, 0.3), amplitudes U(0.2, 1.0), clipped to [0, 1] and zeroed
     outside the inscribed cylinder of radius 0.95*n/2 around the tilt axis.
+    ``first, count``: only the slab ``[first, first + count)`` of the ``nx`` slices is generated (a rank's shard of the
+    volume: identical to slicing the whole phantom, without ever holding it).
     """
     rng = np.random.default_rng(seed)
     c = rng.uniform(-0.6, 0.6, (k, 3))
@@ -14,6 +16,12 @@ def ellipsoids(nx, n, seed=1234, k=20, dtype=np.float32):
     a = rng.uniform(0.2, 1.0, k)
     gx = ((np.arange(nx) + 0.5) / nx * 2 - 1).astype(np.float32) if nx > 1 else np.zeros(1, np.float32)
     gy = ((np.arange(n) + 0.5) / n * 2 - 1).astype(np.float32)
+    if count is None:
+        count = nx - first
+    if first < 0 or count < 0 or first + count > nx:
+        raise ValueError("slab outside the volume")
+    gx = gx[first:first + count]
+    nx = count
     vol = np.zeros((nx, n, n), np.float32)
     yy, zz = np.meshgrid(gy, gy, indexing="ij")
     cyl = (yy * yy + zz * zz) <= 0.95 ** 2

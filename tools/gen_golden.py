@@ -157,6 +157,20 @@ def main():
     ref, ref_fusion = import_reference()
     import oracle
 
+    if "--only-baseline-digests" in sys.argv:
+        # round 3: the imported reference's matrix at the BASELINE geometries (config 3: 512 x 90, config 5: 512 x 70,
+        # config 4: 1024 x 120) -- digests only; the other entries of A_digest.json stay as they are
+        path = os.path.join(GOLD, "A_digest.json")
+        digests = json.load(open(path))
+        for N, P in [(256, 60), (512, 90), (512, 70), (1024, 120)]:
+            A = ref.parallelRay(N, np.linspace(-70, 70, P))
+            digests[f"N{N}_P{P}_lin70"] = digest(A)
+            print(N, P, digests[f"N{N}_P{P}_lin70"], flush=True)
+            del A
+        with open(path, "w") as f:
+            json.dump(digests, f, indent=1, sort_keys=True)
+        return
+
     digests = {}
     shapes = [(16, 5, 2), (32, 9, 4), (64, 16, 8)]
     extra_angle_sets = {
