@@ -113,14 +113,14 @@ def _oracle_setup(ns, n, nproj, shepp=False):
     return ref
 
 
-def _timed(fn, budget_s, max_iters):
+def _timed(fn, budget_s, max_iters, min_iters=1):
     t0 = time.perf_counter()
     it = 0
     while True:
         fn()
         it += 1
         el = time.perf_counter() - t0
-        if el > budget_s or it >= max_iters:
+        if (el > budget_s and it >= min_iters) or it >= max_iters:
             return it, el
 
 
@@ -160,6 +160,35 @@ def cpu_baselines(n, nproj, budget_s=14.0):
     out["config2_sart_tv_256cube_x60tilts"] = {"iters_per_s_full_volume_equiv": iters / el * ns2 / 256, "cores": threads,
                                                "gvoxel_updates_per_s": ns2 * 256 * 256 * iters / el / 1e9,
                                                "sample": f"{iters} SART+TV iterations on a {ns2}x256x256 slab"}
+    # config 3: 512^3, 90 tilts, FISTA (normalised SIRT step + 10 FGP-TV iterations at lambda 0.1 + Nesterov step + cost)
+    ns3 = max(8, 2 * threads)
+    ref = _oracle_setup(ns3, 512, 90)
+    ref.initialize_fista()
+    fs = {"t0": 1.0}
+
+    def fista_iter():
+        ref.SIRT_norm(1, target="yk")
+        ref.recon, ref.yk = ref.yk, ref.recon               # the oracle's tv_fgp acts on .recon
+        ref.tv_fgp(10, 0.1)
+        ref.recon, ref.yk = ref.yk, ref.recon
+        tk = 0.5 * (1 + np.sqrt(1 + 4 * fs["t0"] ** 2))
+        ref.fista_momentum((fs["t0"] - 1) / tk)
+        fs["t0"] = tk
+        return 0.5 * ref.data_distance(normalize=False) ** 2 + 0.1 * ref.tv()
+    iters, el = _timed(fista_iter, 6.0, 5, min_iters=3)      # at least three iterations
+    out["config3_fista_512cube_x90tilts"] = {"iters_per_s_full_volume_equiv": iters / el * ns3 / 512, "cores": threads,
+                                             "gvoxel_updates_per_s": ns3 * 512 * 512 * iters / el / 1e9,
+                                             "sample": f"{iters} FISTA iterations (SIRT step + 10 FGP-TV + momentum + cost) on a {ns3}x512x512 slab"}
+    # config 4: 1024^3, 120 tilts, ASD-POCS -- a sample of the 128-slice slab one of 8 GPUs owns ("a 1/8 slab")
+    ns4 = max(8, threads)
+    ref = _oracle_setup(ns4, 1024, 120)
+    st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(ns4 * 1024 * 120)}
+    iters, el = _timed(lambda: asd_pocs_step(ref, st), 5.0, 3)
+    out["config4_asd_pocs_1024sq_x120tilts"] = {"ms_per_step_128_slice_slab_equiv": el / iters * 1e3 * 128 / ns4, "cores": threads,
+                                                "iters_per_s_full_volume_equiv": iters / el * ns4 / 1024,
+                                                "gvoxel_updates_per_s": ns4 * 1024.0 * 1024 * iters / el / 1e9,
+                                                "sample": f"{iters} ASD-POCS iterations on a {ns4}x1024x1024 sample of the 128-slice slab "
+                                                          "(1/8 of config 4), scaled by slices (OpenMP is over slices)"}
     oracle.select_build("parity")
     return head, out
 
@@ -284,18 +313,45 @@ def attach_traffic(roofs, shape):
 
 
 # ---- secondary configs (N = 1, same process, after the headline) -----------------------------------------------------------
-def _engine(nx, n, nproj):
+def _engine(nx, n, nproj, noisy=False):
     import ctypes
     from tomo_tv_amd._lib import VOL_ORIGINAL
     from tomo_tv_amd.engine import tomoengine
     from tomo_tv_amd.phantom import ellipsoids, tilt_angles
     t = tomoengine(nx, n, np.deg2rad(tilt_angles(nproj)), device=0)
     vol = ellipsoids(nx, n)
+    if noisy:
+        vol[vol == 0] = 1
     t.be.c("set_volume", VOL_ORIGINAL, vol.ctypes.data_as(ctypes.c_void_p))
     del vol
     t.create_projections()
+    if noisy:
+        t.poisson_noise(100)
     t.restart_recon()
     return t
+
+
+def _shard_step(nloc, n, nproj, steps=10):
+    """ASD-POCS step of a slab of ``nloc`` slices through ``multigpuengine`` on a world-1 RCCL group (every collective call of the
+    N-GPU path issued): this file's own ``--force-dist`` path in a fresh child process (torch must initialise the device before
+    anything else in a process does; this one has long been running kernels through the C ABI)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--force-dist", "--quick", "--nslice", str(nloc), "--nray", str(n),
+           "--nproj", str(nproj), "--steps", str(steps), "--warmup", "2"]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": f"child exited {p.returncode}: {p.stderr[-400:]}"}
+        d = json.loads(line[-1])
+        return {"ms_per_step": d["ms_per_step"], "iters_per_s": d["iters_per_s"], "gvoxel_updates_per_s": d["value"],
+                "ms_per_step_every_voxel_stored": d.get("ms_per_step_every_voxel_stored"),
+                "sart_chains": d["config"].get("sart_chains_per_engine"),
+                "form": "bench.py --force-dist in a child process: multigpuengine on a world-1 RCCL group, every all-reduce / ring "
+                        "exchange of the N-GPU path issued"}
+    except Exception as e:  # noqa: BLE001 -- a secondary figure must not take the headline down
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def _time_steps(t, fn, steps, warmup=1):
@@ -401,6 +457,30 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
         "ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V4 / ms / 1e6,
         "roofline": roof("k_sart_tile<true>", cnt, tot, (8 * V4 + 12 * 128 * 1024) / ns, busy_ms=busy)}
     del t
+    # ---- config 4 WHOLE on one GPU: 1024^3, 120 tilts -- the N = 1 anchor of the config-4 scaling curve (multigpuengine.cpp:163-193)
+    t = _engine(1024, 1024, 120)
+    t.initialize_SART("sequential")
+    st4 = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
+    asd_pocs_step(t, st4)
+    ms = _time_steps(t, lambda: asd_pocs_step(t, st4), 2, warmup=0)
+    asd_pocs_flush(t, st4)
+    out["config4_full_1024cube_x120tilts_1gpu"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": 1024.0 ** 3 / ms / 1e6,
+                                                   "sart_chains": sart_chains(t)}
+    del t
+    # ---- the headline on a realistic tilt series (cpu/utils/pytvlib.py:191-206 with SNR = 100: background lifted to 1, Poisson
+    # noise): no exact zeros anywhere, so k_sart_tile's skipping of unchanged stores has nothing to skip
+    t = _engine(512, 512, 90, noisy=True)
+    t.initialize_SART("sequential")
+    stn = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
+    asd_pocs_step(t, stn)
+    ms = _time_steps(t, lambda: asd_pocs_step(t, stn), 3, warmup=0)
+    asd_pocs_flush(t, stn)
+    out["asd_pocs_noisy_512cube_x90tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": 512.0 ** 3 / ms / 1e6,
+                                              "data": "background 1 + Poisson noise at 100 counts per sample (cpu/sim_ASD.py:31 SNR = 100)"}
+    del t
+    # ---- the slab ONE rank of an 8-GPU strong-scaling run of the headline owns (64 x 512^2, 90 tilts), through the slab-sharded
+    # engine with its real collective calls on a world-1 RCCL group: the compute side of the 8-GPU point of the scaling curve
+    out["shard_64x512sq_x90tilts"] = _shard_step(64, 512, 90)
     # ---- config 5 on ONE GPU: ChemicalTomo data-fusion iteration, ADF + 2 spectral channels, 512^3, 70 tilts
     # (chemistry/reconstructor.py:182-225: sirt_data_fusion(lambdaHAADF 10, lambdaCHEM 0.05, iterSIRT 5) + tv_fgp_4D(5, 1e-4))
     from tomo_tv_amd.chemistry import create_weighted_summation_weights, multimodal
@@ -531,7 +611,7 @@ def main():
             from tomo_tv_amd.engine import multigpuengine
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            t = multigpuengine(nglobal, n, ang)
+            t = multigpuengine(nglobal, n, ang, force_collectives=args.force_dist)   # one rank: still issue the RCCL calls
         else:                                            # launcher test on a CPU box: the numpy slab double of tests/
             on_gpu = False
             sys.path.insert(0, os.path.join(ROOT, "tests"))

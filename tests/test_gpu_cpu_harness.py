@@ -140,24 +140,69 @@ def _asd_setup(golden, N, P, Nx, eps):
     return tomo, g, p
 
 
-# Measured on MI355X (tests/measure_asd_parity.py, table in DESIGN.md section 5).  The loop is chaotic: a normalised TV
-# step of fixed length on a gradient made of v / sqrt(eps + ...) terms flips sign-like entries, so ANY rounding
-# difference is amplified once the iterate is piecewise flat.  The ORACLE ITSELF, fed a tilt series moved by one
-# float32 ulp, ends 20 iterations 1e-2 (eps = 1e-6) to 2e-2 (eps = 1e-8) away from its own unperturbed run -- and the
-# HIP path ends at the same distance (1.0e-2 ... 2.1e-2).  What CAN be held hard:
-#   * the first iteration: the iterate to 1e-5; the first five: every trace value to 1e-5 (measured 1e-8 ... 1e-7), the
-#     iterate to 3e-3 (measured <= 6.2e-4);
-#   * all twenty: the caps below (3x the largest value measured on any fixture shape);
+# The free-running loop is chaotic: a normalised TV step of fixed length on a gradient of v / sqrt(eps + ...) terms flips sign-like
+# entries, so ANY rounding difference is amplified once the iterate is piecewise flat.  Characterised in round 3
+# (tests/measure_asd_parity.py, profiles/r03_asd_parity.md: eight one-ulp seeds per shape, a binary64 trajectory): the ORACLE fed
+# a tilt series moved by one float32 ulp ends 20 iterations 5e-5 ... 2e-2 (16 x 5 x 2: bimodal, seed-dependent) or 2e-2 ... 3.5e-2
+# (N >= 32: every seed) away from its own unperturbed run, and both fp32 paths end equally far from the binary64 trajectory.  So no
+# constant is a meaningful cap; the bound is the oracle's own spread, measured here:
+#   * the first iteration: the iterate to 1e-5; the first five: every trace value to 1e-5 and the iterate within 3x the oracle's
+#     own five-iteration spread;
+#   * all twenty: volume and traces within 3x the LARGEST deviation the oracle shows against itself over 8 one-ulp seeds;
 #   * every single iteration restarted from the oracle's iterate: 1e-5 (test_sim_asd_art_teacher_forced).
-ASD_CAP = {"vol": 6e-2, "trace": 1.5e-2}
+ASD_SEEDS = range(8)
 
 
-def _early_and_capped(tomo_vol, traces, g, key):
-    for got, name in traces:
-        want = g[f"{name}_{key}"]
-        assert np.allclose(got[:5], want[:5], rtol=1e-5), (name, got[:5], want[:5])
-        assert np.max(np.abs(got - want) / np.abs(want)) <= ASD_CAP["trace"], name
-    assert rel_l2(tomo_vol, g[f"final_{key}"]) <= ASD_CAP["vol"]
+def _oracle_self_spread(golden, N, P, Nx, eps, key):
+    """max over 8 seeds of the oracle's deviation from its committed trace when its tilt series moves by one ulp per sample"""
+    from test_gpu_parity import ulp_noise
+    import json
+    g = golden(f"trace_asd_art_N{N}_P{P}_Nx{Nx}.npz")
+    A = golden(f"A_N{N}_P{P}.npz")["A"]
+    p = json.loads(str(g["params"]))
+    out = {"vol": 0.0, "vol5": 0.0, "rmse": 0.0, "dd": 0.0, "tv": 0.0}
+    for seed in ASD_SEEDS:
+        r = oracle.ctvlib(Nx, N, P)
+        r.load_A(A)
+        r.row_inner_product()
+        r.initialize_recon_copy()
+        r.original_volume = g["x0"].copy()
+        r.set_tilt_series(ulp_noise(g["b"], seed))
+        r.tv_eps = eps
+        snap = {}
+        rm, dd, tv = sim_asd_on(r, 20, p, lambda i, t: snap.__setitem__(i, t.recon.copy()) if i == 4 else None)
+        out["vol"] = max(out["vol"], rel_l2(r.recon, g[f"final_{key}"]))
+        out["vol5"] = max(out["vol5"], rel_l2(snap[4], g[f"iter5_{key}"]))
+        for name, got in (("rmse", rm), ("dd", dd), ("tv", tv)):
+            want = g[f"{name}_{key}"]
+            out[name] = max(out[name], float(np.max(np.abs(got - want) / np.abs(want))))
+    return out
+
+
+def sim_asd_on(tomo, Niter, p, on_iter=None):
+    """sim_asd for an object with the ctvlib method table but no harness module (the oracle): same loop, ART only."""
+    beta = p["beta0"]
+    rmse_vec, dd_vec, tv_vec = np.zeros(Niter), np.zeros(Niter), np.zeros(Niter)
+    for i in range(Niter):
+        tomo.copy_recon()
+        tomo.ART(beta)
+        beta *= p["beta_red"]
+        if i == 0:
+            dPOCS = tomo.matrix_2norm() * p["alpha"]
+            dp = dPOCS / p["alpha"]
+        else:
+            dp = tomo.matrix_2norm()
+        dd_vec[i] = tomo.data_distance()
+        rmse_vec[i] = tomo.rmse()
+        tomo.copy_recon()
+        tv_vec[i] = tomo.tv()
+        tomo.tv_gd(p["ng"], dPOCS)
+        dg = tomo.matrix_2norm()
+        if dg > dp * p["r_max"] and dd_vec[i] > p["eps"]:
+            dPOCS *= p["alpha_red"]
+        if on_iter is not None:
+            on_iter(i, tomo)
+    return rmse_vec, dd_vec, tv_vec
 
 
 @pytest.mark.parametrize("eps,key", [(1e-6, "eps1e-06"), (1e-8, "eps1e-08")])
@@ -168,14 +213,22 @@ def test_sim_asd_art_free_running(gpu, golden, N, P, Nx, eps, key):
     assert abs(tomo.original_tv() - float(g[f"tv0_{key}"])) <= 1e-5 * float(g[f"tv0_{key}"])
     sim_asd(tomo, 1, p)
     assert rel_l2(tomo.get_volume(), g[f"iter1_{key}"]) < 1e-5              # one whole iteration: the north-star tolerance
+    spread = _oracle_self_spread(golden, N, P, Nx, eps, key)
     tomo, g, p = _asd_setup(golden, N, P, Nx, eps)
     sim_asd(tomo, 5, p)
-    # the iterate separates before the scalars do (they average over the volume): measured <= 6.2e-4 after five iterations
-    assert rel_l2(tomo.get_volume(), g[f"iter5_{key}"]) < 3e-3
+    # the iterate separates before the scalars do (they average over the volume)
+    e5 = rel_l2(tomo.get_volume(), g[f"iter5_{key}"])
+    assert e5 <= max(1e-5, 3 * spread["vol5"]), (e5, spread)
     # run on: the loop state (beta, dPOCS) is re-derived by running all 20 from scratch on a fresh engine
     tomo, g, p = _asd_setup(golden, N, P, Nx, eps)
     rm, dd, tv = sim_asd(tomo, 20, p)
-    _early_and_capped(tomo.get_volume(), ((rm, "rmse"), (dd, "dd"), (tv, "tv")), g, key)
+    for got, name in ((rm, "rmse"), (dd, "dd"), (tv, "tv")):
+        want = g[f"{name}_{key}"]
+        assert np.allclose(got[:5], want[:5], rtol=1e-5), (name, got[:5], want[:5])
+        dev = float(np.max(np.abs(got - want) / np.abs(want)))
+        assert dev <= max(1e-5, 3 * spread[name]), (name, dev, spread)
+    e20 = rel_l2(tomo.get_volume(), g[f"final_{key}"])
+    assert e20 <= max(1e-5, 3 * spread["vol"]), (e20, spread)
 
 
 @pytest.mark.parametrize("N,P,Nx", SHAPES)

@@ -223,6 +223,46 @@ def test_fista_momentum_and_soft_threshold(gpu, golden):
     assert rel_l2(dev.get_volume(), want) < 1e-7
 
 
+def test_fista_momentum_rotation_keeps_the_three_volumes(gpu, golden):
+    """tomoengine.cpp:381-384 leaves recon == recon_old == the prox result and yk = the extrapolated point.  The engine rotates
+    buffers and keeps recon_old == recon as a flag (two reads, one store per step): every way of looking at or writing the three
+    volumes between steps must see the reference's state."""
+    from tomo_tv_amd._lib import VOL_RECON_OLD
+    N, P, Nx = 32, 9, 4
+    dev, ref, g = make_pair(golden, N, P, Nx)
+    rng = np.random.default_rng(1)
+    seed_volume(dev, ref, g["x_sart"])
+    dev.initialize_fista()
+    ref.initialize_fista()
+
+    def same(tag):
+        for vol, want in ((VOL_RECON, ref.recon), (VOL_YK, ref.yk), (VOL_RECON_OLD, ref.recon_old)):
+            assert np.array_equal(dev.get_volume(vol), want), (tag, vol)
+    for k, beta in enumerate((0.0, 0.28, 0.43, 0.53, 0.6)):
+        y = (g["x_sart"] * np.float32(1 + 0.1 * k) + rng.random(g["x_sart"].shape, dtype=np.float32) * np.float32(0.01))
+        dev.set_volume(y, VOL_YK)
+        ref.yk[:] = y
+        if k == 2:                                   # look at recon_old while it is only a flag, then carry on
+            assert np.array_equal(dev.get_volume(VOL_RECON_OLD), ref.recon_old)
+        if k == 3:                                   # a caller overwrites recon between two steps: recon_old must keep its content
+            z = g["sart_b025"] * np.float32(0.5)
+            dev.set_volume(z, VOL_RECON)
+            ref.recon[:] = z
+        if k == 4:                                   # ... and recon_old itself
+            z = g["sart_b1"]
+            dev.set_volume(z, VOL_RECON_OLD)
+            ref.recon_old[:] = z
+        dev.fista_momentum(beta)
+        ref.fista_momentum(beta)
+        assert np.array_equal(dev.get_volume(VOL_RECON), ref.recon), k
+        assert rel_l2(dev.get_volume(VOL_YK), ref.yk) < 1e-7, k
+        ref.yk[:] = dev.get_volume(VOL_YK)           # (FMA contraction of r + beta (r - old): carry the device's bits)
+        same(k)
+    dev.restart_recon()
+    ref.restart_recon()
+    same("restart")
+
+
 def ulp_noise(x, seed):
     """x moved by one float32 ulp in a random direction per element: the smallest possible input change."""
     rng = np.random.default_rng(seed)
@@ -256,8 +296,9 @@ def test_asd_pocs_free_running_trace(gpu, golden, N, P, Nx):
 
     TV descent with eps=1e-8 follows sign-like gradients (Lipschitz constant ~1/sqrt(eps)) with a normalised step of
     fixed length dPOCS, so the loop is ill-conditioned: it amplifies ANY fp32 rounding difference.  The bound is
-    therefore conditioning-aware: the oracle is run twice, the second time on a tilt series moved by ONE ulp, and
-    the HIP path must stay within 5x of how far the oracle moves itself.  The first iteration is held to 2e-5."""
+    therefore conditioning-aware: the oracle is run again on tilt series moved by ONE ulp per sample (eight seeds), and
+    the HIP path must stay within 3x of the farthest the oracle moves itself (profiles/r03_asd_parity.md: HIP sits at
+    0.03 ... 1.2x of that in every row).  The first iteration is held to 2e-5."""
     from tomo_tv_amd.reconstructor import TomoGPU
     A = golden(f"A_N{N}_P{P}.npz")
     g = golden(f"trace_N{N}_P{P}_Nx{Nx}.npz")
@@ -266,18 +307,20 @@ def test_asd_pocs_free_running_trace(gpu, golden, N, P, Nx):
     rec.tomo.tv_eps = 1e-8
     dd, tv = rec.asd_pocs(Niter=20)
     got = rec.get_recon()
-    ref = oracle.ctvlib(Nx, N, P)
-    ref.load_A(A["A"])
-    ref.tv_eps = 1e-8
-    ref.set_tilt_series(ulp_noise(g["b"], 5))
-    dd2, tv2 = asd_loop(ref, 20, Nx * N * P, lambda t: t.data_distance(normalize=False))
-    self_move = rel_l2(ref.recon, g["asd_final"])
-    self_dd = np.max(np.abs(dd2 - g["asd_dd"]) / g["asd_dd"])
-    self_tv = np.max(np.abs(tv2 - g["asd_tv"]) / g["asd_tv"])
+    self_move = self_dd = self_tv = 0.0
+    for seed in range(8):                # the oracle against itself, tilt series moved by one ulp: eight seeds, the largest deviation
+        ref = oracle.ctvlib(Nx, N, P)
+        ref.load_A(A["A"])
+        ref.tv_eps = 1e-8
+        ref.set_tilt_series(ulp_noise(g["b"], seed))
+        dd2, tv2 = asd_loop(ref, 20, Nx * N * P, lambda t: t.data_distance(normalize=False))
+        self_move = max(self_move, rel_l2(ref.recon, g["asd_final"]))
+        self_dd = max(self_dd, np.max(np.abs(dd2 - g["asd_dd"]) / g["asd_dd"]))
+        self_tv = max(self_tv, np.max(np.abs(tv2 - g["asd_tv"]) / g["asd_tv"]))
     assert np.allclose(dd[:1], g["asd_dd"][:1], rtol=2e-5) and np.allclose(tv[:1], g["asd_tv"][:1], rtol=2e-5)
-    assert np.max(np.abs(dd - g["asd_dd"]) / g["asd_dd"]) <= max(2e-5, 5 * self_dd)
-    assert np.max(np.abs(tv - g["asd_tv"]) / g["asd_tv"]) <= max(2e-5, 5 * self_tv)
-    assert rel_l2(got, g["asd_final"]) <= max(5e-5, 5 * self_move), (rel_l2(got, g["asd_final"]), self_move)
+    assert np.max(np.abs(dd - g["asd_dd"]) / g["asd_dd"]) <= max(2e-5, 3 * self_dd)
+    assert np.max(np.abs(tv - g["asd_tv"]) / g["asd_tv"]) <= max(2e-5, 3 * self_tv)
+    assert rel_l2(got, g["asd_final"]) <= max(5e-5, 3 * self_move), (rel_l2(got, g["asd_final"]), self_move)
 
 
 @pytest.mark.parametrize("N,P,Nx", SHAPES)

@@ -1397,16 +1397,16 @@ __global__ __launch_bounds__(256) void k_soft_threshold(f4 *__restrict__ x, floa
     }
 }
 
-// recon <- yk ; yk <- recon + beta (recon - recon_old) ; recon_old <- recon   (tomoengine.cpp:381-384)
-__global__ __launch_bounds__(256) void k_momentum(f4 *__restrict__ recon, f4 *__restrict__ yk,
-                                                   f4 *__restrict__ old, float beta, int64_t n4)
+// Nesterov step (tomoengine.cpp:381-384: recon <- yk ; yk <- recon + beta (recon - recon_old) ; recon_old <- recon).  The two
+// copies are not stores here: the engine rotates the recon / yk buffers and keeps "recon_old == recon" as a flag, so this pass
+// reads r (the prox result) and old and writes the extrapolated point; out may be the buffer old lives in (same index: read
+// before write in one thread).
+__global__ __launch_bounds__(256) void k_momentum(const f4 *r_in, const f4 *old, f4 *out, float beta, int64_t n4)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         typedef VecOf<4>::T V;
-        V r = nt_ld<512>(reinterpret_cast<const V *>(yk) + i), o = nt_ld<512>(reinterpret_cast<const V *>(old) + i);
-        nt_st<512>(r, reinterpret_cast<V *>(recon) + i);
-        nt_st<512>(r + beta * (r - o), reinterpret_cast<V *>(yk) + i);
-        nt_st<512>(r, reinterpret_cast<V *>(old) + i);
+        V r = nt_ld<512>(reinterpret_cast<const V *>(r_in) + i), o = nt_ld<512>(reinterpret_cast<const V *>(old) + i);
+        nt_st<512>(r + beta * (r - o), reinterpret_cast<V *>(out) + i);
     }
 }
 
@@ -1734,6 +1734,14 @@ __device__ __forceinline__ float tv_rsqrt(float q)
     return y;
 }
 
+// The descent step x - dPOCS g / ||g|| (ctvlib.cpp:452-458).  The reference evaluates (dPOCS * g) / ||g|| per voxel; here the
+// step length dPOCS / ||g|| is formed ONCE per pass (one IEEE division) and the voxel update is one fused multiply-add: the
+// IEEE division per voxel was ~10 of the ~40 vector instructions a voxel of the update pass costs (round 3).  At most 1.5 ulp of
+// the STEP away from the reference's expression.  One definition for every form (march, stored-gradient update, halo planes),
+// so they stay bit-identical to each other.
+__device__ __forceinline__ float tv_step_len(float dPOCS, const double *gnorm2) { return __fdiv_rn(dPOCS, (float)sqrt(*gnorm2)); }
+__device__ __forceinline__ float tv_step(float c, float gv, float len) { return __fmaf_rn(-gv, len, c); }
+
 constexpr int TVL_TZ = 8;          // z-columns per workgroup of the FGP kernel (2 per wave)
 constexpr int TVL_PITCH = 66;      // 64 slices + halo each side
 
@@ -1901,7 +1909,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
     const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
     double acc = 0.0, tvacc = 0.0;
     float nrm_ = 1.f;
-    if (MODE == TVM_UPDATE) nrm_ = (float)sqrt(*up.gnorm2);
+    if (MODE == TVM_UPDATE) nrm_ = tv_step_len(up.dPOCS, up.gnorm2);      // the step length dPOCS / ||g||
     // Item = (y segment, z block, chunk).  Neighbouring z blocks share two of their ten columns and neighbouring chunks a
     // slice on either side: when the neighbours run on different XCDs every shared line is fetched from HBM once per XCD
     // (PMC, round 2: 1.72x the compulsory reads, and the kernel is bound by exactly that traffic: 1.46 GB in 288 us).
@@ -2028,7 +2036,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                         }
                     } else {   // TVM_UPDATE: the expression of k_tv_update
                         const size_t pix = (size_t)(y * n + z);
-                        float v = __fsub_rn(c, __fdiv_rn(__fmul_rn(up.dPOCS, gv), nrm_));   // = k_tv_update's x - (dPOCS g)/||g||
+                        float v = tv_step(c, gv, nrm_);   // = k_tv_update's step
                         if (up.clamp) v = fmaxf(v, 0.f);
                         if (up.stream) __builtin_nontemporal_store(v, up.x_out + pix * sx + (unsigned)s);
                         else up.x_out[pix * sx + (unsigned)s] = v;
@@ -2084,7 +2092,7 @@ __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, 
     const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
     double acc = 0.0, tvacc = 0.0;
     float nrm_ = 1.f;
-    if (MODE == TVM_UPDATE) nrm_ = (float)sqrt(*up.gnorm2);
+    if (MODE == TVM_UPDATE) nrm_ = tv_step_len(up.dPOCS, up.gnorm2);      // the step length dPOCS / ||g||
     int bs, bz, ys;
     if ((nzb & 7) == 0) {       // the XCD-aware item map of k_tv_grad_reg
         const int zpx = nzb >> 3;
@@ -2170,7 +2178,7 @@ __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, 
                         }
                     } else {   // TVM_UPDATE: the expression of k_tv_update
                         const size_t pix = (size_t)(y * n + z);
-                        float v = __fsub_rn(c, __fdiv_rn(__fmul_rn(up.dPOCS, gv), nrm_));
+                        float v = tv_step(c, gv, nrm_);
                         if (up.clamp) v = fmaxf(v, 0.f);
                         if (up.stream) __builtin_nontemporal_store(v, up.x_out + pix * sx + (unsigned)s);
                         else up.x_out[pix * sx + (unsigned)s] = v;
@@ -2223,11 +2231,11 @@ __global__ __launch_bounds__(256) void k_halo_apply(float *__restrict__ halo_lo,
                                                      const float *__restrict__ g_lo, const float *__restrict__ g_hi,
                                                      const double *__restrict__ gnorm2, float dPOCS, int clamp, int npix)
 {
-    const float nrm = (float)sqrt(*gnorm2);
+    const float len = tv_step_len(dPOCS, gnorm2);
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= npix) return;
-    float a = __fsub_rn(halo_lo[p], __fdiv_rn(__fmul_rn(dPOCS, g_lo[p]), nrm));
-    float b = __fsub_rn(halo_hi[p], __fdiv_rn(__fmul_rn(dPOCS, g_hi[p]), nrm));
+    float a = tv_step(halo_lo[p], g_lo[p], len);
+    float b = tv_step(halo_hi[p], g_hi[p], len);
     if (clamp) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
     halo_lo[p] = a;
     halo_hi[p] = b;
@@ -2243,10 +2251,11 @@ __global__ __launch_bounds__(256) void k_tv_update(f4 *__restrict__ x, const f4 
                                                     int64_t n4, f4 *__restrict__ track, double *__restrict__ part,
                                                     float *__restrict__ wrap_lo, float *__restrict__ wrap_hi, int nx, int sx4)
 {
-    float nrm = (float)sqrt(*gnorm2);
+    const float len = tv_step_len(dPOCS, gnorm2);
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f4 v = x[i] - (dPOCS * g[i]) / nrm;
+        f4 xv = x[i], gv = g[i], v;
+        v.x = tv_step(xv.x, gv.x, len); v.y = tv_step(xv.y, gv.y, len); v.z = tv_step(xv.z, gv.z, len); v.w = tv_step(xv.w, gv.w, len);
         if (clamp) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         x[i] = v;
         if (wrap_lo) {

@@ -198,6 +198,7 @@ struct tomo_engine {
     hipStream_t aux = nullptr;                    // second stream for work that is independent of the main sequence
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool async_pending = false;
+    bool old_is_recon = false;                    // RECON_OLD's content is RECON's (tomo_fista_momentum; see get_vol)
     bool geometry_released = false;               // tomo_release_geometry: only tomo_adopt_volumes / tomo_destroy remain valid
     // halos
     float *halo_lo = nullptr, *halo_hi = nullptr, *halo_lo_own = nullptr, *halo_hi_own = nullptr;
@@ -217,15 +218,32 @@ static int dev_alloc(void **p, size_t bytes, bool zero, hipStream_t st)
     return TOMO_OK;
 }
 
-static int get_vol(tomo_engine *e, int id, float **out)
+// After a Nesterov step recon_old == recon (tomoengine.cpp:381-384 copies the prox result into both).  The step keeps that as a
+// FLAG instead of a second store (old_is_recon: the logical content of RECON_OLD is RECON's; its own buffer is stale), so the
+// step reads two volumes and writes one.  Whoever may WRITE recon, or touches recon_old, goes through get_vol, which first makes
+// the copy real; readers of recon use get_vol_ro and leave the flag alone.
+static int get_vol_ro(tomo_engine *e, int id, float **out)
 {
     if (id < 0 || id >= TOMO_VOL_SLOTS) return fail(TOMO_ERR_ARG, "bad volume id");
+    if (id == TOMO_VOL_RECON_OLD && e->old_is_recon) id = TOMO_VOL_RECON;     // read-only view of the same content
     if (!e->vol[id]) {
         int rc = dev_alloc((void **)&e->vol[id], e->vol_elems() * sizeof(float), true, e->stream);
         if (rc) return rc;
     }
     *out = e->vol[id];
     return TOMO_OK;
+}
+
+static int get_vol(tomo_engine *e, int id, float **out)
+{
+    if (id < 0 || id >= TOMO_VOL_SLOTS) return fail(TOMO_ERR_ARG, "bad volume id");
+    if (e->old_is_recon && (id == TOMO_VOL_RECON || id == TOMO_VOL_RECON_OLD)) {
+        e->old_is_recon = false;
+        float *src, *dst; int rc;
+        if ((rc = get_vol_ro(e, TOMO_VOL_RECON, &src)) || (rc = get_vol_ro(e, TOMO_VOL_RECON_OLD, &dst))) return rc;
+        HIPCHK(hipMemcpyAsync(dst, src, e->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    }
+    return get_vol_ro(e, id, out);
 }
 
 static int get_sino(tomo_engine *e, float **slot, float **out)
@@ -977,6 +995,8 @@ int tomo_adopt_volumes(tomo_engine *dst, tomo_engine *src)
         dst->vol[i] = src->vol[i];
         src->vol[i] = nullptr;
     }
+    dst->old_is_recon = src->old_is_recon;
+    src->old_is_recon = false;
     return TOMO_OK;
 }
 
@@ -1067,7 +1087,7 @@ int tomo_set_volume(tomo_engine *e, int vol, const float *data)
 int tomo_get_volume(tomo_engine *e, int vol, float *data)
 {
     NEED(e);
-    float *src; int rc = get_vol(e, vol, &src); if (rc) return rc;
+    float *src; int rc = get_vol_ro(e, vol, &src); if (rc) return rc;
     if (!data) return fail(TOMO_ERR_ARG, "null volume");
     return download(e, src, data, e->npix);
 }
@@ -1089,7 +1109,7 @@ int tomo_set_slice(tomo_engine *e, int vol, int s, const float *img)
 int tomo_get_slice(tomo_engine *e, int vol, int s, float *img)
 {
     NEED(e);
-    float *src; int rc = get_vol(e, vol, &src); if (rc) return rc;
+    float *src; int rc = get_vol_ro(e, vol, &src); if (rc) return rc;
     if (s < 0 || s >= e->nx || !img) return fail(TOMO_ERR_ARG, "slice index out of range");
     if ((rc = ensure_stage(e, e->npix * sizeof(float)))) return rc;
     hipLaunchKernelGGL(k_gather_slice, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, src, e->stage, e->npix, e->sx, s);
@@ -1106,6 +1126,7 @@ int tomo_restart_recon(tomo_engine *e)
     HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_RECON], 0, e->vol_elems() * sizeof(float), e->stream));
     if (e->vol[TOMO_VOL_YK]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_YK], 0, e->vol_elems() * sizeof(float), e->stream));
     if (e->vol[TOMO_VOL_RECON_OLD]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_RECON_OLD], 0, e->vol_elems() * sizeof(float), e->stream));
+    e->old_is_recon = false;                       // every buffer is physically zero
     return TOMO_OK;
 }
 
@@ -1125,7 +1146,7 @@ int tomo_forward_projection(tomo_engine *e, int vol, int sino)
     NEED(e);
     { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *x, *g; int rc;
-    if ((rc = get_vol(e, vol, &x))) return rc;
+    if ((rc = get_vol_ro(e, vol, &x))) return rc;
     if ((rc = sino_slot(e, sino, &g))) return rc;
     return launch_fp_all<FP_STORE>(e, x, nullptr, g);
 }
@@ -1304,7 +1325,8 @@ int tomo_art(tomo_engine *e, float beta) { return tomo_art_order(e, beta, nullpt
 int tomo_art_order(tomo_engine *e, float beta, const int32_t *order_host)
 {
     NEED(e);
-    float *x = e->vol[TOMO_VOL_RECON];
+    float *x;
+    { int rc_ = get_vol(e, TOMO_VOL_RECON, &x); if (rc_) return rc_; }
     int32_t *d_order = nullptr;
     if (order_host) {
         std::vector<char> seen(e->nrows, 0);
@@ -1381,7 +1403,9 @@ int tomo_poisson_ml(tomo_engine *e, float lambda)
 {
     int rc;
     if ((rc = tomo_poisson_residual(e, TOMO_VOL_RECON, TOMO_SINO_B, TOMO_SINO_R))) return rc;
-    return launch_bp_all(e, e->vol[TOMO_VOL_RECON], e->sino[TOMO_SINO_R], nullptr, 1.f, -(lambda / e->lipschitz), 1);
+    float *x;
+    if ((rc = get_vol(e, TOMO_VOL_RECON, &x))) return rc;
+    return launch_bp_all(e, x, e->sino[TOMO_SINO_R], nullptr, 1.f, -(lambda / e->lipschitz), 1);
 }
 
 int tomo_poisson_residual(tomo_engine *e, int vol, int sino_b, int sino_out)
@@ -1616,11 +1640,21 @@ int tomo_soft_threshold(tomo_engine *e, int vol, float lambda)
 int tomo_fista_momentum(tomo_engine *e, float beta)
 {
     NEED(e);
+    // recon <- yk is a rotation of the two buffers, recon_old <- recon a flag (get_vol), and yk_new = r + beta (r - old) lands in
+    // the buffer recon has just left -- which, from the second step on, is also where `old` sits (old == recon then): the step
+    // reads two volumes and writes one (round 2: two reads, three stores: 645 us at 512^3).  Same expression, same bits.
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *x, *yk, *old; int rc;
-    if ((rc = get_vol(e, TOMO_VOL_RECON, &x)) || (rc = get_vol(e, TOMO_VOL_YK, &yk)) || (rc = get_vol(e, TOMO_VOL_RECON_OLD, &old))) return rc;
+    const bool aliased = e->old_is_recon;
+    if ((rc = get_vol_ro(e, TOMO_VOL_RECON, &x)) || (rc = get_vol_ro(e, TOMO_VOL_YK, &yk))) return rc;
+    if (aliased) old = x;                                 // recon_old's content IS recon's
+    else if ((rc = get_vol_ro(e, TOMO_VOL_RECON_OLD, &old))) return rc;
     int64_t n4 = e->vol_elems() / 4;
-    hipLaunchKernelGGL(k_momentum, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (f4 *)yk, (f4 *)old, beta, n4);
+    hipLaunchKernelGGL(k_momentum, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const f4 *)yk, (const f4 *)old, (f4 *)x, beta, n4);
     LAUNCHCHK();
+    e->vol[TOMO_VOL_RECON] = yk;                          // the prox result r
+    e->vol[TOMO_VOL_YK] = x;                              // r + beta (r - old), written over the buffer recon has left
+    e->old_is_recon = true;                               // recon_old == r, not stored
     return TOMO_OK;
 }
 
@@ -1629,7 +1663,7 @@ int tomo_data_distance_sq(tomo_engine *e, int vol)
 {
     NEED(e);
     float *x, *g; int rc;
-    if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &g))) return rc;
+    if ((rc = get_vol_ro(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     if ((rc = launch_fp_all<FP_DD>(e, x, e->sino[TOMO_SINO_B], g))) return rc;
     return reduce_end(e, TOMO_S_DD);
@@ -1649,7 +1683,7 @@ int tomo_data_distance_sq_async(tomo_engine *e, int vol)
         if (rc) return rc;
     }
     float *tmp; int rc;
-    if ((rc = get_vol(e, vol, &tmp)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &tmp))) return rc;   // allocate on the main stream
+    if ((rc = get_vol_ro(e, vol, &tmp)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &tmp))) return rc;   // allocate on the main stream
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
     hipStream_t main_stream = e->stream;
@@ -1678,7 +1712,7 @@ int tomo_diff_norm_sq(tomo_engine *e, int a, int b, int slot)
     NEED(e);
     if (slot < 0 || slot >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
     float *pa, *pb; int rc;
-    if ((rc = get_vol(e, a, &pa)) || (rc = get_vol(e, b, &pb))) return rc;
+    if ((rc = get_vol_ro(e, a, &pa)) || (rc = get_vol_ro(e, b, &pb))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     int64_t n4 = e->vol_elems() / 4;
     hipLaunchKernelGGL(k_sqdiff, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const f4 *)pa, (const f4 *)pb, e->d_part, n4);
@@ -1689,7 +1723,7 @@ int tomo_diff_norm_sq(tomo_engine *e, int a, int b, int slot)
 int tomo_l1_norm(tomo_engine *e, int vol)
 {
     NEED(e);
-    float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
+    float *x; int rc; if ((rc = get_vol_ro(e, vol, &x))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     int64_t n4 = e->vol_elems() / 4;
     hipLaunchKernelGGL(k_l1, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const f4 *)x, e->d_part, n4);
@@ -1747,7 +1781,7 @@ static int field_ptr(tomo_engine *e, int field, float **out)
 {
     if (field == TOMO_FIELD_FGP_D) return get_scratch(e, &e->tvg, out);
     if (field == TOMO_FIELD_FGP_P1) return get_scratch(e, &e->fgp_p[0], out);
-    return get_vol(e, field, out);
+    return get_vol_ro(e, field, out);   // halo packs and fills only read
 }
 
 int tomo_bind_halo(tomo_engine *e, void *device_lo, void *device_hi)
@@ -1854,7 +1888,7 @@ static int tv_grid(tomo_engine *e)
 int tomo_tv_partial(tomo_engine *e, int vol, float eps)
 {
     NEED(e);
-    float *x; int rc; if ((rc = get_vol(e, vol, &x))) return rc;
+    float *x; int rc; if ((rc = get_vol_ro(e, vol, &x))) return rc;
     Halo h{e->halo_lo, e->halo_hi};
     if (e->tv_lds != 8 && e->tv_lds != 1) {   // direct-global stencil (reads x twice)
         if ((rc = reduce_begin(e))) return rc;
