@@ -277,6 +277,30 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "fp_all_lpr" (16): ray-driven all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks
  *                     (0 = wide form) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
+/* ---- native communicator: the slab-sharded path over RCCL on the engine's own stream ---------------------------------------
+ * Replaces, for a C / C++ host as for the Python one, the MPI calls of the reference's sharded CPU engine (mpi_ctvlib.cpp:400-422
+ * ring exchange of boundary slices, :455 / :547 MPI_Allreduce of the norms) and the OpenMP-over-GPUs loop of multigpuengine.cpp:
+ * one engine per rank holding rank's slab (tomo_create with the slab's slice count), one communicator shared by the rank's
+ * engines.  librccl is opened with dlopen on first use.  Rank 0 makes the 128-byte id and hands it to the others by any means
+ * (MPI_Bcast, torch.distributed.broadcast, a file); tomo_comm_init is collective over the group. */
+int tomo_comm_unique_id(void *id128);
+int tomo_comm_init(tomo_engine *e, const void *id128, int world, int rank);   /* also sets the slab's global-edge flags */
+int tomo_comm_share(tomo_engine *e, tomo_engine *other);                       /* another engine of the same rank and device */
+int tomo_comm_destroy(tomo_engine *e);
+int tomo_comm_info(tomo_engine *e, int *world, int *rank);                     /* world = 0: no communicator */
+/* boundary slices of a field into the ring neighbours' halo planes: pack + ONE group of 2 sends and 2 receives */
+int tomo_comm_exchange_halo(tomo_engine *e, int field);
+/* every scalar slot summed over the ranks (into a copy: the buffer keeps the slab's partial sums), read back; and the
+ * non-blocking form collected by tomo_scalars_snapshot_read */
+int tomo_comm_read_scalars(tomo_engine *e, double *out, int count);
+int tomo_comm_scalars_snapshot(tomo_engine *e);
+/* slab-sharded tv_gd / tv_gd_tracked (track_vol < 0: plain), whole call: per inner iteration ONE group {all-reduce of sum g^2 +
+ * the gradient's boundary planes to both neighbours}; every rank advances its halo planes itself.  TOMO_S_TV keeps the slab's
+ * share of the TV value before descent. */
+int tomo_comm_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot);
+/* the plane exchange between two fused FGP iterations (buffers of tomo_bind_fgp_halo) */
+int tomo_comm_fgp_exchange(tomo_engine *e);
+
 /* launch chains a SART / ART sweep of this engine's slab runs as under the current "sart_streams" (1 = one chain on the
  * engine's stream; 2..4 = that many sub-slabs of 64-slice chunks on their own streams).  What the reference hides inside
  * ASTRA's run(Nproj*nIter) (tomoengine.cpp:162-179); bench.py derives the bytes one launch moves from it. */

@@ -1,7 +1,7 @@
 """CPU restatement of the reference's fused multi-modal engine -- TEST INFRASTRUCTURE ONLY.
 
-Follows tomofusion/chemistry/utils/multimodal.cpp (poisson_ml :277-304, rescale :307-328, fuse :425-441,
-data_fusion :452-491, data_distance :218-224) with Sigma from tomofusion/chemistry/utils/fusion_helper.py:5-32.
+Follows tomofusion/chemistry/utils/multimodal.cpp (poisson_ml :277-304, rescale :307-328, SIRT / SART :339-412, fuse :425-441,
+data_fusion :452-491, tv_gd_4D :494, data_distance :218-224) with Sigma from tomofusion/chemistry/utils/fusion_helper.py:5-32.
 The reference's FP / BP / SIRT are ASTRA calls (absent, un-pinned): here they are the parallelRay matrix products
 and the normalised SIRT of oracle/tomo_oracle.c (orc_forward, orc_back, orc_sirt_norm), so everything that passes
 through them is parity-unpinned; the element-wise fusion maths is restated line by line in float32.
@@ -66,13 +66,17 @@ class multimodal:
         self.recon = np.maximum(self.recon - (F(lamC) / self.L_Aps) * upd, 0).astype(F)
         return cost
 
-    def data_fusion(self, lamH, lamC, nIter):
+    def data_fusion(self, lamH, lamC, nIter, method="SIRT"):
         m = self.model()
         self.g = self._fp(self.H, m)
-        # fuse(): nIter normalised SIRT steps (min-constraint 0) started from the model volume, data bh
+        # fuse(): nIter normalised SIRT steps (min-constraint 0) started from the model volume, data bh   multimodal.cpp:339-358;
+        # sart_data_fusion: ONE SART sweep (run(Nproj * 1), relaxation 1) from the same start            multimodal.cpp:377-396
         self.H.set_tilt_series(self.bh)
         self.H.recon[:] = m
-        self.H.SIRT_norm(nIter)
+        if method == "SIRT":
+            self.H.SIRT_norm(nIter)
+        else:
+            self.H.SART(1.0, nIter)
         d = (self.H.recon - m).astype(F)
         x = self.recon
         upd, costC = self._chem_update(True)
@@ -108,6 +112,25 @@ class multimodal:
             self.C.recon[:] = self.recon[e]
             self.C.SIRT_norm(n)
             self.recon[e] = self.C.recon
+
+    def chemical_SART(self, n):
+        """multimodal.cpp:399-412: per element and slice, run(Nproj * n) single-angle SART updates on bChem_e."""
+        for e in range(self.Nel):
+            self.C.set_tilt_series(self.bChem[e])
+            self.C.recon[:] = self.recon[e]
+            self.C.SART(1.0, n)
+            self.recon[e] = self.C.recon
+
+    def tv_gd_4D(self, ng, lam, eps=1e-6):
+        """multimodal.cpp:494,548 -> chemistry/utils/regularizers/tv_gd.cu:208-296: per element ng normalised descent steps
+        of length lam + positivity; the summed TV before descent."""
+        tv = 0.0
+        self.C.tv_eps = eps
+        for e in range(self.Nel):
+            self.C.recon[:] = self.recon[e]
+            tv += self.C.tv_gd(ng, lam)
+            self.recon[e] = self.C.recon
+        return tv
 
     def tv_fgp_4D(self, ng, lam):
         tv = 0.0

@@ -2,7 +2,9 @@
 slab engine (torch-owned scalar/halo buffers bound into the C ABI, engine on torch's stream, all-reduce on the
 device scalar between the TV gradient and update kernels).  The second sharded engine FORCES the real collectives in the
 one-rank group (all_reduce, broadcast, batch_isend_irecv to itself, all_gather_into_tensor, gather): the RCCL calls, tensor
-devices and stream ordering of the N > 1 path, on the only GPU a test box has."""
+devices and stream ordering of the N > 1 path, on the only GPU a test box has.  Round 3: engines 2 and 3 run their collectives
+NATIVELY (tomo_comm_*: ncclGroups issued by libtomo_hip.so on the engine's stream, self-sends in the one-rank group), engine 4
+through torch.distributed; all four must agree."""
 import os
 import sys
 
@@ -28,8 +30,16 @@ N, P, Nx = 32, 7, 70
 ang = np.deg2rad(np.linspace(-60, 60, P))
 x = ellipsoids(Nx, N, seed=5)
 res = []
+def torch_collectives():
+    """the same sharded engine with its collectives through torch.distributed instead of the library's own RCCL groups"""
+    t = multigpuengine(Nx, N, ang, force_collectives=True)
+    assert t.be.native                      # the native communicator exists ...
+    t.use_native_comm = False               # ... and is left unused
+    return t
+
+
 for make in (lambda: tomoengine(Nx, N, ang), lambda: multigpuengine(Nx, N, ang),
-             lambda: multigpuengine(Nx, N, ang, force_collectives=True)):
+             lambda: multigpuengine(Nx, N, ang, force_collectives=True), torch_collectives):
     t = make()
     t.set_volume(x, VOL_ORIGINAL)
     t.create_projections()

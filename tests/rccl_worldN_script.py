@@ -56,15 +56,20 @@ vol = rec.tomo.get_volume()
 vol0 = rec.tomo.get_volume(dst=0)
 assert (vol0 is None) == (rank != 0)
 
-# one communication round per TV step == two rounds, bit for bit; fused FGP == pair
+# the library's own RCCL groups (default) == the torch.distributed collectives; one communication round per TV step == two
+# rounds, bit for bit; fused FGP == pair
+assert t.be.native
 outs = {}
-for one_round in (True, False):
-    t.tv_one_round = one_round
+for one_round in (True, False, "torch"):
+    t.use_native_comm = one_round != "torch"
+    t.tv_one_round = bool(one_round)
     t.set_volume(vol)
     t.copy_recon()
     tv0, dg = t.tv_gd_tracked(4, 0.3)
     outs[one_round] = (tv0, dg, t.get_volume())
+t.use_native_comm = True
 assert outs[True][0] == outs[False][0] and np.array_equal(outs[True][2], outs[False][2])
+assert outs[True][0] == outs["torch"][0] and outs[True][1] == outs["torch"][1] and np.array_equal(outs[True][2], outs["torch"][2])
 fg = {}
 for fused in (True, False):
     t.fgp_fused = fused

@@ -78,6 +78,39 @@ def test_chemical_sirt_and_accessors(gpu):
         dev.set_chem_tilt_series(np.zeros((2, 3)))
 
 
+def test_sart_data_fusion_chemical_sart_and_tv_gd_4d(gpu):
+    """The SART branches of the fused engine and its 4-D TV descent against the oracle (multimodal.cpp:377-412 SART /
+    chemical_SART, :452-491 data_fusion with the SART fuse step, :494,548 tv_gd_4D)."""
+    dev, ref, gt = make_case(N=32, Nx=6, Ph=9, Pc=7, Nel=2, gamma=1.6)
+    dev.chemical_SART(2)
+    ref.chemical_SART(2)
+    assert rel_l2(dev.get_volume(), ref.recon) < TOL
+    dev.rescale_projections()
+    ref.rescale_projections()
+    for it in range(3):
+        (h_dev, c_dev), (h_ref, c_ref) = dev.sart_data_fusion(10, 0.05), ref.data_fusion(10, 0.05, 1, method="SART")
+        assert abs(h_dev - h_ref) <= 2e-5 * h_ref and abs(c_dev - c_ref) <= 2e-5 * abs(c_ref), it
+        assert rel_l2(dev.get_volume(), ref.recon) < 2e-5, it
+    tv_dev, tv_ref = dev.tv_gd(3, 0.05), ref.tv_gd_4D(3, 0.05, eps=dev.ce.tv_eps)
+    assert abs(tv_dev - tv_ref) <= 2e-5 * tv_ref
+    assert rel_l2(dev.get_volume(), ref.recon) < 2e-5
+    assert dev.get_volume().min() >= 0
+
+
+def test_model_of_a_start_volume_with_negative_and_zero_voxels(gpu):
+    """Sigma x^gamma for a caller-supplied volume with negative voxels and an integer gamma is what numpy's ** gives
+    (multimodal.cpp:425-427 uses Eigen's pow), not NaN; 0^gamma = 0."""
+    dev, ref, gt = make_case(gamma=2.0)
+    x = (gt - np.float32(0.2)).astype(np.float32)
+    x[:, :, :4] = 0
+    dev.set_volume(x)
+    dev._mm_model()
+    got = dev.he.get_volume(dev.MODEL)
+    want = sum(np.float32(dev.w[e]) * x[e] ** 2 for e in range(x.shape[0]))
+    assert np.isfinite(got).all() and (x < 0).any()
+    assert rel_l2(got, want) < 1e-6
+
+
 def test_chemicaltomo_driver_runs_and_reduces_costs(gpu):
     """ChemicalTomo.data_fusion end to end (chemistry/reconstructor.py:182-225) on a small synthetic sample."""
     N, Nx, P = 32, 6, 11

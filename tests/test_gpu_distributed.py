@@ -13,3 +13,16 @@ def test_rccl_world1_plumbing_matches_single_engine(gpu):
     p = subprocess.run([sys.executable, os.path.join(HERE, "nccl_world1_script.py")], env=env, capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0 and "NCCL_WORLD1_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_c_host_shards_through_the_native_communicator(gpu, tmp_path):
+    """tests/native/comm_host.c: a plain C program (no Python, no torch) drives the slab-sharded calls of include/tomo_hip.h
+    (tomo_comm_init / tomo_comm_tv_gd / tomo_comm_read_scalars ...) on a one-rank RCCL communicator and must reproduce the
+    single-slab calls bit for bit.  (mpi_ctvlib.cpp:400-422,455,547 is the host it stands in for.)"""
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "comm_host")
+    libdir = os.path.join(root, "tomo_tv_amd")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", os.path.join(HERE, "native", "comm_host.c"), "-o", exe, "-L", libdir, "-ltomo_hip",
+                    "-lm", "-Wl,-rpath," + libdir], check=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "COMM_HOST_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

@@ -134,7 +134,7 @@ def test_tv_gd_three_kernel_forms_agree_at_full_size(tvbig):
         tv0 = t.tv_gd(3, 1.0)
         res[form] = (tv0, t.get_volume())
     t.set_option("tv_lds", 1)
-    assert np.array_equal(res[1][1], res[8][1]) and res[1][0] == res[8][0]
+    assert np.array_equal(res[1][1], res[8][1]) and abs(res[1][0] - res[8][0]) <= 1e-12 * res[8][0]   # (fp64 block sums in arrival order)
     assert rel_l2(res[1][1], res[0][1]) < 1e-6 and abs(res[1][0] - res[0][0]) <= 1e-6 * res[0][0]
     assert res[1][1].min() >= 0 and 0 < rel_l2(res[1][1], x) < 1e-2       # a real step was taken; positivity held
     assert t.tv() < res[1][0]                                               # and it lowered the TV

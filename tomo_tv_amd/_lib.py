@@ -113,6 +113,16 @@ SIGNATURES = {
     "tomo_mm_model": [_p, _p, _i, _p, _f, _p, _i],
     "tomo_mm_update": [_p, _p, _p, _i, _p, _f, _f, _f, _p, _i, _i],
     "tomo_sart_chain_count": [_p, ctypes.POINTER(_i)],
+    "tomo_comm_unique_id": [_p],
+    "tomo_comm_init": [_p, _p, _i, _i],
+    "tomo_comm_share": [_p, _p],
+    "tomo_comm_destroy": [_p],
+    "tomo_comm_info": [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)],
+    "tomo_comm_exchange_halo": [_p, _i],
+    "tomo_comm_read_scalars": [_p, _p, _i],
+    "tomo_comm_scalars_snapshot": [_p],
+    "tomo_comm_tv_gd": [_p, _i, _f, _f, _i, _i],
+    "tomo_comm_fgp_exchange": [_p],
     "tomo_profile_enable": [_p, _i, _i],
     "tomo_profile_read": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
     "tomo_profile_read2": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

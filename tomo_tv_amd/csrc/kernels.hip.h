@@ -1472,7 +1472,14 @@ struct MMArgs { float *x[MM_MAX_EL]; float *u[MM_MAX_EL]; float w[MM_MAX_EL]; in
 // x^g for x >= 0 (the tomograms are clamped at zero) as exp2(g log2 x): the correctly rounded powf costs ~60 vector
 // instructions per element and made the two fusion kernels 4x slower than their memory traffic (1.2 ms per pass at 2 x 512^3);
 // this form is good to ~2e-6 relative at |g log2 x| <= 20, 0 -> 0 for g > 0 (log2 0 = -inf, exp2 -inf = 0).
-__device__ __forceinline__ float pow_pos(float x, float g) { return exp2f(g * log2f(x)); }
+// Domain: the fast path serves x > 0 (tomograms are clamped after every update); x == 0 and x < 0 (a caller-supplied start
+// volume with negative voxels, an integer gamma) take powf's value exactly as numpy's ** / std::pow in the reference would
+// (exp2(g log2 x) alone returned NaN there and for 0^0).  The slow branch is taken per lane only where needed.
+__device__ __forceinline__ float pow_pos(float x, float g)
+{
+    if (__builtin_expect(x > 0.f, 1)) return exp2f(g * log2f(x));
+    return x == 0.f ? (g == 0.f ? 1.f : (g > 0.f ? 0.f : INFINITY)) : powf(x, g);
+}
 __device__ __forceinline__ f4 pow4(f4 v, float g)
 {
     f4 r; r.x = pow_pos(v.x, g); r.y = pow_pos(v.y, g); r.z = pow_pos(v.z, g); r.w = pow_pos(v.w, g); return r;
@@ -1706,14 +1713,39 @@ __global__ __launch_bounds__(256) void k_tv_grad(const float *__restrict__ x, Ha
 // The gradient value from its thirteen inputs, with every rounding written out (explicit fma / mul / sub): the march kernels
 // are instantiated in several modes (store / norm only / recompute-and-update; LDS or register march) and the compiler's
 // contraction choices differ between instantiations -- this keeps all of them bit-identical.
+// A product / sum / difference that keeps ITS OWN rounding.  HIP's __fmul_rn / __fadd_rn / __fsub_rn are plain * + - (see
+// __clang_hip_math.h) and device code is compiled with -ffp-contract=fast-honor-pragmas: a*b + c written with them is fused into
+// one FMA wherever the instruction selector likes, differently in every kernel that inlines the expression (round 3 found the
+// three march forms an ulp apart that way).  The pragma takes the `contract` flag off these instructions, inlined or not.
+__device__ __forceinline__ float nc_mul(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float nc_add(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float nc_sub(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 __device__ __forceinline__ float tv_gval(float c, float xip, float xjp, float xkp, float r0, float xim, float rim,
                                           float xjm, float rjm, float xkm, float rkm)
 {
-    float v1n = __fsub_rn(__fsub_rn(__fmaf_rn(3.0f, c, -xip), xjp), xkp);
-    float gv = __fmul_rn(v1n, r0);
-    gv = __fmaf_rn(__fsub_rn(c, xim), rim, gv);
-    gv = __fmaf_rn(__fsub_rn(c, xjm), rjm, gv);
-    gv = __fmaf_rn(__fsub_rn(c, xkm), rkm, gv);
+    // Round 3: the four terms are four ROUNDED products added left to right -- the structure of the reference's
+    // v1n/v1d + v2n/v2d + v3n/v3d + v4n/v4d (ctvlib.cpp:431-447; round 2 chained FMAs) -- which is what lets the register march
+    // take the three backward terms from where they are cheapest: (c - x_im) R(p-i) is the product (x_ip - c) R formed at the
+    // neighbouring slice (one lane shift of a product instead of two shifts of its factors), (c - x_jm) R(p-j) the product formed
+    // one row earlier, (c - x_km) R(p-k) the one formed one column earlier.  Same operands, same roundings: bit-identical.
+    float v1n = nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), xjp), xkp);
+    float gv = nc_mul(v1n, r0);
+    gv = nc_add(gv, nc_mul(nc_sub(c, xim), rim));
+    gv = nc_add(gv, nc_mul(nc_sub(c, xjm), rjm));
+    gv = nc_add(gv, nc_mul(nc_sub(c, xkm), rkm));
     return gv;
 }
 
@@ -2083,7 +2115,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 // Overlapping chunks (a wave loads 64 slices and owns the 62 in the middle, so every slice shift is a plain DPP: no packed edge
 // values, no readlane fix-ups, no phantom R; 71-78 VGPRs): fewer instructions but 475 against 429 us at 512 slices and 103 against
 // 76 at 64 -- the misaligned 248-byte rows and the extra chunk cost more than the ~20 % of vector instructions they save.
-template <int TZ, bool WITH_TV, int MODE>
+template <int TZ, bool WITH_TV, int MODE, bool EDGE, bool TRACK = false, bool STREAM = false>
 __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, Halo h, double *__restrict__ part, float eps,
                                                     int n, int nx, int sx, int yseg, double *__restrict__ part_tv, TvUpd up)
 {
@@ -2111,26 +2143,48 @@ __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, 
         int zl;
         { int z = (z0 - 1 + (lane < TZ + 2 ? lane : 0)) % n; zl = z < 0 ? z + n : z; }
         auto yrow = [&](int y) { int r = y % n; return r < 0 ? r + n : r; };
-        const bool interior = s0 > 0 && s0 + 64 < nx;
-        float rows[4][TZ + 2], Ra[TZ + 1], Rb[TZ + 1];
+        float rows[4][TZ + 2], Ta[TZ + 1], Tb[TZ + 1];     // Ta / Tb: the -y terms (x_jp - c) R of the previous row, alternating
         float pe[4], pf[4], pc[4];          // packed edge values of the row in slot k: slices s0-1, s0+64, s0
+        // EDGE = false (the launcher picks the instantiation when the slab is a multiple of 64 slices and the image side a
+        // multiple of TZ -- every BASELINE shape): every lane of every wave owns a voxel, so the row carries NO predicate and no
+        // branch: the columns load straight from the volume through a row pointer formed once per row, whether the slice below /
+        // above the chunk is a neighbour's halo plane is a wave-uniform question answered ONCE (scalar select of the base pointer,
+        // hoisted per-lane offset), the eight results of a row are stored back to back after the arithmetic, and the wrap planes
+        // are written by the two chunks that hold them.  Round 2 predicated every column (s_and_saveexec + s_cbranch_execz + a
+        // join per column: ~25 tiny basic blocks per row, which also kept the scheduler from filling the DPP / readlane hazard
+        // slots: 28 s_nop per row) and sent every load of a chunk touching the slab's first or last slice -- on a 64- or 128-slice
+        // slab: all of them -- through a per-lane three-way address select (~8 vector instructions per load).
+        // EDGE = true keeps the predicated per-lane form for everything else (ragged last chunk, partial last z block).
+        const bool lo_in = s0 > 0, hi_in = s0 + 64 < nx;
+        const unsigned zls = (unsigned)zl * (unsigned)sx;
+        const unsigned off_lo = lo_in ? zls + (unsigned)(s0 - 1) : (unsigned)zl, off_hi = hi_in ? zls + (unsigned)(s0 + 64) : (unsigned)zl;
+        unsigned zcs[TZ + 2];
+#pragma unroll
+        for (int j = 0; j < TZ + 2; ++j) zcs[j] = (unsigned)zc[j] * (unsigned)sx + (unsigned)s0;
         auto fetch = [&](int y, float *c, float &e_lo, float &e_hi, float &e_c) __attribute__((always_inline)) {
             int yy = yrow(y) * n;
-            if (interior) {
+            if (!EDGE) {
+                const float *rowp = x + (size_t)yy * sx;            // wave-uniform
 #pragma unroll
-                for (int j = 0; j < TZ + 2; ++j) c[j] = (x + (size_t)(yy + zc[j]) * sx)[(unsigned)s];
+                for (int j = 0; j < TZ + 2; ++j) c[j] = (rowp + zcs[j])[(unsigned)lane];
+                e_c = rowp[zls + (unsigned)s0];
+                e_lo = (lo_in ? rowp : h.lo + yy)[off_lo];
+                e_hi = (hi_in ? rowp : h.hi + yy)[off_hi];
             } else {
 #pragma unroll
                 for (int j = 0; j < TZ + 2; ++j) c[j] = tv_ld(x, h, yy + zc[j], s, nx, sx);
+                e_lo = tv_ld(x, h, yy + zl, s0 - 1, nx, sx);
+                e_hi = tv_ld(x, h, yy + zl, s0 + 64, nx, sx);
+                e_c = tv_ld(x, h, yy + zl, s0, nx, sx);
             }
-            e_lo = tv_ld(x, h, yy + zl, s0 - 1, nx, sx);
-            e_hi = tv_ld(x, h, yy + zl, s0 + 64, nx, sx);
-            e_c = tv_ld(x, h, yy + zl, s0, nx, sx);
         };
-#define TV4_RINV(C, IP, JP, KP, RR, DD)                                                                   \
+        const float vmin = up.clamp ? 0.f : -INFINITY;              // positivity as one v_max whatever the flag
+        const bool planes = up.wrap_lo != nullptr && (EDGE || s0 == 0 || s0 + 64 == nx);   // this chunk holds slice 0 or nx-1
+        // R = 1/sqrt(q) with the three differences it is made of left in D1..D3 (they are the numerators of the backward terms)
+#define TV4_RINV(C, IP, JP, KP, RR, DD, D1, D2, D3)                                                       \
         {                                                                                                 \
-            float d1_ = (C) - (IP), d2_ = (C) - (JP), d3_ = (C) - (KP);                                   \
-            float q_ = __fmaf_rn(d3_, d3_, __fmaf_rn(d2_, d2_, __fmaf_rn(d1_, d1_, eps)));                \
+            D1 = (C) - (IP); D2 = (C) - (JP); D3 = (C) - (KP);                                            \
+            float q_ = __fmaf_rn(D3, D3, __fmaf_rn(D2, D2, __fmaf_rn(D1, D1, eps)));                      \
             RR = tv_rsqrt(q_);                                                                            \
             DD = __fmul_rn(q_, RR);                                                                       \
         }
@@ -2143,76 +2197,100 @@ __global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, 
         auto col = [&](float packed, int j) {                   // column j's value of a packed register, wave-uniform
             return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, packed), j));
         };
-        // one row: cm / c0 / cp = rows y-1, y, y+1; cn receives row y+2; Rp = R of row y-1, Rc receives R of row y
-        auto row = [&](int y, const float *cm, const float *c0, const float *cp, float *cn, float pe0, float pf0, float pc0, float pep,
-                       float &pen, float &pfn, float &pcn, const float *Rp, float *Rc) __attribute__((always_inline)) {
+        // one row: c0 / cp = rows y, y+1; cn receives row y+2; Tp = the -y terms formed in row y-1, Tn receives this row's.
+        // (tv_gval's expression, term by term: G1 = v1n R(p); t2 = (x_ip - c) R of the slice below, shifted in; Tp; Tk of column j-1)
+        auto row = [&](int y, const float *c0, const float *cp, float *cn, float pe0, float pf0, float pc0, float pep,
+                       float &pen, float &pfn, float &pcn, const float *Tp, float *Tn) __attribute__((always_inline)) {
             if (y + 1 < y1) fetch(y + 2, cn, pen, pfn, pcn);    // in flight while this row is computed
-            float REp, ddp;
-            {   // R at the phantom slice s0-1, all columns at once (lane j <- column j)
-                float kp = shl(0.f, pe0);                       // column j+1 (wave shift: the packed columns may pass lane 15)
-                TV4_RINV(pe0, pc0, pep, kp, REp, ddp)
-                (void)ddp;
+            float TEp;
+            {   // the slice-direction term for lane 0, all columns at once (lane j <- column j): (x[s0] - x[s0-1]) R(s0-1)
+                float kp = shl(0.f, pe0), r_, dd_, d1, d2, d3;  // column j+1 (wave shift: the packed columns may pass lane 15)
+                TV4_RINV(pe0, pc0, pep, kp, r_, dd_, d1, d2, d3)
+                (void)dd_; (void)d2; (void)d3;
+                TEp = nc_mul(d1, r_);                           // = -(x[s0] - x[s0-1]) R(s0-1): the terms are kept negated ...
             }
-            float xip[TZ + 1];
+            float G1[TZ + 1], Ti[TZ + 1], Tk[TZ + 1];
 #pragma unroll
             for (int j = 0; j <= TZ; ++j) {
-                float dd;
-                xip[j] = shl(col(pf0, j), c0[j]);
-                TV4_RINV(c0[j], xip[j], cp[j], c0[j + 1], Rc[j], dd)
-                if (WITH_TV && j >= 1 && z0 + j - 1 < n && s < nx) tvacc += (double)dd;
+                float dd, d1, d2, d3, r;
+                const float c = c0[j], xip = shl(col(pf0, j), c);
+                TV4_RINV(c, xip, cp[j], c0[j + 1], r, dd, d1, d2, d3)
+                if (WITH_TV && j >= 1) tvacc += (double)((!EDGE || (z0 + j - 1 < n && s < nx)) ? dd : 0.f);
+                Tk[j] = nc_mul(d3, r);                          // -(x_kp - c) R: minus the -z term of column j+1
+                if (j >= 1) {
+                    Ti[j] = nc_mul(d1, r);                      // -(x_ip - c) R: minus the -slice term of the lane above
+                    Tn[j] = nc_mul(d2, r);                      // -(x_jp - c) R: minus the -y term of the next row
+                    G1[j] = nc_mul(nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), cp[j]), c0[j + 1]), r);
+                }
             }
+            float out[TZ + 1];                                  // the row's results: g (norm pass) or x_new (update pass)
 #pragma unroll
             for (int j = 1; j <= TZ; ++j) {
-                float rim = shr(col(REp, j), Rc[j]);
-                float xim = shr(col(pe0, j), c0[j]);
-                float c = c0[j];
-                float gv = tv_gval(c, xip[j], cp[j], c0[j + 1], Rc[j], xim, rim, cm[j], Rp[j], c0[j - 1], Rc[j - 1]);
-                int z = z0 + j - 1;
-                if (z < n && s < nx) {
-                    if (MODE == TVM_NORM) {
-                        acc += (double)(gv * gv);
-                        if (up.wrap_lo) {      // slab-sharded descent: the gradient's first / last slice for the neighbours
-                            const size_t pix = (size_t)(y * n + z);
-                            if (s == 0) up.wrap_hi[pix] = gv;
-                            if (s == nx - 1) up.wrap_lo[pix] = gv;
-                        }
-                    } else {   // TVM_UPDATE: the expression of k_tv_update
-                        const size_t pix = (size_t)(y * n + z);
-                        float v = tv_step(c, gv, nrm_);
-                        if (up.clamp) v = fmaxf(v, 0.f);
-                        if (up.stream) __builtin_nontemporal_store(v, up.x_out + pix * sx + (unsigned)s);
-                        else up.x_out[pix * sx + (unsigned)s] = v;
-                        if (up.wrap_lo) {
-                            if (s == 0) up.wrap_hi[pix] = v;
-                            if (s == nx - 1) up.wrap_lo[pix] = v;
-                        }
-                        if (up.track) {
-                            float *tr = up.track + pix * sx;
-                            float d = v - tr[(unsigned)s];
-                            acc += (double)(d * d);
-                            if (up.stream) __builtin_nontemporal_store(v, tr + (unsigned)s);
-                            else tr[(unsigned)s] = v;
-                        }
+                float t2 = shr(col(TEp, j), Ti[j]);
+                float gv = nc_sub(nc_sub(nc_sub(G1[j], t2), Tp[j]), Tk[j - 1]);   // ... and subtracted: a - (-t) == a + t, bit for bit
+                const bool ok = !EDGE || (z0 + j - 1 < n && s < nx);
+                if (MODE == TVM_NORM) {
+                    out[j] = gv;
+                    float g2 = gv * gv;
+                    acc += (double)(ok ? g2 : 0.f);
+                } else {
+                    out[j] = fmaxf(tv_step(c0[j], gv, nrm_), vmin);   // the expression of k_tv_update
+                }
+            }
+            const size_t pix0 = (size_t)(y * n + z0);                 // wave-uniform
+            if (MODE == TVM_UPDATE) {
+                float *xo = up.x_out + pix0 * sx + (unsigned)s0;
+#pragma unroll
+                for (int j = 1; j <= TZ; ++j) {
+                    if (EDGE && !(z0 + j - 1 < n && s < nx)) continue;
+                    float *q = xo + (size_t)(j - 1) * sx;
+                    if (STREAM) __builtin_nontemporal_store(out[j], q + (unsigned)lane);
+                    else q[(unsigned)lane] = out[j];
+                }
+                if (TRACK) {
+                    float *tr = up.track + pix0 * sx + (unsigned)s0;
+                    float told[TZ + 1];
+#pragma unroll
+                    for (int j = 1; j <= TZ; ++j) told[j] = (!EDGE || (z0 + j - 1 < n && s < nx)) ? (tr + (size_t)(j - 1) * sx)[(unsigned)lane] : out[j];
+#pragma unroll
+                    for (int j = 1; j <= TZ; ++j) {
+                        float d = out[j] - told[j];
+                        acc += (double)(d * d);
+                        if (EDGE && !(z0 + j - 1 < n && s < nx)) continue;
+                        float *q = tr + (size_t)(j - 1) * sx;
+                        if (STREAM) __builtin_nontemporal_store(out[j], q + (unsigned)lane);
+                        else q[(unsigned)lane] = out[j];
                     }
+                }
+            }
+            if (planes) {      // the result's first / last slice: the wrap planes (single slab) or what the neighbours receive (sharded)
+                if (s == 0) {                                       // one lane, the row's eight values back to back
+#pragma unroll
+                    for (int j = 1; j <= TZ; ++j) if (!EDGE || z0 + j - 1 < n) up.wrap_hi[pix0 + (j - 1)] = out[j];
+                }
+                if (s == nx - 1) {
+#pragma unroll
+                    for (int j = 1; j <= TZ; ++j) if (!EDGE || z0 + j - 1 < n) up.wrap_lo[pix0 + (j - 1)] = out[j];
                 }
             }
         };
         fetch(y0 - 1, rows[0], pe[0], pf[0], pc[0]);
         fetch(y0, rows[1], pe[1], pf[1], pc[1]);
         fetch(y0 + 1, rows[2], pe[2], pf[2], pc[2]);
-        // R of row y0-1 for the output columns (its +y neighbour is row y0)
+        // the -y terms of row y0: (x(y0) - x(y0-1)) R(row y0-1) for the output columns
 #pragma unroll
         for (int j = 1; j <= TZ; ++j) {
-            float xi = shl(col(pf[0], j), rows[0][j]), dd;
-            TV4_RINV(rows[0][j], xi, rows[1][j], rows[0][j + 1], Ra[j], dd)
-            (void)dd;
+            float xi = shl(col(pf[0], j), rows[0][j]), r, dd, d1, d2, d3;
+            TV4_RINV(rows[0][j], xi, rows[1][j], rows[0][j + 1], r, dd, d1, d2, d3)
+            (void)dd; (void)d1; (void)d3;
+            Ta[j] = nc_mul(d2, r);
         }
-#define TV4_ROW(SM, S0, SP, SN, RP, RC) row(y, rows[SM], rows[S0], rows[SP], rows[SN], pe[S0], pf[S0], pc[S0], pe[SP], pe[SN], pf[SN], pc[SN], RP, RC)
+#define TV4_ROW(S0, SP, SN, TP, TN) row(y, rows[S0], rows[SP], rows[SN], pe[S0], pf[S0], pc[S0], pe[SP], pe[SN], pf[SN], pc[SN], TP, TN)
         for (int y = y0; y < y1;) {
-            TV4_ROW(0, 1, 2, 3, Ra, Rb); if (++y >= y1) break;
-            TV4_ROW(1, 2, 3, 0, Rb, Ra); if (++y >= y1) break;
-            TV4_ROW(2, 3, 0, 1, Ra, Rb); if (++y >= y1) break;
-            TV4_ROW(3, 0, 1, 2, Rb, Ra); ++y;
+            TV4_ROW(1, 2, 3, Ta, Tb); if (++y >= y1) break;
+            TV4_ROW(2, 3, 0, Tb, Ta); if (++y >= y1) break;
+            TV4_ROW(3, 0, 1, Ta, Tb); if (++y >= y1) break;
+            TV4_ROW(0, 1, 2, Tb, Ta); ++y;
         }
 #undef TV4_ROW
 #undef TV4_RINV

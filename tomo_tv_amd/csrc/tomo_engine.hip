@@ -8,7 +8,11 @@
 #include "kernels.hip.h"
 #include "sysmat.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <functional>
@@ -94,6 +98,9 @@ struct ChainHelper {
     }
 };
 
+struct CommRef;
+struct tomo_engine;
+static void comm_release(tomo_engine *e);
 struct tomo_engine {
     int nx = 0, n = 0, np = 0, sx = 0, sxc = 0, vec = 1, device = 0;   // sx = row pitch, sxc = computed width
     int64_t npix = 0, nrows = 0, nnz = 0;
@@ -198,6 +205,10 @@ struct tomo_engine {
     hipStream_t aux = nullptr;                    // second stream for work that is independent of the main sequence
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool async_pending = false;
+    struct CommRef *comm = nullptr;               // native RCCL communicator (tomo_comm_init / tomo_comm_share); see the comm section
+    float *comm_send_first = nullptr, *comm_send_last = nullptr, *comm_g_lo = nullptr, *comm_g_hi = nullptr;   // N*N planes
+    float *comm_fgp = nullptr;                    // the engine's own planes of the fused FGP exchange when the host binds none
+    double *comm_scal = nullptr;                  // TOMO_S_COUNT doubles: the all-reduced copy of the scalar buffer
     bool old_is_recon = false;                    // RECON_OLD's content is RECON's (tomo_fista_momentum; see get_vol)
     bool geometry_released = false;               // tomo_release_geometry: only tomo_adopt_volumes / tomo_destroy remain valid
     // halos
@@ -950,6 +961,7 @@ int tomo_destroy(tomo_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (int u = 0; u < tomo_engine::MAX_CHAINS; ++u) if (e->sub_stream[u]) { (void)hipStreamSynchronize(e->sub_stream[u]); (void)hipStreamDestroy(e->sub_stream[u]); (void)hipEventDestroy(e->ev_sjoin[u]); }
+    comm_release(e);
     if (e->ev_sfork) (void)hipEventDestroy(e->ev_sfork);
     if (e->ev_peer) (void)hipEventDestroy(e->ev_peer);
     if (e->ev_snap) (void)hipEventDestroy(e->ev_snap);
@@ -1950,8 +1962,11 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv, float *g_first 
             } else {
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
             if (e->tv_march4) {
-                if (with_tv) hipLaunchKernelGGL((k_tv_march4<8, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, gp);
-                else hipLaunchKernelGGL((k_tv_march4<8, false, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, gp);
+                const bool edge = e->nx % 64 != 0 || e->n % 8 != 0;      // lanes without a voxel exist: the predicated form
+#define TV4_NORM(WTV, EDGE, PTV) hipLaunchKernelGGL((k_tv_march4<8, WTV, TVM_NORM, EDGE>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, PTV, gp)
+                if (with_tv) { if (edge) TV4_NORM(true, true, e->d_part_tv); else TV4_NORM(true, false, e->d_part_tv); }
+                else { if (edge) TV4_NORM(false, true, (double *)nullptr); else TV4_NORM(false, false, (double *)nullptr); }
+#undef TV4_NORM
             }
             else if (with_tv) hipLaunchKernelGGL((k_tv_grad_reg<8, true, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, gp);
             else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_NORM>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, gp);
@@ -2065,7 +2080,13 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
                 hipLaunchKernelGGL((k_tv_grad_reg<4, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
             } else {
             dim3 grid(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg));
-            if (e->tv_march4) hipLaunchKernelGGL((k_tv_march4<8, false, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
+            if (e->tv_march4) {
+                const bool edge = e->nx % 64 != 0 || e->n % 8 != 0, trk = track != nullptr, strm = up.stream != 0;
+#define TV4_UPD(EDGE, TRK, STRM) hipLaunchKernelGGL((k_tv_march4<8, false, TVM_UPDATE, EDGE, TRK, STRM>), grid, dim3(256), 0, e->stream, x, h, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up)
+                if (edge) { if (trk) { if (strm) TV4_UPD(true, true, true); else TV4_UPD(true, true, false); } else { if (strm) TV4_UPD(true, false, true); else TV4_UPD(true, false, false); } }
+                else { if (trk) { if (strm) TV4_UPD(false, true, true); else TV4_UPD(false, true, false); } else { if (strm) TV4_UPD(false, false, true); else TV4_UPD(false, false, false); } }
+#undef TV4_UPD
+            }
             else hipLaunchKernelGGL((k_tv_grad_reg<8, false, true, TVM_UPDATE>), grid, dim3(256), 0, e->stream, x, h, (float *)nullptr, e->d_part, e->tv_last_eps, e->n, e->nx, e->sx, yseg, (double *)nullptr, up);
             }
         }
@@ -2279,6 +2300,245 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
     e->is_first = f; e->is_last = l;
     if (rc) return rc;
     return tomo_fgp_end(e, iters);
+}
+
+
+// ---- native communicator: RCCL on the engine's own stream --------------------------------------------------------------------
+// The slab-sharded path needs, per ASD-POCS iteration: one ring exchange of halo planes, ten rounds of {all-reduce of ||g||^2 +
+// the gradient's boundary planes to the two neighbours}, and one all-reduce of the iteration's scalars (mpi_ctvlib.cpp:400-422
+// ring, :455,:547 MPI_Allreduce).  Through torch.distributed each of these is two collectives issued from Python on RCCL's own
+// stream with an event hop in and out: measured on a world-1 group ~100 us per round, 1.1 ms of a 5.3 ms step on the 64-slice
+// slab of an 8-GPU strong-scaling run.  Here a round is ONE ncclGroup (all-reduce + 2 sends + 2 receives = one RCCL kernel)
+// enqueued by this library on the engine's stream, so a whole sharded tv_gd is one C call with every launch stream-ordered and
+// no Python, no second stream, no event hop in between.  It also gives a C / C++ host a way to shard (the C ABI had
+// no communicator entry).  librccl is opened with dlopen on first use (the copy already in the process if there is one -- torch
+// ships its own), so single-GPU users never load it.
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return TOMO_OK;
+    void *h = nullptr;
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);     // the copy already in the process, if any
+    for (const char *nm : names) if (!h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(TOMO_ERR_STATE, std::string("librccl not found: ") + dlerror());
+#define RCCL_SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return fail(TOMO_ERR_STATE, "librccl lacks " name); } while (0)
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); RCCL_SYM(CommInitRank, "ncclCommInitRank"); RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(AllReduce, "ncclAllReduce"); RCCL_SYM(Send, "ncclSend"); RCCL_SYM(Recv, "ncclRecv");
+    RCCL_SYM(GroupStart, "ncclGroupStart"); RCCL_SYM(GroupEnd, "ncclGroupEnd"); RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+    g_rccl.lib = h;
+    return TOMO_OK;
+}
+#define NCCLCHK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail(TOMO_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+
+struct CommRef {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    std::atomic<int> refs{1};
+};
+
+static void comm_release(tomo_engine *e)
+{
+    if (!e->comm) return;
+    if (e->comm->refs.fetch_sub(1) == 1) {
+        if (e->comm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm->comm);
+        delete e->comm;
+    }
+    e->comm = nullptr;
+    if (e->comm_fgp && e->fgp_lo == e->comm_fgp) e->fgp_lo = e->fgp_hi = e->fgp_send_first = e->fgp_send_last = nullptr;
+    void *ptrs[] = {e->comm_send_first, e->comm_send_last, e->comm_g_lo, e->comm_g_hi, e->comm_scal, e->comm_fgp};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    e->comm_fgp = nullptr;
+    e->comm_send_first = e->comm_send_last = e->comm_g_lo = e->comm_g_hi = nullptr;
+    e->comm_scal = nullptr;
+}
+
+static int comm_buffers(tomo_engine *e)
+{
+    if (e->comm_scal) return TOMO_OK;
+    int rc;
+    float **planes[] = {&e->comm_send_first, &e->comm_send_last, &e->comm_g_lo, &e->comm_g_hi};
+    for (float **p : planes) if ((rc = dev_alloc((void **)p, e->npix * sizeof(float), true, e->stream))) return rc;
+    if (!e->fgp_lo) {        // a host that binds no planes of its own (tomo_bind_fgp_halo) gets the engine's: lo 1, hi 4, send_first 4, send_last 1
+        if ((rc = dev_alloc((void **)&e->comm_fgp, 10 * e->npix * sizeof(float), true, e->stream))) return rc;
+        e->fgp_lo = e->comm_fgp; e->fgp_hi = e->comm_fgp + e->npix; e->fgp_send_first = e->comm_fgp + 5 * e->npix; e->fgp_send_last = e->comm_fgp + 9 * e->npix;
+    }
+    return dev_alloc((void **)&e->comm_scal, TOMO_S_COUNT * sizeof(double), true, e->stream);
+}
+
+// ring exchange inside an open group: my last plane(s) -> next's lo, my first plane(s) -> prev's hi.  With prev == next (two
+// ranks) the two messages to the one peer match in posting order on both sides; with one rank they are self-sends.
+static int comm_ring(tomo_engine *e, const float *first, size_t nfirst, const float *last, size_t nlast, float *lo, float *hi)
+{
+    const CommRef *c = e->comm;
+    const int nxt = (c->rank + 1) % c->world, prv = (c->rank + c->world - 1) % c->world;
+    NCCLCHK(g_rccl.Send(last, nlast, ncclFloat32, nxt, c->comm, e->stream));
+    NCCLCHK(g_rccl.Send(first, nfirst, ncclFloat32, prv, c->comm, e->stream));
+    NCCLCHK(g_rccl.Recv(lo, nlast, ncclFloat32, prv, c->comm, e->stream));
+    NCCLCHK(g_rccl.Recv(hi, nfirst, ncclFloat32, nxt, c->comm, e->stream));
+    return TOMO_OK;
+}
+#define NEED_COMM(e) do { NEED(e); if (!(e)->comm) return fail(TOMO_ERR_STATE, "engine has no communicator (tomo_comm_init)"); { int rc_ = comm_buffers(e); if (rc_) return rc_; } } while (0)
+
+int tomo_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(TOMO_ERR_ARG, "null id buffer");
+    int rc = rccl_load(); if (rc) return rc;
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return TOMO_OK;
+}
+
+int tomo_comm_init(tomo_engine *e, const void *id128, int world, int rank)
+{
+    NEED(e);
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(TOMO_ERR_ARG, "bad communicator arguments");
+    int rc = rccl_load(); if (rc) return rc;
+    comm_release(e);
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    CommRef *c = new CommRef();
+    c->world = world; c->rank = rank;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);      // collective: every rank of the group calls it
+    if (r != ncclSuccess) { delete c; return fail(TOMO_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+    e->comm = c;
+    e->is_first = rank == 0; e->is_last = rank == world - 1;
+    return TOMO_OK;
+}
+
+int tomo_comm_share(tomo_engine *e, tomo_engine *other)
+{
+    NEED(e);
+    if (!other || !other->comm) return fail(TOMO_ERR_ARG, "the other engine has no communicator");
+    if (other->device != e->device) return fail(TOMO_ERR_ARG, "engines on different devices cannot share a communicator");
+    if (e->comm == other->comm) return TOMO_OK;
+    comm_release(e);
+    other->comm->refs.fetch_add(1);
+    e->comm = other->comm;
+    e->is_first = e->comm->rank == 0; e->is_last = e->comm->rank == e->comm->world - 1;
+    return TOMO_OK;
+}
+
+int tomo_comm_destroy(tomo_engine *e) { if (!e) return fail(TOMO_ERR_ARG, "null engine"); (void)hipSetDevice(e->device); if (e->stream) (void)hipStreamSynchronize(e->stream); comm_release(e); return TOMO_OK; }
+
+int tomo_comm_info(tomo_engine *e, int *world, int *rank)
+{
+    if (!e) return fail(TOMO_ERR_ARG, "null engine");
+    if (world) *world = e->comm ? e->comm->world : 0;
+    if (rank) *rank = e->comm ? e->comm->rank : 0;
+    return TOMO_OK;
+}
+
+// the field's boundary slices to the ring neighbours' halo planes (before a stencil pass): pack + one group
+int tomo_comm_exchange_halo(tomo_engine *e, int field)
+{
+    NEED_COMM(e);
+    int rc;
+    if ((rc = tomo_halo_pack_both(e, field, e->comm_send_first, e->comm_send_last))) return rc;
+    NCCLCHK(g_rccl.GroupStart());
+    rc = comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->halo_lo, e->halo_hi);
+    NCCLCHK(g_rccl.GroupEnd());
+    return rc;
+}
+
+// all slots of the scalar buffer summed over the ranks into a COPY (the buffer itself keeps this slab's partial sums), read back:
+// blocking form and the snapshot form of tomo_scalars_snapshot (collected by tomo_scalars_snapshot_read)
+static int comm_sum_scalars(tomo_engine *e)
+{
+    { int rc = tomo_async_wait(e); if (rc) return rc; }
+    HIPCHK(hipMemcpyAsync(e->comm_scal, e->d_scal, TOMO_S_COUNT * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    NCCLCHK(g_rccl.AllReduce(e->comm_scal, e->comm_scal, TOMO_S_COUNT, ncclFloat64, ncclSum, e->comm->comm, e->stream));
+    return TOMO_OK;
+}
+
+int tomo_comm_read_scalars(tomo_engine *e, double *out, int count)
+{
+    NEED_COMM(e);
+    if (!out || count < 0 || count > TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar count");
+    int rc = comm_sum_scalars(e); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, e->comm_scal, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return TOMO_OK;
+}
+
+int tomo_comm_scalars_snapshot(tomo_engine *e)
+{
+    NEED_COMM(e);
+    int rc = comm_sum_scalars(e); if (rc) return rc;
+    if (!e->h_snap) {
+        HIPCHK(hipHostMalloc((void **)&e->h_snap, TOMO_S_COUNT * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_snap, hipEventDisableTiming));
+    }
+    HIPCHK(hipMemcpyAsync(e->h_snap, e->comm_scal, TOMO_S_COUNT * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(e->ev_snap, e->stream));
+    e->snap_pending = true;
+    return TOMO_OK;
+}
+
+// slab-sharded tv_gd, whole call: the halo planes once, then per inner iteration the norm pass, ONE group {all-reduce of sum g^2
+// in place + the gradient's boundary planes round the ring}, the update pass and the halo planes advanced locally
+// (engine.py: _tv_descent_one_round is the same protocol over torch.distributed; bit-identical results).  TV before descent
+// stays in TOMO_S_TV as this slab's partial sum; track_vol < 0: plain tv_gd.
+int tomo_comm_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot)
+{
+    NEED_COMM(e);
+    int rc;
+    if ((rc = tomo_comm_exchange_halo(e, e->tv_target))) return rc;
+    if (ng <= 0) {
+        if ((rc = tomo_tv_partial(e, e->tv_target, eps)) || (rc = tomo_positivity(e, e->tv_target))) return rc;
+        if (track_vol >= 0) {
+            if ((rc = tomo_diff_norm_sq(e, e->tv_target, track_vol, slot))) return rc;
+            return tomo_copy_volume(e, track_vol, e->tv_target);
+        }
+        return TOMO_OK;
+    }
+    for (int g = 0; g < ng; ++g) {
+        if ((rc = tomo_tv_grad_planes(e, eps, g == 0, e->comm_send_first, e->comm_send_last))) return rc;
+        NCCLCHK(g_rccl.GroupStart());
+        ncclResult_t r = g_rccl.AllReduce(e->d_scal + TOMO_S_GNORM, e->d_scal + TOMO_S_GNORM, 1, ncclFloat64, ncclSum, e->comm->comm, e->stream);
+        rc = comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->comm_g_lo, e->comm_g_hi);
+        NCCLCHK(g_rccl.GroupEnd());
+        if (r != ncclSuccess) return fail(TOMO_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+        if (rc) return rc;
+        if (g == ng - 1) {
+            rc = track_vol >= 0 ? tomo_tv_update_tracked(e, dPOCS, 1, track_vol, slot) : tomo_tv_update(e, dPOCS, 1);
+            if (rc) return rc;
+        } else {
+            if ((rc = tomo_tv_update(e, dPOCS, 0))) return rc;                                   // reads the old halo planes ...
+            if ((rc = tomo_tv_halo_apply(e, dPOCS, 0, e->comm_g_lo, e->comm_g_hi))) return rc;  // ... which then follow the neighbours
+        }
+    }
+    return TOMO_OK;
+}
+
+// the exchange between two fused FGP iterations: send_last (P1 of my last slice) -> next's lo, send_first (A, P1, P2, P3 of my
+// first slice) -> prev's hi (tomo_bind_fgp_halo names the four buffers)
+int tomo_comm_fgp_exchange(tomo_engine *e)
+{
+    NEED_COMM(e);
+    if (!e->fgp_lo) return fail(TOMO_ERR_STATE, "slab-sharded fused FGP needs tomo_bind_fgp_halo");
+    NCCLCHK(g_rccl.GroupStart());
+    int rc = comm_ring(e, e->fgp_send_first, 4 * (size_t)e->npix, e->fgp_send_last, (size_t)e->npix, e->fgp_lo, e->fgp_hi);
+    NCCLCHK(g_rccl.GroupEnd());
+    return rc;
 }
 
 int tomo_set_option(tomo_engine *e, const char *name, int value)

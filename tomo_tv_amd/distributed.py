@@ -54,6 +54,13 @@ class SlabComm:
     def global_rank(self, r):
         return r if self.group is None else self.dist.get_global_rank(self.group, r)
 
+    def native_ok(self):
+        """True when the engine may run its collectives itself: RCCL from ``libtomo_hip.so`` on the engine's stream
+        (``tomo_comm_*``: one ncclGroup per communication round, no second stream, no Python between the kernels) instead of
+        ``torch.distributed`` calls.  ``TOMO_NATIVE_COMM=0`` keeps the torch path (both give the same bits)."""
+        import os
+        return self.on_device() and os.environ.get("TOMO_NATIVE_COMM", "1") != "0"
+
     def on_device(self):
         """True when the collectives need device tensors (RCCL), False for host tensors (gloo)."""
         return self.dist.get_backend(self.group) == "nccl"

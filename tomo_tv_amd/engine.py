@@ -46,6 +46,7 @@ class _SlabBackend:
             check(self.L.tomo_create(nslice, nray, nproj, _ptr(ang), device, ctypes.byref(h)))
         self.h = h
         self._scal_t = self._halo_lo = self._halo_hi = None
+        self.native = False                 # collectives by the library itself (enable_native_comm)
 
     def close(self):
         if getattr(self, "h", None):
@@ -95,6 +96,27 @@ class _SlabBackend:
         self.c("bind_halo", ctypes.c_void_p(self._halo_lo.data_ptr()), ctypes.c_void_p(self._halo_hi.data_ptr()))
         self.c("bind_fgp_halo", *(ctypes.c_void_p(t.data_ptr()) for t in
                                   (self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last)))
+
+    def enable_native_comm(self, comm):
+        """A native RCCL communicator for this engine (include/tomo_hip.h: tomo_comm_*): rank 0 makes the id, the process
+        group carries it to the others, every rank joins.  From then on the engine's collectives are ncclGroups on its own
+        stream.  Collective over ``comm``."""
+        import torch
+        idbuf = (ctypes.c_ubyte * 128)()
+        if comm.rank == 0:
+            check(self.L.tomo_comm_unique_id(idbuf))
+        t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.tdev)
+        comm.broadcast(t, 0)
+        if comm.world == 1 and not comm.force:
+            pass                                            # broadcast was a no-op: the id is already rank 0's
+        raw = bytes(t.cpu().tolist())
+        check(self.L.tomo_comm_init(self.h, ctypes.c_char_p(raw), comm.world, comm.rank))
+        self.native = True
+
+    def comm_scalars(self):
+        out = np.zeros(S_COUNT, np.float64)
+        self.c("comm_read_scalars", _ptr(out), S_COUNT)
+        return out
 
     def scalar_tensor(self, slot):
         return self._scal_t[slot:slot + 1]
@@ -437,6 +459,8 @@ class _EngineBase:
         if self.comm is not None:
             self.be.enable_torch()
             self.be.c("set_slab_edges", int(self.comm.rank == 0), int(self.comm.rank == self.comm.world - 1))
+            if getattr(self.comm, "native_ok", lambda: False)() and hasattr(self.be, "enable_native_comm"):
+                self.be.enable_native_comm(self.comm)
 
     # ---- helpers -------------------------------------------------------------------------------------
     def _scalar(self, slot):
@@ -447,6 +471,9 @@ class _EngineBase:
         """Global values of several partial-sum slots: one all-reduce and one read-back for all of them."""
         if self.comm is None:
             v = self.be.scalars()
+            return [float(v[k]) for k in slots]
+        if self._native():
+            v = self.be.comm_scalars()
             return [float(v[k]) for k in slots]
         t = self.be.scalar_gather(slots)
         self.comm.allreduce_sum(t)
@@ -461,6 +488,9 @@ class _EngineBase:
                 self.be.scalars_snapshot()
                 return ("snapshot", slots)
             return ("values", self._scalars(slots))              # sub-slab group: immediate
+        if self._native():
+            self.be.c("comm_scalars_snapshot")
+            return ("snapshot", slots)
         t = self.be.scalar_gather(slots)
         self.comm.allreduce_sum(t)
         if t.is_cuda:
@@ -482,8 +512,17 @@ class _EngineBase:
             return [float(v) for v in token[1].tolist()]
         return list(token[1])
 
+    def _native(self):
+        """the engine runs its own collectives (RCCL from the library on its stream)"""
+        return self.comm is not None and getattr(self.be, "native", False) and self.use_native_comm
+
+    use_native_comm = True   # False: keep the torch.distributed calls although a native communicator exists (A/B, tests)
+
     def _exchange(self, field, planes=None):
         """Ring exchange of the field's boundary planes (``planes``: already packed by the producing kernel)."""
+        if planes is None and self._native():
+            self.be.c("comm_exchange_halo", int(field))
+            return
         lo, hi = planes if planes is not None else self.be.pack_planes(field)
         hlo, hhi = self.be.halo_tensors()
         self.comm.exchange_planes(lo, hi, hlo, hhi)
@@ -680,6 +719,9 @@ class _EngineBase:
         if self.comm is None:
             self.be.c("tv_gd", ng, float(dPOCS), self.tv_eps)
             return self._scalar(S_TV)
+        if self._native() and self.tv_one_round:
+            self.be.c("comm_tv_gd", ng, float(dPOCS), self.tv_eps, -1, 0)      # the whole sharded descent: one call
+            return self._scalar(S_TV)
         if ng <= 0:
             tv0 = self._tv_of(vol, self.tv_eps)
             self.be.c("positivity", vol)
@@ -732,10 +774,11 @@ class _EngineBase:
             # iteration only needs D (tv_fgp.cu:272) and P1 of the slice below
             self.be.c("fgp_fused_begin", vol)
             first, last, lo, hi = self.be.fgp_planes()
+            xchg = (lambda: self.be.c("comm_fgp_exchange")) if self._native() else (lambda: self.comm.exchange_planes(first, last, lo, hi))
             for i in range(ng - 1):
-                self.comm.exchange_planes(first, last, lo, hi)
+                xchg()
                 self.be.c("fgp_fused_step", lam, int(i == 0))
-            self.comm.exchange_planes(first, last, lo, hi)
+            xchg()
             self.be.c("fgp_fused_end", lam)
             return tv0
         self.be.c("fgp_begin_vol", vol)
@@ -949,6 +992,9 @@ class tomoengine(_EngineBase):
             return finish(self._scalars((S_TV, S_DIFF) + extra))
         if self.comm is None:
             self.be.c("tv_gd_tracked", ng, float(dPOCS), self.tv_eps, VOL_TEMP, S_DIFF)
+            return read()
+        if self._native() and self.tv_one_round:
+            self.be.c("comm_tv_gd", ng, float(dPOCS), self.tv_eps, VOL_TEMP, S_DIFF)
             return read()
         if ng <= 0:
             tv0 = self.tv_gd(ng, dPOCS)
