@@ -2115,8 +2115,16 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 // Overlapping chunks (a wave loads 64 slices and owns the 62 in the middle, so every slice shift is a plain DPP: no packed edge
 // values, no readlane fix-ups, no phantom R; 71-78 VGPRs): fewer instructions but 475 against 429 us at 512 slices and 103 against
 // 76 at 64 -- the misaligned 248-byte rows and the extra chunk cost more than the ~20 % of vector instructions they save.
+#ifndef TV4_WAVES_PER_EU
+#define TV4_WAVES_PER_EU 0
+#endif
+#if TV4_WAVES_PER_EU
+#define TV4_OCC __attribute__((amdgpu_waves_per_eu(TV4_WAVES_PER_EU, TV4_WAVES_PER_EU)))
+#else
+#define TV4_OCC
+#endif
 template <int TZ, bool WITH_TV, int MODE, bool EDGE, bool TRACK = false, bool STREAM = false>
-__global__ __launch_bounds__(256) void k_tv_march4(const float *__restrict__ x, Halo h, double *__restrict__ part, float eps,
+__global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restrict__ x, Halo h, double *__restrict__ part, float eps,
                                                     int n, int nx, int sx, int yseg, double *__restrict__ part_tv, TvUpd up)
 {
     static_assert(MODE == TVM_NORM || MODE == TVM_UPDATE, "gradient modes without a stored gradient");

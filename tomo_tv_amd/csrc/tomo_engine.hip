@@ -140,6 +140,10 @@ struct tomo_engine {
     uint32_t *d_ft_slot_ptr = nullptr, *d_ft_slot_seg0 = nullptr, *d_ft_rsptr = nullptr, *d_ft_rsidx = nullptr;
     uint2 *d_ft_tent = nullptr;
     float *ft_part = nullptr, *ft_part_aux = nullptr;
+    // all-angle FP as a two-stage pipeline over groups of 64-slice chunks ("fp_tile_pipe"): [0] main stream, [1] second stream
+    int fp_tile_pipe = 0;   // off: measured (round 3) 1.50 vs 1.52 ms at 512^3 x 90, 1.91 vs 1.83 ms at 128 x 1024^2 x 120, 0.127 vs 0.154 ms at 256^3 x 60
+    hipStream_t fp_red_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fp_tile[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, ev_fp_red[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool attr_fp = false, attr_bp = false, attr_st = false;   // dynamic-LDS limits raised on this engine's device
     // The SART chain of one slab is a string of dependent launches (tile step -> residual finish -> tile step ...): ~5.7 us of
     // idle chip after each and a tail of partly filled CUs at the end of each.  Slices are independent, so the sweep CAN run as
@@ -410,14 +414,42 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
             e->attr_fp = true;
         }
     }
-    float **slot = (e->aux && e->stream == e->aux) ? &e->ft_part_aux : &e->ft_part;
+    const int which = (e->aux && e->stream == e->aux) ? 1 : 0;
+    float **slot = which ? &e->ft_part_aux : &e->ft_part;
+    // The tile kernel is LDS / vector-ALU bound and WRITES the partial sums; the reduce kernel is HBM-read bound.  With
+    // "fp_tile_pipe" = P >= 2 the projection runs as P groups of chunks, the reduce of group k on a helper stream beside the tile
+    // kernel of group k+1 (two halves of the scratch, events both ways): the two kernels want different parts of the chip.
+    // Built and measured in round 3 -- and it buys nothing (numbers at the option's declaration): the tile kernel's one 1024-thread
+    // workgroup per CU leaves room for one reduce wave per SIMD, which reads no faster than the tile kernel's own stores leave
+    // the memory system idle.  Kept as an option, default off.
+    int ncp_call = e->ft_ncp, pipe = 0;
+    if (e->fp_tile_pipe >= 2 && nchunk >= 2 * 2) {          // groups of at least two chunks (64-lane reduce spans)
+        int P = std::min(e->fp_tile_pipe, nchunk / 2);
+        int per = (nchunk + P - 1) / P;
+        per = (per + 1) & ~1;
+        if (per <= e->ft_ncp && per < nchunk) { ncp_call = per; pipe = 1; }
+    }
     if (!*slot) {
-        int rc = dev_alloc((void **)slot, (size_t)std::max<uint32_t>(1, e->ft_nseg) * e->ft_ncp * 64 * sizeof(float), false, e->stream);
+        // sized for both schemes: one pass of ft_ncp chunks, or two halves of a pipelined group each
+        size_t chunks = std::max<size_t>(e->ft_ncp, 2 * (size_t)((((e->sxc / 64 + 1) / 2) + 1) & ~1));
+        int rc = dev_alloc((void **)slot, (size_t)std::max<uint32_t>(1, e->ft_nseg) * chunks * 64 * sizeof(float), false, e->stream);
         if (rc) return rc;
     }
-    float *part = *slot;
-    for (int c0 = 0; c0 < nchunk; c0 += e->ft_ncp) {
-        int ncp = std::min(e->ft_ncp, nchunk - c0);
+    if (pipe && !e->fp_red_stream[which]) {
+        HIPCHK(hipStreamCreateWithFlags(&e->fp_red_stream[which], hipStreamNonBlocking));
+        for (int h = 0; h < 2; ++h) {
+            HIPCHK(hipEventCreateWithFlags(&e->ev_fp_tile[which][h], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_fp_red[which][h], hipEventDisableTiming));
+        }
+    }
+    const size_t half_elems = (size_t)std::max<uint32_t>(1, e->ft_nseg) * ncp_call * 64;
+    int k = 0;
+    for (int c0 = 0; c0 < nchunk; c0 += ncp_call, ++k) {
+        int ncp = std::min(ncp_call, nchunk - c0);
+        const int half = k & 1;
+        float *part = *slot + (pipe ? half * half_elems : 0);
+        hipStream_t rs = pipe ? e->fp_red_stream[which] : e->stream;
+        if (pipe && k >= 2) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fp_red[which][half], 0));   // this half of the scratch is free again
         {
             ProfScope ps(e, TOMO_K_FP_TILE);
             dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * ncp)), block(FT_THREADS);
@@ -425,17 +457,28 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
                                e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, c0, ncp);
             LAUNCHCHK();
         }
-        ProfScope ps(e, TOMO_K_FP_REDUCE);
-        int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
-        int64_t items = (int64_t)e->nrows * (ncp * 16 / lpr);
-        int64_t waves = (items + 64 / lpr - 1) / (64 / lpr);
-        dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-        switch (lpr) {
-        case 64: hipLaunchKernelGGL((k_fp_tile_reduce<64, MODE>), grid, block, 0, e->stream, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
-        case 32: hipLaunchKernelGGL((k_fp_tile_reduce<32, MODE>), grid, block, 0, e->stream, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
-        default: hipLaunchKernelGGL((k_fp_tile_reduce<16, MODE>), grid, block, 0, e->stream, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+        if (pipe) {
+            HIPCHK(hipEventRecord(e->ev_fp_tile[which][half], e->stream));
+            HIPCHK(hipStreamWaitEvent(rs, e->ev_fp_tile[which][half], 0));
         }
-        LAUNCHCHK();
+        {
+            ProfScope ps(e, TOMO_K_FP_REDUCE, rs);
+            int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
+            int64_t items = (int64_t)e->nrows * (ncp * 16 / lpr);
+            int64_t waves = (items + 64 / lpr - 1) / (64 / lpr);
+            dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+            switch (lpr) {
+            case 64: hipLaunchKernelGGL((k_fp_tile_reduce<64, MODE>), grid, block, 0, rs, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+            case 32: hipLaunchKernelGGL((k_fp_tile_reduce<32, MODE>), grid, block, 0, rs, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+            default: hipLaunchKernelGGL((k_fp_tile_reduce<16, MODE>), grid, block, 0, rs, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+            }
+            LAUNCHCHK();
+        }
+        if (pipe) HIPCHK(hipEventRecord(e->ev_fp_red[which][half], rs));
+    }
+    if (pipe) {                                             // the projection is complete on the caller's stream
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fp_red[which][0], 0));
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fp_red[which][1], 0));
     }
     return TOMO_OK;
 }
@@ -961,6 +1004,7 @@ int tomo_destroy(tomo_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (int u = 0; u < tomo_engine::MAX_CHAINS; ++u) if (e->sub_stream[u]) { (void)hipStreamSynchronize(e->sub_stream[u]); (void)hipStreamDestroy(e->sub_stream[u]); (void)hipEventDestroy(e->ev_sjoin[u]); }
+    for (int w = 0; w < 2; ++w) if (e->fp_red_stream[w]) { (void)hipStreamSynchronize(e->fp_red_stream[w]); (void)hipStreamDestroy(e->fp_red_stream[w]); for (int h = 0; h < 2; ++h) { (void)hipEventDestroy(e->ev_fp_tile[w][h]); (void)hipEventDestroy(e->ev_fp_red[w][h]); } }
     comm_release(e);
     if (e->ev_sfork) (void)hipEventDestroy(e->ev_sfork);
     if (e->ev_peer) (void)hipEventDestroy(e->ev_peer);
@@ -2552,6 +2596,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
 #ifdef TOMO_WHATIF
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
+    if (std::strcmp(name, "fp_tile_pipe") == 0) { e->fp_tile_pipe = std::max(0, value); return TOMO_OK; }
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? std::min(value, (int)tomo_engine::MAX_CHAINS) : (value == 1 ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "art_tile") == 0) { e->art_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_skip_same") == 0) { e->sart_skip_same = value ? 1 : 0; return TOMO_OK; }

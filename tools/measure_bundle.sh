@@ -1,6 +1,6 @@
-# Round-2 measurement bundle (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats of the same
+# Measurement bundle of a round (tools/measure_bundle.sh r03) (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats of the same
 # command, PMC traffic passes (FETCH_SIZE / WRITE_SIZE in separate runs, no tracing domains besides the kernel trace).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R && python3 bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --quick > $O/bench_trace.log 2>&1
