@@ -1520,17 +1520,25 @@ __global__ __launch_bounds__(256) void k_mm_update(MMArgs a, const f4 *__restric
 // sums[s] += sum_m v[m][s]^2 over the rows m of this workgroup; a thread owns 4 consecutive slices (one float4 per row), so a
 // wave reads 1 KiB contiguous per row.  (Round 1's scalar form with a 64-bit modulo per element made a CGLS iteration
 // spend twice as long in these helpers as in the projectors.)
-__global__ __launch_bounds__(256) void k_slice_sumsq(const float *__restrict__ v, double *__restrict__ sums, int64_t m,
+// Round 3: two passes without atomics -- a workgroup leaves ITS rows' sums in part[blockIdx.y][slice] and k_slice_sumsq_finish adds
+// the workgroups' sums in ascending order.  (4096 workgroups x 512 double atomics onto the same 512 addresses was most of the
+// kernel's 300-416 us for a 537 MB volume, and arrival order made the per-slice alpha / beta differ in the last bits between runs.)
+// All 256 threads load: the two halves of a workgroup take alternate groups of 8 rows and meet in LDS.
+__global__ __launch_bounds__(256) void k_slice_sumsq(const float *__restrict__ v, double *__restrict__ part, int64_t m,
                                                       int sx, int rows_per_block)
 {
-    const int s4 = blockIdx.x * 256 + threadIdx.x;                  // float4 column: slices 4*s4 .. 4*s4+3
-    if (s4 * 4 >= sx) return;
+    __shared__ double sh[128 * 4];
+    const int cols = sx / 4;                                          // float4 columns of a row
+    const int per = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);     // threads side by side on one row
+    const int half = threadIdx.x / per, nhalf = 256 / per;            // row phases of this workgroup (1, 2 or 4)
+    const int s4 = blockIdx.x * per + (threadIdx.x % per);            // float4 column: slices 4*s4 .. 4*s4+3
+    const bool live = s4 < cols;
     const int64_t m0 = (int64_t)blockIdx.y * rows_per_block, m1 = min(m, m0 + rows_per_block);
-    const f4 *p = reinterpret_cast<const f4 *>(v) + s4;
-    const int64_t pitch4 = sx / 4;
+    const f4 *p = reinterpret_cast<const f4 *>(v) + (live ? s4 : 0);
+    const int64_t pitch4 = cols;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int64_t r = m0; r < m1; r += 8) {            // 8 independent loads per trip (one per trip left the pass latency-bound:
-        f4 a[8];                                      // 459 us for a 537 MB volume); added in row order as before
+    for (int64_t r = m0 + 8 * half; live && r < m1; r += 8 * nhalf) {  // 8 independent loads per trip, rows in ascending order
+        f4 a[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[u] = (r + u < m1) ? p[(r + u) * pitch4] : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1538,7 +1546,27 @@ __global__ __launch_bounds__(256) void k_slice_sumsq(const float *__restrict__ v
             a0 += (double)(a[u].x * a[u].x); a1 += (double)(a[u].y * a[u].y); a2 += (double)(a[u].z * a[u].z); a3 += (double)(a[u].w * a[u].w);
         }
     }
-    atomicAdd(&sums[4 * s4], a0); atomicAdd(&sums[4 * s4 + 1], a1); atomicAdd(&sums[4 * s4 + 2], a2); atomicAdd(&sums[4 * s4 + 3], a3);
+    // the row phases of a column meet in LDS, phase 0 adds them in ascending phase order
+    for (int h = 1; h < nhalf; ++h) {
+        if (half == h && per <= 128) { double *q = sh + (threadIdx.x % per) * 4; q[0] = a0; q[1] = a1; q[2] = a2; q[3] = a3; }
+        __syncthreads();
+        if (half == 0 && per <= 128) { const double *q = sh + (threadIdx.x % per) * 4; a0 += q[0]; a1 += q[1]; a2 += q[2]; a3 += q[3]; }
+        __syncthreads();
+    }
+    if (half == 0 && live) {
+        double *o = part + (size_t)blockIdx.y * sx + 4 * (size_t)s4;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    }
+}
+
+// sums[s] = sum over the nb workgroups' partial sums, ascending
+__global__ void k_slice_sumsq_finish(const double *__restrict__ part, double *__restrict__ sums, int nb, int sx)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= sx) return;
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a += part[(size_t)b * sx + s];
+    sums[s] = a;
 }
 
 // coef[s] = num[s] / den[s] (0 when den == 0)

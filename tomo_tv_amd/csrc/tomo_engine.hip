@@ -193,6 +193,7 @@ struct tomo_engine {
     float *cur_b = nullptr;
     float *cg_p = nullptr, *cg_z = nullptr, *cg_w = nullptr, *fbp_h = nullptr;   // CGLS direction / A^T r / A p; WBP kernel
     double *cg_sums = nullptr;                    // 2*sx per-slice sums
+    double *cg_part = nullptr;                    // 1024 x sx: the workgroups' partial sums of a per-slice reduction
     float *cg_coef = nullptr;                     // sx per-slice coefficients                      // data sinogram of the SART call in progress
     float *tvg = nullptr;                         // TV gradient tensor; doubles as FGP "D"
     float *fgp_p[3] = {nullptr, nullptr, nullptr};
@@ -1011,7 +1012,7 @@ int tomo_destroy(tomo_engine *e)
     if (e->ev_snap) (void)hipEventDestroy(e->ev_snap);
     if (e->h_snap) (void)hipHostFree(e->h_snap);
     free_geometry(e);
-    void *ptrs[] = {e->tv_alt, e->halo_lo_alt, e->halo_hi_alt, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_coef, e->sart_alt,
+    void *ptrs[] = {e->tv_alt, e->halo_lo_alt, e->halo_hi_alt, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_part, e->cg_coef, e->sart_alt,
                     e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < TOMO_VOL_SLOTS; ++i) if (e->vol[i]) (void)hipFree(e->vol[i]);
@@ -1479,10 +1480,14 @@ int tomo_poisson_residual(tomo_engine *e, int vol, int sino_b, int sino_out)
 // (algo_cgls->initialize per call), independently per slice (alpha, beta are per-slice scalars), positivity at the end.
 static int slice_sumsq(tomo_engine *e, const float *v, int64_t m, double *sums)
 {
-    HIPCHK(hipMemsetAsync(sums, 0, e->sx * sizeof(double), e->stream));
-    int rpb = (int)std::max<int64_t>(64, (m + 4095) / 4096);
-    dim3 grid((unsigned)((e->sx / 4 + 255) / 256), (unsigned)((m + rpb - 1) / rpb));
-    hipLaunchKernelGGL(k_slice_sumsq, grid, dim3(256), 0, e->stream, v, sums, m, e->sx, rpb);
+    const int cols = e->sx / 4, per = cols >= 256 ? 256 : (cols >= 128 ? 128 : 64);
+    const int nby = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (m + 63) / 64));   // workgroups along the rows
+    const int rpb = (int)((m + nby - 1) / nby);
+    if (!e->cg_part) { int rc = dev_alloc((void **)&e->cg_part, (size_t)1024 * e->sx * sizeof(double), false, e->stream); if (rc) return rc; }
+    dim3 grid((unsigned)((cols + per - 1) / per), (unsigned)nby);
+    hipLaunchKernelGGL(k_slice_sumsq, grid, dim3(256), 0, e->stream, v, e->cg_part, m, e->sx, rpb);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_slice_sumsq_finish, dim3((e->sx + 255) / 256), dim3(256), 0, e->stream, (const double *)e->cg_part, sums, nby, e->sx);
     LAUNCHCHK();
     return TOMO_OK;
 }

@@ -100,18 +100,35 @@ class _SlabBackend:
     def enable_native_comm(self, comm):
         """A native RCCL communicator for this engine (include/tomo_hip.h: tomo_comm_*): rank 0 makes the id, the process
         group carries it to the others, every rank joins.  From then on the engine's collectives are ncclGroups on its own
-        stream.  Collective over ``comm``."""
+        stream.  Collective over ``comm``.  If ANY rank fails to join (no librccl, an init error) every rank falls back to the
+        ``torch.distributed`` collectives together -- a mixed group would deadlock -- and says so once on stderr."""
+        import sys
         import torch
+
+        def all_ok(ok):
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.tdev)
+            if comm.world > 1 or comm.force:
+                comm.dist.all_reduce(flag, op=comm.dist.ReduceOp.MIN, group=comm.group)
+            return int(flag.item()) == 1
         idbuf = (ctypes.c_ubyte * 128)()
+        # every rank makes an id (only rank 0's is used): the call that opens librccl, so a rank without it is found BEFORE
+        # anybody enters the collective ncclCommInitRank
+        ok = int(self.L.tomo_comm_unique_id(idbuf) == 0)
+        err = b"" if ok else self.L.tomo_last_error()
+        if all_ok(ok):
+            t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.tdev)
+            comm.broadcast(t, 0)
+            raw = bytes(t.cpu().tolist())
+            ok = int(self.L.tomo_comm_init(self.h, ctypes.c_char_p(raw), comm.world, comm.rank) == 0)
+            err = b"" if ok else self.L.tomo_last_error()
+            if all_ok(ok):
+                self.native = True
+                return
+        self.L.tomo_comm_destroy(self.h)
+        self.native = False
         if comm.rank == 0:
-            check(self.L.tomo_comm_unique_id(idbuf))
-        t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.tdev)
-        comm.broadcast(t, 0)
-        if comm.world == 1 and not comm.force:
-            pass                                            # broadcast was a no-op: the id is already rank 0's
-        raw = bytes(t.cpu().tolist())
-        check(self.L.tomo_comm_init(self.h, ctypes.c_char_p(raw), comm.world, comm.rank))
-        self.native = True
+            print(f"tomo_tv_amd: native RCCL communicator unavailable ({(err or b'another rank failed').decode()}); "
+                  "using torch.distributed collectives", file=sys.stderr, flush=True)
 
     def comm_scalars(self):
         out = np.zeros(S_COUNT, np.float64)
