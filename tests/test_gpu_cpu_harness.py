@@ -320,3 +320,45 @@ def test_create_projections_snr_branch_and_update_proj_angles(gpu, golden):
     ref2.ART(0.5)
     assert rel_l2(tomo.get_volume(), ref2.recon) < 1e-5
     assert abs(tomo.data_distance() - ref2.data_distance()) <= 1e-5 * ref2.data_distance()
+
+
+@pytest.mark.parametrize("N,P,Nx", [(16, 5, 2), (32, 9, 4)])
+def test_reference_helpers_on_the_oracle_vs_mirror_on_the_gpu(gpu, golden, N, P, Nx):
+    """The fixture holds what the IMPORTED reference helpers (cpu/utils/pytvlib.py:171-213) make of the oracle class; the
+    mirror helpers on the GPU facade must reproduce it: tilt series, eight iterations of dd / rmse, final volume, for SIRT, ART
+    and cimminoSIRT, noise-free and with SNR = 100 (background lifted to 1, seeded Poisson draw)."""
+    g = golden(f"trace_refharness_N{N}_P{P}_Nx{Nx}.npz")
+    ang = g["angles_deg"]
+    for alg in ("SIRT", "ART", "cimminoSIRT"):
+        for snr in (0, 100):
+            t = ctvlib(Nx, N, P)
+            H.initialize_algorithm(t, alg, N, ang)
+            beta = 0.5
+            if alg == "SIRT":
+                beta = 1 / t.lipschits()
+            if alg == "cimminoSIRT":
+                beta = N * P / t.lipschits()
+            H.create_projections(t, g["x0"].copy(), 0)
+            key = f"{alg}_snr{snr}"
+            if snr:                                       # the draw is part of the fixture (a Poisson stream desynchronises on an ulp)
+                lifted = g["x0"].copy()
+                lifted[lifted == 0] = 1
+                H.create_projections(t, lifted, 0)
+                clean = t.get_projections()
+                t.set_tilt_series(g[f"b_{key}"])
+                assert abs(clean.sum(dtype=np.float64) / g[f"b_{key}"].sum(dtype=np.float64) - 1) < 1e-3
+            else:
+                assert rel_l2(t.get_projections(), g[f"b_{key}"]) < 1e-5
+            dd, rm = [], []
+            for i in range(8):
+                H.run(t, alg, beta)
+                if alg != "SIRT":
+                    beta *= 0.995
+                dd.append(t.data_distance())
+                rm.append(t.rmse())
+            assert np.allclose(dd, g[f"dd_{key}"], rtol=1e-5) and np.allclose(rm, g[f"rmse_{key}"], rtol=1e-5), key
+            assert rel_l2(t.get_volume(), g[f"recon_{key}"]) < 1e-5, key
+    t = ctvlib(Nx, N, P)
+    H.initialize_algorithm(t, "SIRT", N, ang)
+    H.load_exp_tilt_series(t, g["exp_ts"])
+    assert np.array_equal(t.get_projections(), g["exp_b"])

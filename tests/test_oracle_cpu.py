@@ -151,3 +151,38 @@ def test_config1_trace_is_converging():
     g = np.load(os.path.join(GOLDEN, "trace_config1_sirt50.npz"))
     assert g["recon"].shape == (1, 256, 256)
     assert np.all(np.diff(g["dd"]) < 0) and g["rmse"][-1] < g["rmse"][0]
+
+
+@pytest.mark.parametrize("N,P,Nx", [(16, 5, 2), (32, 9, 4)])
+def test_harness_mirror_equals_the_imported_reference_helpers(N, P, Nx):
+    """tests/golden/trace_refharness_*.npz: the reference's OWN harness helpers (cpu/utils/pytvlib.py:171-213, imported by
+    tools/gen_golden.py --only-refharness) executed on the oracle class.  The product's mirror of those helpers
+    (tomo_tv_amd.cpu_harness: same names and signatures) executed on the same class must give the same bits: what is compared
+    is the helper logic -- which engine methods are called, in which order, with which arguments."""
+    from tomo_tv_amd import cpu_harness as H
+    g = np.load(os.path.join(GOLDEN, f"trace_refharness_N{N}_P{P}_Nx{Nx}.npz"))
+    ang = g["angles_deg"]
+    for alg in ("SIRT", "ART", "cimminoSIRT"):
+        for snr in (0, 100):
+            t = oracle.ctvlib(Nx, N, P)
+            H.initialize_algorithm(t, alg, N, ang)
+            beta0 = 0.5
+            if alg == "SIRT":
+                beta0 = 1 / t.lipschits()
+            if alg == "cimminoSIRT":
+                beta0 = N * P / t.lipschits()
+            H.create_projections(t, g["x0"].copy(), snr)
+            key = f"{alg}_snr{snr}"
+            assert np.array_equal(t.b, g[f"b_{key}"]), key
+            beta = beta0
+            for i in range(8):
+                H.run(t, alg, beta)
+                if alg != "SIRT":
+                    beta *= 0.995
+                # (the oracle's fp64 sums are OpenMP reductions: the last bit depends on the team)
+                assert abs(t.data_distance() - g[f"dd_{key}"][i]) <= 1e-12 * g[f"dd_{key}"][i], (key, i)
+                assert abs(t.rmse() - g[f"rmse_{key}"][i]) <= 1e-12 * g[f"rmse_{key}"][i], (key, i)
+            assert np.array_equal(t.recon, g[f"recon_{key}"]), key
+    t = oracle.ctvlib(Nx, N, P)
+    H.load_exp_tilt_series(t, g["exp_ts"])
+    assert np.array_equal(t.b, g["exp_b"])

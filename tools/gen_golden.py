@@ -130,6 +130,53 @@ def asd_art_traces(shapes, Niter=20):
                             provenance="oracle/ restatement of the Cimmino branch (ctvlib.cpp:198-199,212-216,245-251)")
 
 
+def refharness_traces(ref):
+    """Round 3: the harness helpers of tomofusion/cpu/utils/pytvlib.py -- initialize_algorithm (:178-189), create_projections
+    (:191-206), run (:171-176), load_exp_tilt_series (:208-213) -- IMPORTED and executed here, acting on the oracle class (which
+    carries the ctvlib method table).  Only the loop around them is typed (cpu/sim_tomo.py:35-61).  What the fixtures pin: which
+    engine methods each helper calls, in which order and with which arguments (background lift before the projection, noise after
+    it, the transpose of load_exp_tilt_series, row_inner_product / cimminos_method by algorithm name)."""
+    import io
+    import contextlib
+    import oracle
+    for N, P, Nx in [(32, 9, 4), (16, 5, 2)]:
+        ang = np.linspace(-70, 70, P)
+        out = {"angles_deg": ang}
+        x0 = phantom(Nx, N)
+        out["x0"] = x0
+        for alg in ("SIRT", "ART", "cimminoSIRT"):
+            for snr in (0, 100):
+                t = oracle.ctvlib(Nx, N, P)
+                with contextlib.redirect_stdout(io.StringIO()):              # the reference prints a banner
+                    ref.initialize_algorithm(t, alg, N, ang)
+                beta0 = 0.5
+                if alg == "SIRT":
+                    beta0 = 1 / t.lipschits()
+                if alg == "cimminoSIRT":
+                    beta0 = N * P / t.lipschits()
+                vol = x0.copy()
+                ref.create_projections(t, vol, snr)                          # lifts the background in place when snr != 0
+                key = f"{alg}_snr{snr}"
+                out[f"b_{key}"] = t.b.copy()
+                beta, dd, rm = beta0, np.zeros(8), np.zeros(8)
+                for i in range(8):
+                    ref.run(t, alg, beta)
+                    if alg != "SIRT":
+                        beta *= 0.995
+                    dd[i], rm[i] = t.data_distance(), t.rmse()
+                out[f"dd_{key}"], out[f"rmse_{key}"], out[f"recon_{key}"] = dd, rm, t.recon.copy()
+        # load_exp_tilt_series: (Nslice, Nray, Nproj) -> the engine's (Nslice, Nray*Nproj) layout
+        ts = np.random.default_rng(5).random((Nx, N, P)).astype(np.float32)
+        t = oracle.ctvlib(Nx, N, P)
+        ref.load_exp_tilt_series(t, ts)
+        out["exp_ts"], out["exp_b"] = ts, t.b.copy()
+        out["provenance"] = ("helpers initialize_algorithm / create_projections / run / load_exp_tilt_series IMPORTED from the reference's "
+                             "tomofusion/cpu/utils/pytvlib.py and executed on the oracle class; loop typed from cpu/sim_tomo.py:35-61; "
+                             "noise from numpy default_rng(4321) (quirk Q13)")
+        np.savez_compressed(os.path.join(GOLD, f"trace_refharness_N{N}_P{P}_Nx{Nx}.npz"), **out)
+        print("wrote", f"trace_refharness_N{N}_P{P}_Nx{Nx}.npz")
+
+
 def method_tables():
     """Method NAMES of the reference's five pybind11 classes (interface data for tests/test_abi_cpu.py)."""
     import re
@@ -157,6 +204,9 @@ def main():
     ref, ref_fusion = import_reference()
     import oracle
 
+    if "--only-refharness" in sys.argv:
+        refharness_traces(ref)
+        return
     if "--only-baseline-digests" in sys.argv:
         # round 3: the imported reference's matrix at the BASELINE geometries (config 3: 512 x 90, config 5: 512 x 70,
         # config 4: 1024 x 120) -- digests only; the other entries of A_digest.json stay as they are
