@@ -346,7 +346,7 @@ def test_reference_helpers_on_the_oracle_vs_mirror_on_the_gpu(gpu, golden, N, P,
                 H.create_projections(t, lifted, 0)
                 clean = t.get_projections()
                 t.set_tilt_series(g[f"b_{key}"])
-                assert abs(clean.sum(dtype=np.float64) / g[f"b_{key}"].sum(dtype=np.float64) - 1) < 1e-3
+                assert abs(clean.sum(dtype=np.float64) / g[f"b_{key}"].sum(dtype=np.float64) - 1) < 3e-2     # (a Poisson draw keeps the total to ~1/sqrt(counts))
             else:
                 assert rel_l2(t.get_projections(), g[f"b_{key}"]) < 1e-5
             dd, rm = [], []
