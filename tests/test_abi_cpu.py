@@ -45,6 +45,21 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
 
 
+def test_communicator_entry_points_reject_bad_arguments_without_a_gpu():
+    """tomo_comm_* (the native RCCL path of the slab sharding) on null engines / null buffers: error codes and a message, no
+    crash, nothing initialised (librccl is only opened by tomo_comm_unique_id / tomo_comm_init on a real engine)."""
+    from tomo_tv_amd import _lib
+    L = _lib.load()
+    w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert L.tomo_comm_info(None, ctypes.byref(w), ctypes.byref(r)) != 0 and L.tomo_last_error()
+    assert L.tomo_comm_unique_id(None) != 0
+    for fn, args in (("tomo_comm_init", (None, None, 1, 0)), ("tomo_comm_share", (None, None)), ("tomo_comm_destroy", (None,)),
+                     ("tomo_comm_exchange_halo", (None, 0)), ("tomo_comm_read_scalars", (None, None, 1)),
+                     ("tomo_comm_scalars_snapshot", (None,)), ("tomo_comm_tv_gd", (None, 1, 0.1, 1e-6, -1, 0)),
+                     ("tomo_comm_fgp_exchange", (None,))):
+        assert getattr(L, fn)(*args) != 0, fn
+
+
 def test_error_reporting_host_side():
     from tomo_tv_amd import _lib
     L = _lib.load()
