@@ -2143,14 +2143,13 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 // Overlapping chunks (a wave loads 64 slices and owns the 62 in the middle, so every slice shift is a plain DPP: no packed edge
 // values, no readlane fix-ups, no phantom R; 71-78 VGPRs): fewer instructions but 475 against 429 us at 512 slices and 103 against
 // 76 at 64 -- the misaligned 248-byte rows and the extra chunk cost more than the ~20 % of vector instructions they save.
-#ifndef TV4_WAVES_PER_EU
-#define TV4_WAVES_PER_EU 0
+// Occupancy: the update pass fits 96 VGPRs (5 waves per SIMD) without a spill, the norm pass does not (62 spilled registers at 5
+// waves: 816 us measured with an earlier form); TV4_UPD_WAVES (build-time) asks for 5 on the update pass only -- measured 377.7 vs
+// 376.0 us per inner iteration at 512 slices and 65.6 vs 57.8 at 64: the compiler's own choice (120 VGPRs, 4 waves) stays.
+#ifndef TV4_UPD_WAVES
+#define TV4_UPD_WAVES 4
 #endif
-#if TV4_WAVES_PER_EU
-#define TV4_OCC __attribute__((amdgpu_waves_per_eu(TV4_WAVES_PER_EU, TV4_WAVES_PER_EU)))
-#else
-#define TV4_OCC
-#endif
+#define TV4_OCC __attribute__((amdgpu_waves_per_eu((MODE == TVM_UPDATE && !TRACK) ? TV4_UPD_WAVES : 4, (MODE == TVM_UPDATE && !TRACK) ? TV4_UPD_WAVES : 8)))
 template <int TZ, bool WITH_TV, int MODE, bool EDGE, bool TRACK = false, bool STREAM = false>
 __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restrict__ x, Halo h, double *__restrict__ part, float eps,
                                                     int n, int nx, int sx, int yseg, double *__restrict__ part_tv, TvUpd up)
@@ -2245,33 +2244,31 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 (void)dd_; (void)d2; (void)d3;
                 TEp = nc_mul(d1, r_);                           // = -(x[s0] - x[s0-1]) R(s0-1): the terms are kept negated ...
             }
-            float G1[TZ + 1], Ti[TZ + 1], Tk[TZ + 1];
+            float out[TZ + 1];                                  // the row's results: g (norm pass) or x_new (update pass)
+            float tk_prev = 0.f;                                // -(x_kp - c) R of column j-1: minus the -z term of column j
 #pragma unroll
-            for (int j = 0; j <= TZ; ++j) {
+            for (int j = 0; j <= TZ; ++j) {                     // one pass over the columns: R, the shared products, the gradient
                 float dd, d1, d2, d3, r;
                 const float c = c0[j], xip = shl(col(pf0, j), c);
                 TV4_RINV(c, xip, cp[j], c0[j + 1], r, dd, d1, d2, d3)
                 if (WITH_TV && j >= 1) tvacc += (double)((!EDGE || (z0 + j - 1 < n && s < nx)) ? dd : 0.f);
-                Tk[j] = nc_mul(d3, r);                          // -(x_kp - c) R: minus the -z term of column j+1
+                const float tk = nc_mul(d3, r);                 // handed to column j+1
                 if (j >= 1) {
-                    Ti[j] = nc_mul(d1, r);                      // -(x_ip - c) R: minus the -slice term of the lane above
+                    const float ti = nc_mul(d1, r);             // -(x_ip - c) R: minus the -slice term of the lane above
                     Tn[j] = nc_mul(d2, r);                      // -(x_jp - c) R: minus the -y term of the next row
-                    G1[j] = nc_mul(nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), cp[j]), c0[j + 1]), r);
+                    const float g1 = nc_mul(nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), cp[j]), c0[j + 1]), r);
+                    const float t2 = shr(col(TEp, j), ti);
+                    const float gv = nc_sub(nc_sub(nc_sub(g1, t2), Tp[j]), tk_prev);   // the terms are kept negated and subtracted: a - (-t) == a + t
+                    const bool ok = !EDGE || (z0 + j - 1 < n && s < nx);
+                    if (MODE == TVM_NORM) {
+                        out[j] = gv;
+                        float g2 = gv * gv;
+                        acc += (double)(ok ? g2 : 0.f);
+                    } else {
+                        out[j] = fmaxf(tv_step(c, gv, nrm_), vmin);   // the expression of k_tv_update
+                    }
                 }
-            }
-            float out[TZ + 1];                                  // the row's results: g (norm pass) or x_new (update pass)
-#pragma unroll
-            for (int j = 1; j <= TZ; ++j) {
-                float t2 = shr(col(TEp, j), Ti[j]);
-                float gv = nc_sub(nc_sub(nc_sub(G1[j], t2), Tp[j]), Tk[j - 1]);   // ... and subtracted: a - (-t) == a + t, bit for bit
-                const bool ok = !EDGE || (z0 + j - 1 < n && s < nx);
-                if (MODE == TVM_NORM) {
-                    out[j] = gv;
-                    float g2 = gv * gv;
-                    acc += (double)(ok ? g2 : 0.f);
-                } else {
-                    out[j] = fmaxf(tv_step(c0[j], gv, nrm_), vmin);   // the expression of k_tv_update
-                }
+                tk_prev = tk;
             }
             const size_t pix0 = (size_t)(y * n + z0);                 // wave-uniform
             if (MODE == TVM_UPDATE) {
