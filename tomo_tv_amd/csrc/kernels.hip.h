@@ -1956,7 +1956,7 @@ inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
 //               buffer (neighbours still read the old x), clamp / wrapped halo planes / tracked norm + snapshot as in
 //               k_tv_update.  One volume write per inner iteration instead of two, 8 instead of 12 bytes read.
 //   TVM_STORE   the round-1 form (g stored; k_tv_update applies it): kept for the A/B option and the other kernel forms.
-enum { TVM_STORE = 0, TVM_NORM = 1, TVM_UPDATE = 2 };
+enum { TVM_STORE = 0, TVM_NORM = 1, TVM_UPDATE = 2, TVM_VALUE = 3 };   // TVM_VALUE (k_tv_march4 only): the TV value alone, no gradient
 struct TvUpd { float *x_out; const double *gnorm2; float dPOCS; int clamp; float *track; float *wrap_lo; float *wrap_hi;
                int stream; };   // stream: non-temporal stores of x_new / the snapshot (slabs beyond the Infinity Cache: -3 %; thin slabs: +3 %)
 
@@ -2154,7 +2154,8 @@ template <int TZ, bool WITH_TV, int MODE, bool EDGE, bool TRACK = false, bool ST
 __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restrict__ x, Halo h, double *__restrict__ part, float eps,
                                                     int n, int nx, int sx, int yseg, double *__restrict__ part_tv, TvUpd up)
 {
-    static_assert(MODE == TVM_NORM || MODE == TVM_UPDATE, "gradient modes without a stored gradient");
+    static_assert(MODE == TVM_NORM || MODE == TVM_UPDATE || MODE == TVM_VALUE, "modes without a stored gradient");
+    static_assert(MODE != TVM_VALUE || WITH_TV, "the value mode sums the TV integrand");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
     double acc = 0.0, tvacc = 0.0;
@@ -2237,8 +2238,8 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
         auto row = [&](int y, const float *c0, const float *cp, float *cn, float pe0, float pf0, float pc0, float pep,
                        float &pen, float &pfn, float &pcn, const float *Tp, float *Tn) __attribute__((always_inline)) {
             if (y + 1 < y1) fetch(y + 2, cn, pen, pfn, pcn);    // in flight while this row is computed
-            float TEp;
-            {   // the slice-direction term for lane 0, all columns at once (lane j <- column j): (x[s0] - x[s0-1]) R(s0-1)
+            float TEp = 0.f;
+            if (MODE != TVM_VALUE) {   // the slice-direction term for lane 0, all columns at once (lane j <- column j): (x[s0] - x[s0-1]) R(s0-1)
                 float kp = shl(0.f, pe0), r_, dd_, d1, d2, d3;  // column j+1 (wave shift: the packed columns may pass lane 15)
                 TV4_RINV(pe0, pc0, pep, kp, r_, dd_, d1, d2, d3)
                 (void)dd_; (void)d2; (void)d3;
@@ -2253,7 +2254,7 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 TV4_RINV(c, xip, cp[j], c0[j + 1], r, dd, d1, d2, d3)
                 if (WITH_TV && j >= 1) tvacc += (double)((!EDGE || (z0 + j - 1 < n && s < nx)) ? dd : 0.f);
                 const float tk = nc_mul(d3, r);                 // handed to column j+1
-                if (j >= 1) {
+                if (j >= 1 && MODE != TVM_VALUE) {
                     const float ti = nc_mul(d1, r);             // -(x_ip - c) R: minus the -slice term of the lane above
                     Tn[j] = nc_mul(d2, r);                      // -(x_jp - c) R: minus the -y term of the next row
                     const float g1 = nc_mul(nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), cp[j]), c0[j + 1]), r);
@@ -2312,7 +2313,7 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
         fetch(y0 + 1, rows[2], pe[2], pf[2], pc[2]);
         // the -y terms of row y0: (x(y0) - x(y0-1)) R(row y0-1) for the output columns
 #pragma unroll
-        for (int j = 1; j <= TZ; ++j) {
+        for (int j = 1; MODE != TVM_VALUE && j <= TZ; ++j) {
             float xi = shl(col(pf[0], j), rows[0][j]), r, dd, d1, d2, d3;
             TV4_RINV(rows[0][j], xi, rows[1][j], rows[0][j + 1], r, dd, d1, d2, d3)
             (void)dd; (void)d1; (void)d3;
@@ -2328,7 +2329,7 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
 #undef TV4_ROW
 #undef TV4_RINV
     }
-    block_accumulate(acc, part);
+    if (MODE != TVM_VALUE) block_accumulate(acc, part);
     if (WITH_TV) {
         __syncthreads();
         block_accumulate(tvacc, part_tv);

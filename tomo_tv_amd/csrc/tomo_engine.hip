@@ -1961,7 +1961,10 @@ int tomo_tv_partial(tomo_engine *e, int vol, float eps)
     if (!e->d_part_tv) { if ((rc = dev_alloc((void **)&e->d_part_tv, NPART * sizeof(double), true, e->stream))) return rc; }
     if ((rc = part_begin(e, e->d_part_tv))) return rc;
     const int yseg = 32;
-    if (e->tv_lds == 1) {
+    if (e->tv_lds == 1 && e->tv_march4 && e->nx % 64 == 0 && e->n % 8 == 0) {
+        // the value alone from the branch-free march (round 3): the R loop without the gradient half
+        hipLaunchKernelGGL((k_tv_march4<8, true, TVM_VALUE, false>), dim3(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg)), dim3(256), 0, e->stream, x, h, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
+    } else if (e->tv_lds == 1) {
         hipLaunchKernelGGL((k_tv_grad_reg<8, true, false>), dim3(tv_march_grid(e->n, 8, e->sxc / 64, (e->n + yseg - 1) / yseg)), dim3(256), 0, e->stream, x, h, (float *)nullptr, (double *)nullptr, eps, e->n, e->nx, e->sx, yseg, e->d_part_tv, TvUpd{});
     } else {
         dim3 grid((unsigned)(((e->n + 7) / 8) * (e->sxc / 64)), (unsigned)((e->n + yseg - 1) / yseg));
