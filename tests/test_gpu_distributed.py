@@ -26,3 +26,28 @@ def test_c_host_shards_through_the_native_communicator(gpu, tmp_path):
                     "-lm", "-Wl,-rpath," + libdir], check=True)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "COMM_HOST_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_c_host_two_ranks_on_two_gpus(gpu, tmp_path):
+    """The same C program as rank 0 and rank 1 of a two-GPU communicator (id passed through a file): activates by itself on a box
+    with >= 2 GPUs, skips on the single-GPU boxes of this pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    root = os.path.dirname(HERE)
+    exe, idf = str(tmp_path / "comm_host"), str(tmp_path / "comm.id")
+    libdir = os.path.join(root, "tomo_tv_amd")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", os.path.join(HERE, "native", "comm_host.c"), "-o", exe, "-L", libdir, "-ltomo_hip",
+                    "-lm", "-Wl,-rpath," + libdir], check=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, "2", str(r), idf, str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in (0, 1)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank C host timed out")
+    assert all(p.returncode == 0 for p in procs) and "COMM_HOST_OK" in outs[0][0], str(outs)[-3000:]
