@@ -65,6 +65,38 @@ for other in res[1:]:
     a, b = res[0], other
     assert np.allclose(a[0], b[0], rtol=1e-6), (a[0], b[0])
     assert all(np.array_equal(p, q) for p, q in zip(a[1:], b[1:]))
+# the fused multi-modal engine, slab-sharded on the same one-rank group (two native communicators: HAADF and chemical engine;
+# tv_gd / tv_fgp per element through the library's own ring exchange) against the single-process class
+from tomo_tv_amd.chemistry import create_weighted_summation_weights, multigpufusion, multimodal  # noqa: E402
+ha, ca = np.deg2rad(np.linspace(-60, 60, 6)), np.deg2rad(np.linspace(-50, 55, 5))
+w = create_weighted_summation_weights([30, 8], 1.6, 3)
+gt = np.stack([ellipsoids(12, N, seed=3 + e, k=6) * np.float32(0.6 + 0.3 * e) for e in range(2)])
+mm_out = []
+for cls in (multimodal, multigpufusion):
+    mm = cls(12, N, 2, ha, ca)
+    if cls is multigpufusion:
+        assert mm.ce.be.native and mm.he.be.native
+    mm.set_gamma(1.6)
+    mm.set_weights(w)
+    mm.set_volume(gt)
+    mm._mm_model()
+    mm.he.be.c("forward_projection", mm.MODEL, 0)
+    bh = mm.he.get_projections()
+    for e in range(2):
+        mm.ce.be.c("forward_projection", int(mm._x[e]), int(mm._b[e]))
+    mm.set_haadf_tilt_series(bh / bh.max())
+    mm.restart_recon()
+    mm.set_measureChem(True)
+    mm.set_measureHaadf(True)
+    mm.estimate_lipschitz()
+    c1 = [mm.poisson_ml(0.05) for _ in range(2)]
+    mm.rescale_tomograms(10)
+    mm.rescale_projections()
+    c2 = mm.sirt_data_fusion(10, 0.05, 2)
+    c3 = [mm.tv_fgp_4D(3, 1e-4), mm.tv_gd(2, 0.05)]
+    mm_out.append((np.array(c1 + list(c2) + c3), mm.get_volume()))
+assert np.allclose(mm_out[0][0], mm_out[1][0], rtol=1e-6), (mm_out[0][0], mm_out[1][0])
+assert np.array_equal(mm_out[0][1], mm_out[1][1])
 assert t.get_volume(dst=0).shape == (Nx, N, N)
 assert t.is_multi_gpu_enabled() is False and t.get_gpu_ids() == [0]
 dist.destroy_process_group()
