@@ -1638,6 +1638,14 @@ __global__ void k_halo_pack(const float *__restrict__ x, float *__restrict__ dst
 }
 
 // dst = sum of n device doubles (the partial sums several slab engines on one device hold for the same quantity)
+// scalar read-back without the copy engine: the device writes the slots straight into pinned host memory (a D2H hipMemcpyAsync
+// of 128 bytes left a ~50 us bubble on the stream after it: rocprofv3 gap analysis, round 3)
+__global__ void k_scalars_to_host(const double *__restrict__ src, double *__restrict__ host_dst, int n)
+{
+    int i = threadIdx.x;
+    if (i < n) host_dst[i] = src[i];
+}
+
 struct SumSrc { const double *p[8]; int n; };
 __global__ void k_sum_doubles(SumSrc src, double *__restrict__ dst)
 {

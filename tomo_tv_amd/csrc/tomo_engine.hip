@@ -1812,7 +1812,8 @@ int tomo_scalars_snapshot(tomo_engine *e)
         HIPCHK(hipHostMalloc((void **)&e->h_snap, TOMO_S_COUNT * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&e->ev_snap, hipEventDisableTiming));
     }
-    HIPCHK(hipMemcpyAsync(e->h_snap, e->d_scal, TOMO_S_COUNT * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    hipLaunchKernelGGL(k_scalars_to_host, dim3(1), dim3(64), 0, e->stream, (const double *)e->d_scal, e->h_snap, (int)TOMO_S_COUNT);
+    LAUNCHCHK();
     HIPCHK(hipEventRecord(e->ev_snap, e->stream));
     e->snap_pending = true;
     return TOMO_OK;
@@ -2539,7 +2540,8 @@ int tomo_comm_scalars_snapshot(tomo_engine *e)
         HIPCHK(hipHostMalloc((void **)&e->h_snap, TOMO_S_COUNT * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&e->ev_snap, hipEventDisableTiming));
     }
-    HIPCHK(hipMemcpyAsync(e->h_snap, e->comm_scal, TOMO_S_COUNT * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    hipLaunchKernelGGL(k_scalars_to_host, dim3(1), dim3(64), 0, e->stream, (const double *)e->comm_scal, e->h_snap, (int)TOMO_S_COUNT);
+    LAUNCHCHK();
     HIPCHK(hipEventRecord(e->ev_snap, e->stream));
     e->snap_pending = true;
     return TOMO_OK;
