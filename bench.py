@@ -403,11 +403,16 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     log = KernelLog(t, {"k_fp_tile": K_FP_TILE, "k_fp_tile_reduce": K_FP_REDUCE, "k_bp_tile": K_BP_TILE})
     ms = _time_steps(t, lambda: (t.SIRT(1), t.data_distance()), 5)
     pr = log.read()
+    # the step's first forward projection is the one the previous data_distance already made ("fp_reuse", bit-identical); the
+    # same loop with every projection recomputed, for the record:
+    t.set_option("fp_reuse", 0)
+    ms_noreuse = _time_steps(t, lambda: (t.SIRT(1), t.data_distance()), 5)
+    t.set_option("fp_reuse", 1)
     nnz = nnz_per_pixel_angle * n * n * P
     avg = lambda k: pr[k][1] / max(pr[k][0], 1)  # noqa: E731
     fp_ms = avg("k_fp_tile") + avg("k_fp_tile_reduce")
     out["config3_sirt_512cube_x90tilts"] = {
-        "ms_per_step": ms, "iters_per_s": 1e3 / ms,
+        "ms_per_step": ms, "iters_per_s": 1e3 / ms, "ms_per_step_every_projection_recomputed": ms_noreuse,
         # all-angle FP = k_fp_tile + k_fp_tile_reduce (4V + 4S algorithmic); one entry = one FMA and one 4-byte LDS read per slice
         "roofline_fp_all": dict(roof("k_fp_tile+k_fp_tile_reduce", 1, fp_ms, 4 * V + 4 * S, flops=2 * nnz * nx, lds_bytes=4 * nnz * nx),
                                 k_fp_tile_avg_ms=avg("k_fp_tile"), k_fp_tile_reduce_avg_ms=avg("k_fp_tile_reduce")),

@@ -111,6 +111,23 @@ def test_model_of_a_start_volume_with_negative_and_zero_voxels(gpu):
     assert rel_l2(got, want) < 1e-6
 
 
+def test_data_fusion_with_and_without_projection_reuse(gpu):
+    """multimodal::data_fusion projects the model volume for its cost and then runs SIRT from a copy of it (multimodal.cpp:452-470);
+    the engine starts that SIRT run from the projection it already has ("fp_reuse").  Bit-identical to projecting twice."""
+    outs = []
+    for reuse in (1, 0):
+        dev, ref, gt = make_case(gamma=1.6)
+        dev.he.set_option("fp_reuse", reuse)
+        dev.ce.set_option("fp_reuse", reuse)
+        for _ in range(2):
+            dev.poisson_ml(0.05)
+        dev.rescale_tomograms(10)
+        dev.rescale_projections()
+        costs = [dev.sirt_data_fusion(10, 0.05, 3) for _ in range(2)]
+        outs.append((np.array(costs), dev.get_volume()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_chemicaltomo_driver_runs_and_reduces_costs(gpu):
     """ChemicalTomo.data_fusion end to end (chemistry/reconstructor.py:182-225) on a small synthetic sample."""
     N, Nx, P = 32, 6, 11

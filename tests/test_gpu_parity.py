@@ -263,6 +263,52 @@ def test_fista_momentum_rotation_keeps_the_three_volumes(gpu, golden):
     same("restart")
 
 
+def test_projection_reuse_is_bit_identical_and_never_stale(gpu, golden):
+    """"fp_reuse": a SIRT / CGLS call whose volume is exactly what the model sinogram was last projected from starts from that
+    sinogram instead of projecting again (the reference's drivers alternate step and data_distance: gpu/reconstructor.py:61-71).
+    Same bits as always projecting -- and every way of changing the volume or the sinogram in between must drop the claim."""
+    from tomo_tv_amd._lib import SINO_G, VOL_TEMP
+    N, P, Nx = 32, 9, 4
+    A = golden(f"A_N{N}_P{P}.npz")
+    g = golden(f"trace_N{N}_P{P}_Nx{Nx}.npz")
+    ang = np.asarray(A["angles_deg"]) * np.pi / 180
+
+    def run(reuse):
+        t = tomoengine(Nx, N, ang)
+        t.set_option("fp_reuse", reuse)
+        t.set_tilt_series(g["b"])
+        out = []
+        for k in range(4):                                   # the plain driver loop: step, data_distance, step, ...
+            t.SIRT(1)
+            out.append(t.data_distance())
+        out.append(t.get_volume())
+        t.CGLS(2)                                            # restart projects the volume the last data_distance projected
+        out.append(t.get_volume())
+        hazards = [lambda: t.set_volume(g["x_sart"]), lambda: t.set_recon(g["x_sart"][1], 1), lambda: t.tv_gd(2, 0.05),
+                   lambda: t.tv_fgp(2, 0.05), lambda: t.SART(0.5, 1), lambda: t.restart_recon(), lambda: t.positivity(),
+                   lambda: (t.set_volume(g["sart_b025"], VOL_TEMP), t.be.c("forward_projection", VOL_TEMP, SINO_G)),
+                   lambda: t.be.c("set_sinogram", SINO_G, g["b"].ctypes.data), lambda: t.soft_threshold(0.01),
+                   lambda: (t.initialize_fista(), t.fista_momentum(0.3), t.remove_momentum())]
+        for h in hazards:                                    # data_distance, THEN something that changes recon or G, then a step
+            t.set_volume(g["sart_b1"])
+            t.data_distance()
+            h()
+            t.SIRT(1)
+            out.append(t.get_volume())
+        t.set_volume(g["sart_b1"])                           # a copy inherits the claim (multimodal::data_fusion's pattern)
+        t.data_distance()
+        t.be.c("copy_volume", VOL_TEMP, VOL_RECON)
+        t.be.c("sirt_data", VOL_TEMP, 0, 2)
+        out.append(t.get_volume(VOL_TEMP))
+        t.data_distance_begin(VOL_TEMP)                      # projected on the second stream, reused on the main one
+        t.be.c("sirt_data", VOL_TEMP, 0, 1)
+        out.append(t.get_volume(VOL_TEMP))
+        return out
+    a, b = run(1), run(0)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert np.array_equal(np.asarray(u), np.asarray(v)), i
+
+
 def ulp_noise(x, seed):
     """x moved by one float32 ulp in a random direction per element: the smallest possible input change."""
     rng = np.random.default_rng(seed)

@@ -511,6 +511,25 @@ __global__ __launch_bounds__(256) void k_fp_tile_reduce(const float *__restrict_
     }
 }
 
+// residual rows from a projection already in hand: the epilogues of k_fp_tile_reduce / k_fp_rows in FP_RESID and FP_RESID_NORM
+// mode applied to a stored g = A x (same expressions, so the same bits as projecting again)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sino_resid(const float *__restrict__ b, const float *__restrict__ g,
+                                                     const float *__restrict__ rowsum, float *__restrict__ out, int64_t n4, int sx4)
+{
+    typedef VecOf<4>::T V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        V bv = reinterpret_cast<const V *>(b)[i], acc = reinterpret_cast<const V *>(g)[i], r;
+        if (MODE == FP_RESID) {
+            r = bv - acc;
+        } else {
+            float rs = rowsum[i / sx4];
+            r = rs > 0.f ? (bv - acc) / rs : vzero<4>();
+        }
+        reinterpret_cast<V *>(out)[i] = r;
+    }
+}
+
 // ---- voxel-driven back-projector, one angle (the SART update) ---------------------------------------
 // x[p][s] = max(0, x[p][s] + beta * (w0 r[j0][s] + w1 r[j1][s]) / (w0 + w1))
 // cell[p] = {j0, w0, j1, w1}: the (at most two) rays of this angle through pixel p.  r = this angle's

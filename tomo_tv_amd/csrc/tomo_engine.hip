@@ -214,6 +214,11 @@ struct tomo_engine {
     float *comm_send_first = nullptr, *comm_send_last = nullptr, *comm_g_lo = nullptr, *comm_g_hi = nullptr;   // N*N planes
     float *comm_fgp = nullptr;                    // the engine's own planes of the fused FGP exchange when the host binds none
     double *comm_scal = nullptr;                  // TOMO_S_COUNT doubles: the all-reduced copy of the scalar buffer
+    // "the model sinogram G is A * (volume v in its present state)": set by a plain projection into G (tomo_forward_projection,
+    // tomo_data_distance_sq), inherited by a copy of v, dropped by anything else that touches G or writes v (fp_reuse, below)
+    uint64_t vol_version[TOMO_VOL_SLOTS] = {};
+    struct { int vol = -1; uint64_t ver = 0; } g_valid[2];
+    int fp_reuse = 1;
     bool old_is_recon = false;                    // RECON_OLD's content is RECON's (tomo_fista_momentum; see get_vol)
     bool geometry_released = false;               // tomo_release_geometry: only tomo_adopt_volumes / tomo_destroy remain valid
     // halos
@@ -232,6 +237,23 @@ static int dev_alloc(void **p, size_t bytes, bool zero, hipStream_t st)
     HIPCHK(hipMalloc(p, bytes ? bytes : 4));
     if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes ? bytes : 4, st));
     return TOMO_OK;
+}
+
+// ---- a projection already in hand is not computed again -------------------------------------------------------------------
+// The reference's drivers evaluate `data_distance()` after every SIRT / CGLS step (gpu/reconstructor.py:61-71, show_convergence
+// defaults to True) and the next step starts by projecting the very same volume; multimodal::data_fusion projects the model
+// volume for its cost and then starts a SIRT run from a copy of it (multimodal.cpp:452-470).  The engine remembers which volume
+// (slot and write-version) the model sinogram G was projected from; a SIRT / CGLS call whose volume is still that one forms its
+// first residual from G instead of projecting again -- the same kernels produced G, so the bits are the same ("fp_reuse" = 0
+// switches it off).  Conservative by construction: every write-intent access of a volume (get_vol) bumps its version, every
+// access of G through the slot accessors drops the claim, and only the two plain projections make it.
+static void g_clear(tomo_engine *e) { e->g_valid[0].vol = e->g_valid[1].vol = -1; }
+static void g_set(tomo_engine *e, int vol) { e->g_valid[0].vol = vol; e->g_valid[0].ver = e->vol_version[vol]; e->g_valid[1].vol = -1; }
+static bool g_is_projection_of(const tomo_engine *e, int vol)
+{
+    if (!e->fp_reuse || vol < 0 || vol >= TOMO_VOL_SLOTS || !e->sino[TOMO_SINO_G]) return false;
+    for (int k = 0; k < 2; ++k) if (e->g_valid[k].vol == vol && e->g_valid[k].ver == e->vol_version[vol]) return true;
+    return false;
 }
 
 // After a Nesterov step recon_old == recon (tomoengine.cpp:381-384 copies the prox result into both).  The step keeps that as a
@@ -253,6 +275,7 @@ static int get_vol_ro(tomo_engine *e, int id, float **out)
 static int get_vol(tomo_engine *e, int id, float **out)
 {
     if (id < 0 || id >= TOMO_VOL_SLOTS) return fail(TOMO_ERR_ARG, "bad volume id");
+    ++e->vol_version[id];                               // the caller may write it
     if (e->old_is_recon && (id == TOMO_VOL_RECON || id == TOMO_VOL_RECON_OLD)) {
         e->old_is_recon = false;
         float *src, *dst; int rc;
@@ -264,6 +287,7 @@ static int get_vol(tomo_engine *e, int id, float **out)
 
 static int get_sino(tomo_engine *e, float **slot, float **out)
 {
+    if (slot == &e->sino[TOMO_SINO_G]) g_clear(e);      // whoever asks for G may overwrite it
     if (!*slot) {
         int rc = dev_alloc((void **)slot, e->sino_elems() * sizeof(float), true, e->stream);
         if (rc) return rc;
@@ -482,6 +506,16 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fp_red[which][0], 0));
         if (k >= 2) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_fp_red[which][1], 0));
     }
+    return TOMO_OK;
+}
+
+// residual rows from a projection already in G (fp_reuse)
+template <int MODE>
+static int launch_sino_resid(tomo_engine *e, const float *b, const float *g, float *out)
+{
+    const int64_t n4 = (int64_t)e->sino_elems() / 4;
+    hipLaunchKernelGGL((k_sino_resid<MODE>), dim3(grid_1d(n4)), dim3(256), 0, e->stream, b, g, e->d_rowsum, out, n4, e->sx / 4);
+    LAUNCHCHK();
     return TOMO_OK;
 }
 
@@ -1055,6 +1089,8 @@ int tomo_adopt_volumes(tomo_engine *dst, tomo_engine *src)
     }
     dst->old_is_recon = src->old_is_recon;
     src->old_is_recon = false;
+    for (int i = 0; i < TOMO_VOL_SLOTS; ++i) ++dst->vol_version[i];
+    g_clear(dst);
     return TOMO_OK;
 }
 
@@ -1185,6 +1221,7 @@ int tomo_restart_recon(tomo_engine *e)
     if (e->vol[TOMO_VOL_YK]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_YK], 0, e->vol_elems() * sizeof(float), e->stream));
     if (e->vol[TOMO_VOL_RECON_OLD]) HIPCHK(hipMemsetAsync(e->vol[TOMO_VOL_RECON_OLD], 0, e->vol_elems() * sizeof(float), e->stream));
     e->old_is_recon = false;                       // every buffer is physically zero
+    ++e->vol_version[TOMO_VOL_RECON]; ++e->vol_version[TOMO_VOL_YK]; ++e->vol_version[TOMO_VOL_RECON_OLD];
     return TOMO_OK;
 }
 
@@ -1193,8 +1230,10 @@ int tomo_copy_volume(tomo_engine *e, int dst, int src)
     NEED(e);
     { int rc_ = order_after_async(e); if (rc_) return rc_; }
     float *d, *s; int rc;
-    if ((rc = get_vol(e, dst, &d)) || (rc = get_vol(e, src, &s))) return rc;
+    const bool g_src = g_is_projection_of(e, src);
+    if ((rc = get_vol(e, dst, &d)) || (rc = get_vol_ro(e, src, &s))) return rc;
     if (d != s) HIPCHK(hipMemcpyAsync(d, s, e->vol_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    if (g_src && dst != src) { e->g_valid[1].vol = dst; e->g_valid[1].ver = e->vol_version[dst]; }   // G = A * src = A * dst
     return TOMO_OK;
 }
 
@@ -1206,7 +1245,9 @@ int tomo_forward_projection(tomo_engine *e, int vol, int sino)
     float *x, *g; int rc;
     if ((rc = get_vol_ro(e, vol, &x))) return rc;
     if ((rc = sino_slot(e, sino, &g))) return rc;
-    return launch_fp_all<FP_STORE>(e, x, nullptr, g);
+    if ((rc = launch_fp_all<FP_STORE>(e, x, nullptr, g))) return rc;
+    if (sino == TOMO_SINO_G) g_set(e, vol);
+    return TOMO_OK;
 }
 
 int tomo_back_projection(tomo_engine *e, int sino, int vol)
@@ -1259,9 +1300,12 @@ int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter)
 {
     NEED(e);
     float *x, *r, *b; int rc;
+    const bool reuse = niter > 0 && sino_b != TOMO_SINO_G && g_is_projection_of(e, vol);   // G is A * this volume, as it stands
+    if (reuse) { if ((rc = order_after_async(e))) return rc; }                            // (an evaluation on the second stream made it)
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, sino_b, &b))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if ((rc = launch_fp_all<FP_RESID_NORM>(e, x, b, r))) return rc;
+        if (it == 0 && reuse) { if ((rc = launch_sino_resid<FP_RESID_NORM>(e, b, e->sino[TOMO_SINO_G], r))) return rc; }
+        else if ((rc = launch_fp_all<FP_RESID_NORM>(e, x, b, r))) return rc;
         if ((rc = launch_bp_all(e, x, r, e->d_colsum_all, 1.f, 1.f, 1))) return rc;
     }
     return TOMO_OK;
@@ -1507,6 +1551,8 @@ int tomo_cgls(tomo_engine *e, int vol, int niter)
 {
     NEED(e);
     float *x, *r, *b, *w; int rc;
+    const bool reuse_g = g_is_projection_of(e, vol);        // the restart's A x is already in G (a data_distance of this volume)
+    if (reuse_g) { if ((rc = order_after_async(e))) return rc; }
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, TOMO_SINO_B, &b))) return rc;
     if ((rc = get_scratch(e, &e->cg_p, &w)) || (rc = get_scratch(e, &e->cg_z, &w))) return rc;
     if ((rc = get_sino(e, &e->cg_w, &w))) return rc;
@@ -1518,7 +1564,8 @@ int tomo_cgls(tomo_engine *e, int vol, int niter)
         hipLaunchKernelGGL(k_slice_ratio, dim3((e->sx + 255) / 256), dim3(256), 0, e->stream, num, den, e->cg_coef, e->sx);
     };
     // r = b - A x ; z = A^T r ; p = z ; gamma = |z|^2
-    if ((rc = launch_fp_all<FP_RESID>(e, x, b, r))) return rc;
+    if (reuse_g) { if ((rc = launch_sino_resid<FP_RESID>(e, b, e->sino[TOMO_SINO_G], r))) return rc; }
+    else if ((rc = launch_fp_all<FP_RESID>(e, x, b, r))) return rc;
     if ((rc = launch_bp_all(e, e->cg_z, r, nullptr, 0.f, 1.f, 0))) return rc;
     HIPCHK(hipMemcpyAsync(e->cg_p, e->cg_z, nv * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
     if ((rc = slice_sumsq(e, e->cg_z, e->npix, gam))) return rc;
@@ -1714,6 +1761,7 @@ int tomo_fista_momentum(tomo_engine *e, float beta)
     int64_t n4 = e->vol_elems() / 4;
     hipLaunchKernelGGL(k_momentum, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const f4 *)yk, (const f4 *)old, (f4 *)x, beta, n4);
     LAUNCHCHK();
+    ++e->vol_version[TOMO_VOL_RECON]; ++e->vol_version[TOMO_VOL_YK]; ++e->vol_version[TOMO_VOL_RECON_OLD];
     e->vol[TOMO_VOL_RECON] = yk;                          // the prox result r
     e->vol[TOMO_VOL_YK] = x;                              // r + beta (r - old), written over the buffer recon has left
     e->old_is_recon = true;                               // recon_old == r, not stored
@@ -1728,6 +1776,7 @@ int tomo_data_distance_sq(tomo_engine *e, int vol)
     if ((rc = get_vol_ro(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_G], &g))) return rc;
     if ((rc = reduce_begin(e))) return rc;
     if ((rc = launch_fp_all<FP_DD>(e, x, e->sino[TOMO_SINO_B], g))) return rc;
+    g_set(e, vol);                                      // FP_DD also stores g = A x
     return reduce_end(e, TOMO_S_DD);
 }
 
@@ -2218,6 +2267,8 @@ int tomo_fgp_grad(tomo_engine *e, float lambda)
 
 int tomo_fgp_end(tomo_engine *e, int iters)
 {
+    if (e && e->fgp_target >= 0 && e->fgp_target < TOMO_VOL_SLOTS) ++e->vol_version[e->fgp_target];   // the prox result lands in the volume
+
     NEED(e);
     if (!e->tvg) return fail(TOMO_ERR_STATE, "tomo_fgp_begin has not been called");
     (void)iters;  // D is the zero-filled buffer when no iteration ran, exactly like d_update (tv_fgp.cu:223,272)
@@ -2322,6 +2373,8 @@ int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration)
 // the last iteration only needs D (tv_fgp.cu:272), written straight over the target volume
 int tomo_fgp_fused_end(tomo_engine *e, float lambda)
 {
+    if (e && e->fgp_target >= 0 && e->fgp_target < TOMO_VOL_SLOTS) ++e->vol_version[e->fgp_target];   // the prox result lands in the volume
+
     NEED(e);
     if (!e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
     ProfScope ps(e, TOMO_K_FGP_OBJ);
@@ -2607,6 +2660,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
 #ifdef TOMO_WHATIF
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
+    if (std::strcmp(name, "fp_reuse") == 0) { e->fp_reuse = value != 0; g_clear(e); return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_pipe") == 0) { e->fp_tile_pipe = std::max(0, value); return TOMO_OK; }
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? std::min(value, (int)tomo_engine::MAX_CHAINS) : (value == 1 ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "art_tile") == 0) { e->art_tile = value ? 1 : 0; return TOMO_OK; }
