@@ -392,11 +392,17 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
         tk = 0.5 * (1 + np.sqrt(1 + 4 * st["t0"] ** 2))
         t.fista_momentum((st["t0"] - 1) / tk)
         st["t0"] = tk
-        return 0.5 * t.data_distance() ** 2 + 0.1 * t.tv()
+        cost = 0.5 * t.data_distance() ** 2 + 0.1 * t.tv()
+        t.fista_project_yk()            # what TomoGPU.fista does: A yk for the next step from this A r and the last (linearity)
+        return cost
     log = KernelLog(t, {"k_fgp_fused": K_FGP_GRAD})
     ms = _time_steps(t, fista_iter, 5)
     cnt, tot, busy = log.read()["k_fgp_fused"]
-    out["config3_fista_512cube_x90tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
+    t.set_option("fp_reuse", 0)
+    ms_noreuse = _time_steps(t, fista_iter, 5)
+    t.set_option("fp_reuse", 1)
+    out["config3_fista_512cube_x90tilts"] = {"ms_per_step": ms, "ms_per_step_every_projection_recomputed": ms_noreuse,
+                                             "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
                                              "roofline": roof("k_fgp_fused", cnt, tot, 28 * V, busy_ms=busy)}
     t.remove_momentum()
     t.restart_recon()

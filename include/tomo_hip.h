@@ -139,6 +139,10 @@ int tomo_scale_volume(tomo_engine *e, int vol, float factor);           /* multi
 int tomo_positivity(tomo_engine *e, int vol);                           /* ctvlib.cpp:224-231 */
 int tomo_soft_threshold(tomo_engine *e, int vol, float lambda);         /* matrix_ops.cu:64-75 */
 int tomo_fista_momentum(tomo_engine *e, float beta);                    /* tomoengine.cpp:381-384 */
+/* A yk = (1 + beta) A recon - beta A recon_old by linearity, from the projections the driver's cost evaluation made anyway
+ * (gpu/reconstructor.py:121-155): call after tomo_data_distance_sq(RECON); a no-op unless provably valid; *done = 1 when the model
+ * sinogram now holds A yk and the next tomo_sirt(YK) will start from it */
+int tomo_fista_project_yk(tomo_engine *e, int *done);
 
 /* ---- scalar reductions: partial sums of this slab land in the device scalar buffer ------------------ */
 int tomo_data_distance_sq(tomo_engine *e, int vol);                     /* tomoengine.cpp:410-413 -> TOMO_S_DD (also fills G) */
@@ -275,7 +279,13 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "bp_tile" (1):    all-angle back-projection from LDS-staged residual-row windows (k_bp_tile; bit-identical to the
  *                     pixel-driven k_bp_all it replaces; used when every tile's ray window fits, else k_bp_all)
  *   "fp_all_lpr" (16): ray-driven all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks
- *                     (0 = wide form) */
+ *                     (0 = wide form)
+ *   "fp_reuse" (1):   a tomo_sirt / tomo_sirt_data / tomo_cgls call whose volume is exactly what the model sinogram was last
+ *                     projected from (tomo_forward_projection into TOMO_SINO_G, tomo_data_distance_sq; tracked by slot and
+ *                     write-version, inherited by tomo_copy_volume) starts from that sinogram instead of projecting again:
+ *                     bit-identical.  Also gates tomo_fista_project_yk.  0 = every projection recomputed
+ *   "fp_tile_pipe" (0): experimental: the tile projector's reduce pass of one chunk group overlapped with the tile pass of
+ *                     the next on a second stream (no gain measured) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
 /* ---- native communicator: the slab-sharded path over RCCL on the engine's own stream ---------------------------------------
  * Replaces, for a C / C++ host as for the Python one, the MPI calls of the reference's sharded CPU engine (mpi_ctvlib.cpp:400-422

@@ -309,6 +309,77 @@ def test_projection_reuse_is_bit_identical_and_never_stale(gpu, golden):
         assert np.array_equal(np.asarray(u), np.asarray(v)), i
 
 
+def test_fista_projects_the_extrapolated_point_by_linearity(gpu, golden):
+    """tomo_fista_project_yk: A yk = (1 + beta) A r - beta A r_old from the two projections the cost evaluations made.  The shortcut
+    must (a) actually be taken in the driver loop from the second iteration on, (b) stay within the parity tolerance of the loop
+    that projects yk every time, and (c) refuse whenever a volume it relies on was touched in between."""
+    from tomo_tv_amd._lib import SINO_G, VOL_YK, VOL_RECON_OLD
+    N, P, Nx = 32, 9, 4
+    A = golden(f"A_N{N}_P{P}.npz")
+    g = golden(f"trace_N{N}_P{P}_Nx{Nx}.npz")
+    ang = np.asarray(A["angles_deg"]) * np.pi / 180
+
+    def loop(reuse, niter=6, meddle=None):
+        t = tomoengine(Nx, N, ang)
+        t.set_option("fp_reuse", reuse)
+        t.set_tilt_series(g["b"])
+        pytvlib.initialize_algorithm(t, "fista")
+        t0, taken, costs = 1.0, [], []
+        for k in range(niter):
+            pytvlib.run(t, "fista")
+            t.tv_fgp(5, 0.1, vol=VOL_YK)
+            tk = 0.5 * (1 + np.sqrt(1 + 4 * t0 ** 2))
+            t.fista_momentum((t0 - 1) / tk)
+            t0 = tk
+            costs.append(0.5 * t.data_distance() ** 2 + 0.1 * t.tv())
+            if meddle is not None and k == 3:
+                meddle(t, "before")
+            taken.append(t.fista_project_yk())
+            if meddle is not None and k == 3:
+                meddle(t, "after")
+        return t.get_volume(), t.get_volume(VOL_YK), np.array(costs), taken
+    x1, y1, c1, taken = loop(1)
+    x0, y0, c0, never = loop(0)
+    assert taken == [True] * 6 and never == [False] * 6      # (iteration 1: beta = 0, yk is r itself)
+    assert rel_l2(x1, x0) < TOL and rel_l2(y1, y0) < TOL and np.allclose(c1, c0, rtol=1e-5)
+    # the projection it leaves IS the projection of yk, to rounding
+    t = tomoengine(Nx, N, ang)
+    t.set_tilt_series(g["b"])
+    pytvlib.initialize_algorithm(t, "fista")
+    for beta in (0.0, 0.28, 0.43):
+        pytvlib.run(t, "fista")
+        t.tv_fgp(3, 0.1, vol=VOL_YK)
+        t.fista_momentum(beta)
+        t.data_distance()
+        assert t.fista_project_yk()
+        lin = np.zeros((Nx, N * P), np.float32)
+        t.be.c("get_sinogram", SINO_G, lin.ctypes.data)
+        t.be.c("forward_projection", VOL_YK, SINO_G)
+        direct = np.zeros_like(lin)
+        t.be.c("get_sinogram", SINO_G, direct.ctypes.data)
+        assert rel_l2(lin, direct) < 1e-6
+    # hazards: anything that changes recon / yk / recon_old between the pieces makes the next shortcut refuse (and the loop
+    # that follows equals the always-project loop given the same meddling)
+    def hazard(fn, when):
+        def meddle(t, at):
+            if at == when:
+                fn(t)
+        a = loop(1, meddle=meddle)
+        b = loop(0, meddle=meddle)
+        assert rel_l2(a[0], b[0]) < TOL and rel_l2(a[1], b[1]) < TOL, (fn, when)
+        return a[3]
+    tk_before = hazard(lambda t: t.set_volume(g["sart_b1"]), "before")            # recon changed after its projection
+    assert tk_before[3] is False
+    tk = hazard(lambda t: t.set_volume(g["sart_b1"], VOL_YK), "before")           # yk is no longer the extrapolated point
+    assert tk[3] is False
+    tk = hazard(lambda t: t.set_volume(g["sart_b1"]), "after")                    # recon (-> recon_old) changed after saving A r
+    assert tk[3] is True and tk[4] is False and tk[5] is True
+    tk = hazard(lambda t: t.set_volume(g["sart_b025"], VOL_RECON_OLD), "after")   # recon_old is not the iterate that was projected
+    assert tk[4] is False
+    tk = hazard(lambda t: t.set_volume(g["sart_b025"], VOL_YK), "after")          # yk replaced after A yk was formed: SIRT must project
+    assert tk[3] is True
+
+
 def ulp_noise(x, seed):
     """x moved by one float32 ulp in a random direction per element: the smallest possible input change."""
     rng = np.random.default_rng(seed)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "tomo_positivity": [_p, _i],
     "tomo_soft_threshold": [_p, _i, _f],
     "tomo_fista_momentum": [_p, _f],
+    "tomo_fista_project_yk": [_p, ctypes.POINTER(_i)],
     "tomo_data_distance_sq": [_p, _i],
     "tomo_diff_norm_sq": [_p, _i, _i, _i],
     "tomo_data_distance_sq_async": [_p, _i],

@@ -530,6 +530,16 @@ __global__ __launch_bounds__(256) void k_sino_resid(const float *__restrict__ b,
     }
 }
 
+// p <- (1 + beta) g - beta p : the projection of the Nesterov point y = r + beta (r - r_old) by linearity from A r (g) and A r_old (p)
+__global__ __launch_bounds__(256) void k_sino_extrapolate(const VecOf<4>::T *__restrict__ g, VecOf<4>::T *__restrict__ p, float beta,
+                                                          int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        VecOf<4>::T a = g[i], b = p[i];
+        p[i] = a + beta * (a - b);
+    }
+}
+
 // ---- voxel-driven back-projector, one angle (the SART update) ---------------------------------------
 // x[p][s] = max(0, x[p][s] + beta * (w0 r[j0][s] + w1 r[j1][s]) / (w0 + w1))
 // cell[p] = {j0, w0, j1, w1}: the (at most two) rays of this angle through pixel p.  r = this angle's

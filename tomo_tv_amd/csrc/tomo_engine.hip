@@ -219,6 +219,11 @@ struct tomo_engine {
     uint64_t vol_version[TOMO_VOL_SLOTS] = {};
     struct { int vol = -1; uint64_t ver = 0; } g_valid[2];
     int fp_reuse = 1;
+    // FISTA: the projection of the extrapolated point by linearity (tomo_fista_project_yk)
+    float *g_prev = nullptr;                      // A * (the iterate before the last Nesterov step)
+    bool g_prev_valid = false, mom_p_ok = false;
+    uint64_t g_prev_recon_ver = 0;
+    struct { float beta = 0.f; uint64_t ver_recon = 0, ver_yk = 0, ver_old = 0; bool set = false; } mom;
     bool old_is_recon = false;                    // RECON_OLD's content is RECON's (tomo_fista_momentum; see get_vol)
     bool geometry_released = false;               // tomo_release_geometry: only tomo_adopt_volumes / tomo_destroy remain valid
     // halos
@@ -1030,6 +1035,8 @@ static void free_geometry(tomo_engine *e)
                      (void **)&e->d_rowcross, (void **)&e->d_cell};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
+    if (e->g_prev) { (void)hipFree(e->g_prev); e->g_prev = nullptr; }
+    e->g_prev_valid = e->mom_p_ok = e->mom.set = false;
     e->geometry_released = true;
 }
 
@@ -1753,6 +1760,10 @@ int tomo_fista_momentum(tomo_engine *e, float beta)
     // the buffer recon has just left -- which, from the second step on, is also where `old` sits (old == recon then): the step
     // reads two volumes and writes one (round 2: two reads, three stores: 645 us at 512^3).  Same expression, same bits.
     { int rc_ = order_after_async(e); if (rc_) return rc_; }
+    // is the saved projection (tomo_fista_project_yk) A * (what recon_old holds now)?  recon_old was set to recon by the last step and
+    // neither has been touched since, and the projection was saved from that very recon
+    e->mom_p_ok = e->g_prev_valid && e->mom.set && e->vol_version[TOMO_VOL_RECON] == e->mom.ver_recon
+                  && e->vol_version[TOMO_VOL_RECON_OLD] == e->mom.ver_old && e->g_prev_recon_ver == e->vol_version[TOMO_VOL_RECON];
     float *x, *yk, *old; int rc;
     const bool aliased = e->old_is_recon;
     if ((rc = get_vol_ro(e, TOMO_VOL_RECON, &x)) || (rc = get_vol_ro(e, TOMO_VOL_YK, &yk))) return rc;
@@ -1765,6 +1776,48 @@ int tomo_fista_momentum(tomo_engine *e, float beta)
     e->vol[TOMO_VOL_RECON] = yk;                          // the prox result r
     e->vol[TOMO_VOL_YK] = x;                              // r + beta (r - old), written over the buffer recon has left
     e->old_is_recon = true;                               // recon_old == r, not stored
+    e->mom.beta = beta; e->mom.set = true;
+    e->mom.ver_recon = e->vol_version[TOMO_VOL_RECON]; e->mom.ver_yk = e->vol_version[TOMO_VOL_YK]; e->mom.ver_old = e->vol_version[TOMO_VOL_RECON_OLD];
+    return TOMO_OK;
+}
+
+// FISTA's next gradient step projects yk = r + beta (r - r_old).  The driver has just projected r for its cost
+// (gpu/reconstructor.py:121-155: data_distance after every iteration) and projected r_old one iteration earlier, and the projector
+// is linear: A yk = (1 + beta) A r - beta A r_old, a pass over two sinograms (94 MB) instead of a projection of the volume.  Call it
+// after data_distance(recon); it does nothing unless every piece is provably in place (G = A recon as it stands, recon / yk /
+// recon_old untouched since the last tomo_fista_momentum, the saved A r_old from the very iterate recon_old holds), and then leaves
+// G = A yk with the claim the next tomo_sirt on yk picks up ("fp_reuse").  *done = 1 when the projection was formed.  Not
+// bit-identical to projecting yk (rounding of the combination, ~1e-7 of |b|): parity tests hold it to the oracle at 1e-5 like
+// every other path.
+int tomo_fista_project_yk(tomo_engine *e, int *done)
+{
+    NEED(e);
+    if (done) *done = 0;
+    if (!e->fp_reuse || !g_is_projection_of(e, TOMO_VOL_RECON) || !e->mom.set) return TOMO_OK;
+    if (e->vol_version[TOMO_VOL_RECON] != e->mom.ver_recon || e->vol_version[TOMO_VOL_YK] != e->mom.ver_yk) return TOMO_OK;
+    { int rc_ = order_after_async(e); if (rc_) return rc_; }
+    int rc; float *p;
+    if ((rc = get_sino(e, &e->g_prev, &p))) return rc;
+    float *g = e->sino[TOMO_SINO_G];
+    const int64_t n4 = (int64_t)e->sino_elems() / 4;
+    const bool have_prev = e->mom_p_ok;
+    if (have_prev) {
+        hipLaunchKernelGGL(k_sino_extrapolate, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const VecOf<4>::T *)g, (VecOf<4>::T *)p, e->mom.beta, n4);
+        LAUNCHCHK();
+        e->sino[TOMO_SINO_G] = p;                           // A yk; the buffer that held A r becomes the saved projection
+        e->g_prev = g;
+    } else {
+        HIPCHK(hipMemcpyAsync(p, g, e->sino_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));   // first step: only save A r
+    }
+    e->g_prev_valid = true;
+    e->g_prev_recon_ver = e->vol_version[TOMO_VOL_RECON];
+    if (have_prev || e->mom.beta == 0.f) {                  // (beta = 0: yk is r, bit for bit)
+        g_set(e, TOMO_VOL_YK);
+        if (done) *done = 1;
+    } else {
+        g_clear(e);
+        g_set(e, TOMO_VOL_RECON);
+    }
     return TOMO_OK;
 }
 

@@ -827,6 +827,15 @@ class _EngineBase:
     def fista_momentum(self, beta):
         self.be.c("fista_momentum", float(beta))
 
+    def fista_project_yk(self):
+        """After ``data_distance()`` of the iterate: the projection of the extrapolated point by linearity,
+        A yk = (1 + beta) A r - beta A r_old, from the two projections the cost evaluations made anyway; the next gradient step
+        starts from it instead of projecting yk (include/tomo_hip.h: tomo_fista_project_yk).  A no-op whenever the engine
+        cannot prove the pieces are in place; returns whether the projection was formed."""
+        done = ctypes.c_int(0)
+        self.be.c("fista_project_yk", ctypes.byref(done))
+        return bool(done.value)
+
     def synchronize(self):
         self.be.c("synchronize")
 

@@ -112,6 +112,8 @@ class TomoGPU:
                 t.tv_fgp(nTViter, lambda_param)
             if show_convergence:
                 self.cost[k] = 0.5 * t.data_distance() ** 2 + lambda_param * t.tv()
+                if momentum:
+                    t.fista_project_yk()                      # the cost's A r gives the next step's A yk by linearity
         return self.cost
 
     def asd_pocs(self, Niter=100, eps=0.025, beta0=0.25, beta_reduce=0.9985, r_max=0.95, nTViter=10, alpha=0.2,
