@@ -1797,6 +1797,45 @@ __device__ __forceinline__ float nc_sub(float a, float b)
 #pragma clang fp contract(off)
     return a - b;
 }
+// The same three on a PAIR of values: gfx950 issues v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 at the rate of their scalar
+// forms (two IEEE results per lane per issue, each rounded exactly like the scalar instruction), so arithmetic written on pairs
+// costs half the vector-ALU cycles and keeps every bit.
+// A wave-uniform pointer pinned in scalar registers, accessed with a 32-bit per-lane BYTE offset: the "scalar base + vector
+// offset" form of the global instructions, no address arithmetic per access when the offsets are loop invariants.  Left alone,
+// the optimiser re-associates (row base + column offset) + lane into (row base + lane) + column offset and pays a 64-bit VECTOR
+// add per access (30 of the ~270 vector instructions of a TV march row).
+struct SBase { const __attribute__((address_space(1))) char *p; };
+__device__ __forceinline__ SBase sgpr_base(const void *p)
+{
+    asm("" : "+s"(p));
+    return SBase{(const __attribute__((address_space(1))) char *)p};   // (the barrier hides that p is global memory: say so)
+}
+// (the offset is re-pinned at every use, in place: its zero-extension to 64 bits must sit next to the access for the instruction
+// selector to fold it -- hoisted out of the loop it costs a register pair per offset and a 64-bit vector add per access again)
+__device__ __forceinline__ float ld_so(SBase b, unsigned &byte_off)
+{
+    asm("" : "+v"(byte_off));
+    return *(const __attribute__((address_space(1))) float *)(b.p + byte_off);
+}
+template <bool NT> __device__ __forceinline__ void st_so(SBase b, unsigned &byte_off, float v)
+{
+    asm("" : "+v"(byte_off));
+    auto q = (__attribute__((address_space(1))) float *)(b.p + byte_off);
+    if (NT) __builtin_nontemporal_store(v, q);
+    else *q = v;
+}
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f nc_mul2(v2f a, v2f b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ v2f nc_sub2(v2f a, v2f b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 __device__ __forceinline__ float tv_gval(float c, float xip, float xjp, float xkp, float r0, float xim, float rim,
                                           float xjm, float rjm, float xkm, float rkm)
@@ -2183,6 +2222,9 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 // Occupancy: the update pass fits 96 VGPRs (5 waves per SIMD) without a spill, the norm pass does not (62 spilled registers at 5
 // waves: 816 us measured with an earlier form); TV4_UPD_WAVES (build-time) asks for 5 on the update pass only -- measured 377.7 vs
 // 376.0 us per inner iteration at 512 slices and 65.6 vs 57.8 at 64: the compiler's own choice (120 VGPRs, 4 waves) stays.
+#ifndef TV4_PACKED
+#define TV4_PACKED 1
+#endif
 #ifndef TV4_UPD_WAVES
 #define TV4_UPD_WAVES 4
 #endif
@@ -2231,18 +2273,20 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
         const bool lo_in = s0 > 0, hi_in = s0 + 64 < nx;
         const unsigned zls = (unsigned)zl * (unsigned)sx;
         const unsigned off_lo = lo_in ? zls + (unsigned)(s0 - 1) : (unsigned)zl, off_hi = hi_in ? zls + (unsigned)(s0 + 64) : (unsigned)zl;
-        unsigned zcs[TZ + 2];
+        unsigned vb[TZ + 2];                // byte offsets of the lane's voxel in the columns of a row: loop invariants
 #pragma unroll
-        for (int j = 0; j < TZ + 2; ++j) zcs[j] = (unsigned)zc[j] * (unsigned)sx + (unsigned)s0;
+        for (int j = 0; j < TZ + 2; ++j) vb[j] = ((unsigned)zc[j] * (unsigned)sx + (unsigned)s0 + (unsigned)lane) * 4u;
+        unsigned eb_c = (zls + (unsigned)s0) * 4u, eb_lo = off_lo * 4u, eb_hi = off_hi * 4u;
         auto fetch = [&](int y, float *c, float &e_lo, float &e_hi, float &e_c) __attribute__((always_inline)) {
             int yy = yrow(y) * n;
             if (!EDGE) {
                 const float *rowp = x + (size_t)yy * sx;            // wave-uniform
+                const SBase rb = sgpr_base(rowp);
 #pragma unroll
-                for (int j = 0; j < TZ + 2; ++j) c[j] = (rowp + zcs[j])[(unsigned)lane];
-                e_c = rowp[zls + (unsigned)s0];
-                e_lo = (lo_in ? rowp : h.lo + yy)[off_lo];
-                e_hi = (hi_in ? rowp : h.hi + yy)[off_hi];
+                for (int j = 0; j < TZ + 2; ++j) c[j] = ld_so(rb, vb[j]);
+                e_c = ld_so(rb, eb_c);
+                e_lo = ld_so(sgpr_base(lo_in ? rowp : h.lo + yy), eb_lo);
+                e_hi = ld_so(sgpr_base(hi_in ? rowp : h.hi + yy), eb_hi);
             } else {
 #pragma unroll
                 for (int j = 0; j < TZ + 2; ++j) c[j] = tv_ld(x, h, yy + zc[j], s, nx, sx);
@@ -2276,14 +2320,66 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                        float &pen, float &pfn, float &pcn, const float *Tp, float *Tn) __attribute__((always_inline)) {
             if (y + 1 < y1) fetch(y + 2, cn, pen, pfn, pcn);    // in flight while this row is computed
             float TEp = 0.f;
+            float out[TZ + 1];                                  // the row's results: g (norm pass) or x_new (update pass)
+            float tk_prev = 0.f;                                // -(x_kp - c) R of column j-1: minus the -z term of column j
+#if TV4_PACKED
+            // The columns two at a time on packed fp32 instructions (nc_mul2 / nc_sub2 / fma2: same roundings as the scalar
+            // column loop below, half the issue slots).  Column 0, of which only the -z term is needed, shares its evaluation
+            // with the slice-direction term of lane 0.
+            static_assert((TZ & 1) == 0, "column pairs");
+#define TV4_RINV2(C, IP, JP, KP, RR, DD, D1, D2, D3)                                                      \
+            {                                                                                             \
+                D1 = (C) - (IP); D2 = (C) - (JP); D3 = (C) - (KP);                                        \
+                const v2f q_ = fma2(D3, D3, fma2(D2, D2, fma2(D1, D1, v2f{eps, eps})));                   \
+                RR = v2f{tv_rsqrt(q_.x), tv_rsqrt(q_.y)};                                                 \
+                DD = nc_mul2(q_, RR);                                                                     \
+            }
+            {
+                const float kpe = MODE != TVM_VALUE ? shl(0.f, pe0) : 0.f;   // column j+1 (wave shift: the packed columns may pass lane 15)
+                const v2f c = {c0[0], pe0}, ip = {shl(col(pf0, 0), c0[0]), pc0}, jp = {cp[0], pep}, kp = {c0[1], kpe};
+                v2f r, dd, d1, d2, d3;
+                TV4_RINV2(c, ip, jp, kp, r, dd, d1, d2, d3)
+                (void)dd; (void)d2;
+                tk_prev = nc_mul(d3.x, r.x);
+                if (MODE != TVM_VALUE) TEp = nc_mul(d1.y, r.y);         // = -(x[s0] - x[s0-1]) R(s0-1): the terms are kept negated ...
+            }
+#pragma unroll
+            for (int j = 1; j < TZ; j += 2) {
+                const v2f c = {c0[j], c0[j + 1]}, xip = {shl(col(pf0, j), c0[j]), shl(col(pf0, j + 1), c0[j + 1])};
+                const v2f jp = {cp[j], cp[j + 1]}, kp = {c0[j + 1], c0[j + 2]};
+                v2f r, dd, d1, d2, d3;
+                TV4_RINV2(c, xip, jp, kp, r, dd, d1, d2, d3)
+                const bool ok0 = !EDGE || (z0 + j - 1 < n && s < nx), ok1 = !EDGE || (z0 + j < n && s < nx);
+                if (WITH_TV) { tvacc += (double)(ok0 ? dd.x : 0.f); tvacc += (double)(ok1 ? dd.y : 0.f); }
+                const v2f tk = nc_mul2(d3, r);                  // .y is handed to the next pair
+                if (MODE != TVM_VALUE) {
+                    const v2f ti = nc_mul2(d1, r);              // -(x_ip - c) R: minus the -slice term of the lane above
+                    const v2f tn = nc_mul2(d2, r);              // -(x_jp - c) R: minus the -y term of the next row
+                    Tn[j] = tn.x; Tn[j + 1] = tn.y;
+                    const v2f g1 = nc_mul2(nc_sub2(nc_sub2(fma2(v2f{3.0f, 3.0f}, c, -xip), jp), kp), r);
+                    const v2f t2 = {shr(col(TEp, j), ti.x), shr(col(TEp, j + 1), ti.y)};
+                    const v2f tp = {Tp[j], Tp[j + 1]}, tkp = {tk_prev, tk.x};
+                    const v2f gv = nc_sub2(nc_sub2(nc_sub2(g1, t2), tp), tkp);   // the terms are kept negated and subtracted: a - (-t) == a + t
+                    if (MODE == TVM_NORM) {
+                        out[j] = gv.x; out[j + 1] = gv.y;
+                        const v2f g2 = gv * gv;
+                        acc += (double)(ok0 ? g2.x : 0.f);
+                        acc += (double)(ok1 ? g2.y : 0.f);
+                    } else {
+                        const v2f xn = fma2(-gv, v2f{nrm_, nrm_}, c);            // tv_step, the expression of k_tv_update
+                        out[j] = fmaxf(xn.x, vmin); out[j + 1] = fmaxf(xn.y, vmin);
+                    }
+                }
+                tk_prev = tk.y;
+            }
+#undef TV4_RINV2
+#else
             if (MODE != TVM_VALUE) {   // the slice-direction term for lane 0, all columns at once (lane j <- column j): (x[s0] - x[s0-1]) R(s0-1)
                 float kp = shl(0.f, pe0), r_, dd_, d1, d2, d3;  // column j+1 (wave shift: the packed columns may pass lane 15)
                 TV4_RINV(pe0, pc0, pep, kp, r_, dd_, d1, d2, d3)
                 (void)dd_; (void)d2; (void)d3;
                 TEp = nc_mul(d1, r_);                           // = -(x[s0] - x[s0-1]) R(s0-1): the terms are kept negated ...
             }
-            float out[TZ + 1];                                  // the row's results: g (norm pass) or x_new (update pass)
-            float tk_prev = 0.f;                                // -(x_kp - c) R of column j-1: minus the -z term of column j
 #pragma unroll
             for (int j = 0; j <= TZ; ++j) {                     // one pass over the columns: R, the shared products, the gradient
                 float dd, d1, d2, d3, r;
@@ -2308,29 +2404,27 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 }
                 tk_prev = tk;
             }
+#endif
             const size_t pix0 = (size_t)(y * n + z0);                 // wave-uniform
             if (MODE == TVM_UPDATE) {
-                float *xo = up.x_out + pix0 * sx + (unsigned)s0;
+                // (column j >= 1 of a row is pixel y n + z0 + j - 1 whenever it is stored: vb[j] is its offset in the output row too)
+                const SBase xo = sgpr_base(up.x_out + (size_t)y * n * sx);
 #pragma unroll
                 for (int j = 1; j <= TZ; ++j) {
                     if (EDGE && !(z0 + j - 1 < n && s < nx)) continue;
-                    float *q = xo + (size_t)(j - 1) * sx;
-                    if (STREAM) __builtin_nontemporal_store(out[j], q + (unsigned)lane);
-                    else q[(unsigned)lane] = out[j];
+                    st_so<STREAM>(xo, vb[j], out[j]);
                 }
                 if (TRACK) {
-                    float *tr = up.track + pix0 * sx + (unsigned)s0;
+                    const SBase tr = sgpr_base(up.track + (size_t)y * n * sx);
                     float told[TZ + 1];
 #pragma unroll
-                    for (int j = 1; j <= TZ; ++j) told[j] = (!EDGE || (z0 + j - 1 < n && s < nx)) ? (tr + (size_t)(j - 1) * sx)[(unsigned)lane] : out[j];
+                    for (int j = 1; j <= TZ; ++j) told[j] = (!EDGE || (z0 + j - 1 < n && s < nx)) ? ld_so(tr, vb[j]) : out[j];
 #pragma unroll
                     for (int j = 1; j <= TZ; ++j) {
                         float d = out[j] - told[j];
                         acc += (double)(d * d);
                         if (EDGE && !(z0 + j - 1 < n && s < nx)) continue;
-                        float *q = tr + (size_t)(j - 1) * sx;
-                        if (STREAM) __builtin_nontemporal_store(out[j], q + (unsigned)lane);
-                        else q[(unsigned)lane] = out[j];
+                        st_so<STREAM>(tr, vb[j], out[j]);
                     }
                 }
             }
