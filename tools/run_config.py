@@ -37,7 +37,9 @@ def step(k, st):
         tk = 0.5 * (1 + np.sqrt(1 + 4 * st["t0"] ** 2))
         t.fista_momentum((st["t0"] - 1) / tk)
         st["t0"] = tk
-        return 0.5 * t.data_distance() ** 2 + 0.1 * t.tv()
+        c = 0.5 * t.data_distance() ** 2 + 0.1 * t.tv()
+        t.fista_project_yk()            # as TomoGPU.fista: the next step's A yk from this A r and the last
+        return c
     if a.alg == "sirt":
         t.SIRT(1); return t.data_distance()
     if a.alg == "sart":
