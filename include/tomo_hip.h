@@ -284,8 +284,8 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     projected from (tomo_forward_projection into TOMO_SINO_G, tomo_data_distance_sq; tracked by slot and
  *                     write-version, inherited by tomo_copy_volume) starts from that sinogram instead of projecting again:
  *                     bit-identical.  Also gates tomo_fista_project_yk.  0 = every projection recomputed
- *   "fp_tile_pipe" (0): experimental: the tile projector's reduce pass of one chunk group overlapped with the tile pass of
- *                     the next on a second stream (no gain measured) */
+ *   "fp_tile_pipe" (0): experimental, P >= 2: the tile projector runs as P groups of 64-slice chunks, the reduce pass of one
+ *                     group on a second stream beside the tile pass of the next (no gain measured) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
 /* ---- native communicator: the slab-sharded path over RCCL on the engine's own stream ---------------------------------------
  * Replaces, for a C / C++ host as for the Python one, the MPI calls of the reference's sharded CPU engine (mpi_ctvlib.cpp:400-422
