@@ -2225,6 +2225,9 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
 #ifndef TV4_PACKED
 #define TV4_PACKED 1
 #endif
+#ifndef TV4_PACKED_EDGE
+#define TV4_PACKED_EDGE 0      // the predicated EDGE forms spill with the pairs (28-36 B) and lose: 450 vs 415 us at 500 slices, 127 vs 112 at 100
+#endif
 #ifndef TV4_UPD_WAVES
 #define TV4_UPD_WAVES 4
 #endif
@@ -2273,6 +2276,9 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
         const bool lo_in = s0 > 0, hi_in = s0 + 64 < nx;
         const unsigned zls = (unsigned)zl * (unsigned)sx;
         const unsigned off_lo = lo_in ? zls + (unsigned)(s0 - 1) : (unsigned)zl, off_hi = hi_in ? zls + (unsigned)(s0 + 64) : (unsigned)zl;
+        // (the norm pass that also sums the TV value is two registers over the 128 of four waves per SIMD with the ten offsets
+        // held: that one instantiation forms its addresses per access instead -- 9 dwords of scratch otherwise)
+        constexpr bool SOFF = !EDGE && !(WITH_TV && MODE == TVM_NORM);   // (and the predicated EDGE forms spill with them too)
         unsigned vb[TZ + 2];                // byte offsets of the lane's voxel in the columns of a row: loop invariants
 #pragma unroll
         for (int j = 0; j < TZ + 2; ++j) vb[j] = ((unsigned)zc[j] * (unsigned)sx + (unsigned)s0 + (unsigned)lane) * 4u;
@@ -2281,12 +2287,20 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
             int yy = yrow(y) * n;
             if (!EDGE) {
                 const float *rowp = x + (size_t)yy * sx;            // wave-uniform
-                const SBase rb = sgpr_base(rowp);
+                if constexpr (SOFF) {
+                    const SBase rb = sgpr_base(rowp);
 #pragma unroll
-                for (int j = 0; j < TZ + 2; ++j) c[j] = ld_so(rb, vb[j]);
-                e_c = ld_so(rb, eb_c);
-                e_lo = ld_so(sgpr_base(lo_in ? rowp : h.lo + yy), eb_lo);
-                e_hi = ld_so(sgpr_base(hi_in ? rowp : h.hi + yy), eb_hi);
+                    for (int j = 0; j < TZ + 2; ++j) c[j] = ld_so(rb, vb[j]);
+                    e_c = ld_so(rb, eb_c);
+                    e_lo = ld_so(sgpr_base(lo_in ? rowp : h.lo + yy), eb_lo);
+                    e_hi = ld_so(sgpr_base(hi_in ? rowp : h.hi + yy), eb_hi);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TZ + 2; ++j) c[j] = (rowp + ((unsigned)zc[j] * (unsigned)sx + (unsigned)s0))[(unsigned)lane];
+                    e_c = rowp[zls + (unsigned)s0];
+                    e_lo = (lo_in ? rowp : h.lo + yy)[off_lo];
+                    e_hi = (hi_in ? rowp : h.hi + yy)[off_hi];
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < TZ + 2; ++j) c[j] = tv_ld(x, h, yy + zc[j], s, nx, sx);
@@ -2322,7 +2336,7 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
             float TEp = 0.f;
             float out[TZ + 1];                                  // the row's results: g (norm pass) or x_new (update pass)
             float tk_prev = 0.f;                                // -(x_kp - c) R of column j-1: minus the -z term of column j
-#if TV4_PACKED
+            if constexpr (TV4_PACKED && (!EDGE || TV4_PACKED_EDGE)) {
             // The columns two at a time on packed fp32 instructions (nc_mul2 / nc_sub2 / fma2: same roundings as the scalar
             // column loop below, half the issue slots).  Column 0, of which only the -z term is needed, shares its evaluation
             // with the slice-direction term of lane 0.
@@ -2373,7 +2387,7 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 tk_prev = tk.y;
             }
 #undef TV4_RINV2
-#else
+            } else {
             if (MODE != TVM_VALUE) {   // the slice-direction term for lane 0, all columns at once (lane j <- column j): (x[s0] - x[s0-1]) R(s0-1)
                 float kp = shl(0.f, pe0), r_, dd_, d1, d2, d3;  // column j+1 (wave shift: the packed columns may pass lane 15)
                 TV4_RINV(pe0, pc0, pep, kp, r_, dd_, d1, d2, d3)
@@ -2404,27 +2418,36 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 }
                 tk_prev = tk;
             }
-#endif
+            }
             const size_t pix0 = (size_t)(y * n + z0);                 // wave-uniform
             if (MODE == TVM_UPDATE) {
                 // (column j >= 1 of a row is pixel y n + z0 + j - 1 whenever it is stored: vb[j] is its offset in the output row too)
                 const SBase xo = sgpr_base(up.x_out + (size_t)y * n * sx);
+                float *xo_e = up.x_out + pix0 * sx + (unsigned)s0;          // (EDGE: address per access)
 #pragma unroll
                 for (int j = 1; j <= TZ; ++j) {
                     if (EDGE && !(z0 + j - 1 < n && s < nx)) continue;
-                    st_so<STREAM>(xo, vb[j], out[j]);
+                    if constexpr (SOFF) st_so<STREAM>(xo, vb[j], out[j]);
+                    else if (STREAM) __builtin_nontemporal_store(out[j], xo_e + (size_t)(j - 1) * sx + (unsigned)lane);
+                    else (xo_e + (size_t)(j - 1) * sx)[(unsigned)lane] = out[j];
                 }
                 if (TRACK) {
                     const SBase tr = sgpr_base(up.track + (size_t)y * n * sx);
+                    float *tr_e = up.track + pix0 * sx + (unsigned)s0;
                     float told[TZ + 1];
 #pragma unroll
-                    for (int j = 1; j <= TZ; ++j) told[j] = (!EDGE || (z0 + j - 1 < n && s < nx)) ? ld_so(tr, vb[j]) : out[j];
+                    for (int j = 1; j <= TZ; ++j) {
+                        if constexpr (SOFF) told[j] = ld_so(tr, vb[j]);
+                        else told[j] = (z0 + j - 1 < n && s < nx) ? (tr_e + (size_t)(j - 1) * sx)[(unsigned)lane] : out[j];
+                    }
 #pragma unroll
                     for (int j = 1; j <= TZ; ++j) {
                         float d = out[j] - told[j];
                         acc += (double)(d * d);
                         if (EDGE && !(z0 + j - 1 < n && s < nx)) continue;
-                        st_so<STREAM>(tr, vb[j], out[j]);
+                        if constexpr (SOFF) st_so<STREAM>(tr, vb[j], out[j]);
+                        else if (STREAM) __builtin_nontemporal_store(out[j], tr_e + (size_t)(j - 1) * sx + (unsigned)lane);
+                        else (tr_e + (size_t)(j - 1) * sx)[(unsigned)lane] = out[j];
                     }
                 }
             }

@@ -16,8 +16,8 @@ python3 tools/prof_summary.py $O/trace_full $O/kernel_stats_full.txt > /dev/null
 python3 tools/prof_summary.py $O/trace_fista $O/kernel_stats_fista.txt > /dev/null
 python3 tools/prof_summary.py $O/trace_sirt $O/kernel_stats_sirt.txt > /dev/null
 mkdir -p $O/pmc_bench $O/pmc_sirt $O/pmc_fista; mv $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_bench/; mv $O/pmcs_FETCH_SIZE $O/pmcs_WRITE_SIZE $O/pmc_sirt/; mv $O/pmcf_FETCH_SIZE $O/pmcf_WRITE_SIZE $O/pmc_fista/
-python3 tools/pmc_summary.py $O/pmc_bench $O/pmc_traffic.txt > /dev/null
-python3 tools/pmc_summary.py $O/pmc_sirt $O/pmc_traffic_sirt.txt > /dev/null
-python3 tools/pmc_summary.py $O/pmc_fista $O/pmc_traffic_fista.txt > /dev/null
+python3 tools/pmc_summary.py $O/pmc_bench $O/pmc_traffic.txt "python3 bench.py --steps 1 --warmup 0 --quick" 512x512x90 > /dev/null
+python3 tools/pmc_summary.py $O/pmc_sirt $O/pmc_traffic_sirt.txt "python3 tools/run_config.py --alg sirt --iters 1" 512x512x90 > /dev/null
+python3 tools/pmc_summary.py $O/pmc_fista $O/pmc_traffic_fista.txt "python3 tools/run_config.py --alg fista --iters 1" 512x512x90 > /dev/null
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
 tail -1 $O/bench.json | cut -c1-300; head -14 $O/kernel_stats.txt | cut -c1-150; cat $O/fista.log $O/sirt.log | tail -5

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 
-def main(root, out):
+def main(root, out, command=None, shape=None):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -32,10 +32,14 @@ def main(root, out):
             f = acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1]
             w = acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]
             traffic[k.replace("void ", "").strip()] = {"fetch_kib_raw": f, "write_kib": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
-    json.dump({"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                         "(gfx950: FETCH_SIZE counts 128-B requests as 64 B)", "kernels": traffic},
-              open(os.path.splitext(out)[0] + ".json", "w"), indent=1, sort_keys=True)
+    doc = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                     "(gfx950: FETCH_SIZE counts 128-B requests as 64 B)", "kernels": traffic}
+    if command:
+        doc["command"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- " + command
+    if shape:
+        doc["shape"] = [int(v) for v in shape.split("x")]           # slices (= image side) x image side x tilts
+    json.dump(doc, open(os.path.splitext(out)[0] + ".json", "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:5])
