@@ -239,6 +239,48 @@ def test_sub_slab_group_equals_one_engine(gpu, K, nx):
     assert np.array_equal(b["gd"], b["tmp"]) and np.array_equal(b["slice"], b["sirt"][nx - 2]) and np.array_equal(b["set"], a["set"])
 
 
+def fista_loop(t, niter, shortcut):
+    """gpu/reconstructor.py:121-155 as TomoGPU.fista runs it (prox on the stepped point, momentum, cost, projection by linearity)."""
+    from tomo_tv_amd import pytvlib
+    from tomo_tv_amd._lib import VOL_YK
+    pytvlib.initialize_algorithm(t, "fista")
+    t0, cost, taken = 1.0, [], []
+    for _ in range(niter):
+        pytvlib.run(t, "fista")
+        t.tv_fgp(4, 0.05, vol=VOL_YK)
+        tk = 0.5 * (1 + np.sqrt(1 + 4 * t0 ** 2))
+        t.fista_momentum((t0 - 1) / tk)
+        t0 = tk
+        cost.append(0.5 * t.data_distance() ** 2 + 0.05 * t.tv())
+        taken.append(t.fista_project_yk() if shortcut else False)
+    return np.array(cost), taken, t.get_volume()
+
+
+@pytest.mark.parametrize("form", ["ring2", "ring3", "group2"])
+def test_fista_with_the_projection_by_linearity_on_slabs(gpu, form):
+    """The FISTA driver on slab-sharded engines (thread ring) and on a sub-slab group: the linearity shortcut is taken on every slab
+    engine from the first cost evaluation on, and the run equals the single engine that projects every time."""
+    nx, n, p = 70, 32, 7
+    ang = np.deg2rad(np.linspace(-60, 60, p))
+    x = noisy_phantom(nx, n, 23)
+    one = tomoengine(nx, n, ang)
+    one.set_volume(x, 2)
+    one.create_projections()
+    b = one.get_projections()
+    one.set_option("fp_reuse", 0)
+    one.restart_recon()
+    want_cost, _, want = fista_loop(one, 5, False)
+    if form.startswith("ring"):
+        cost, taken, got = run_sharded(int(form[-1]), nx, n, ang, np.zeros_like(x), lambda t: fista_loop(t, 5, True), b=b)
+    else:
+        t = tomoengine(nx, n, ang, sub_slabs=2)
+        t.set_tilt_series(b)
+        t.restart_recon()
+        cost, taken, got = fista_loop(t, 5, True)
+    assert taken == [True] * 5
+    assert rel_l2(got, want) < 1e-5 and np.allclose(cost, want_cost, rtol=1e-5)
+
+
 def test_sub_slab_group_asd_pocs_at_full_size(gpu):
     """512 x 512^2, 90 tilts: three ASD-POCS iterations of TomoGPU on two sub-slabs against one slab."""
     from tomo_tv_amd.phantom import tilt_angles
