@@ -30,6 +30,22 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 30):
     print(' tv', flush=True); tv, dg = dev.tv_gd_tracked(2, 0.01); dev.synchronize(); tvr = ref.tv_gd(2, 0.01); e.append(abs(tv-tvr)/tvr); e.append(rel(dev.get_volume(), ref.recon))
     print(' fgp', flush=True); a = dev.tv_fgp(3, 0.02); dev.synchronize(); b = ref.tv_fgp(3, 0.02); e.append(abs(a-b)/b); e.append(rel(dev.get_volume(), ref.recon))
     print(' cgls', flush=True); dev.CGLS(1); dev.synchronize()
+    # the FISTA driver loop (gpu/reconstructor.py:121-155): gradient step on yk, FGP prox, momentum, cost, the next A yk by linearity
+    print(' fista', flush=True)
+    from tomo_tv_amd import pytvlib
+    from tomo_tv_amd._lib import VOL_YK
+    dev.restart_recon(); ref.restart_recon()
+    pytvlib.initialize_algorithm(dev, "fista"); ref.initialize_fista()
+    t0 = 1.0
+    for k in range(4):
+        pytvlib.run(dev, "fista"); dev.tv_fgp(3, 0.05, vol=VOL_YK)
+        ref.SIRT_norm(1, target="yk"); ref.recon, ref.yk = ref.yk, ref.recon; ref.tv_fgp(3, 0.05); ref.recon, ref.yk = ref.yk, ref.recon
+        tk = 0.5 * (1 + np.sqrt(1 + 4 * t0 ** 2)); dev.fista_momentum((t0 - 1) / tk); ref.fista_momentum((t0 - 1) / tk); t0 = tk
+        cd = 0.5 * dev.data_distance() ** 2 + 0.05 * dev.tv(); cr = 0.5 * ref.data_distance(normalize=False) ** 2 + 0.05 * ref.tv()
+        took = dev.fista_project_yk()
+        e.append(abs(cd - cr) / max(cr, 1e-30)); e.append(0.0 if took else 1.0)
+    e.append(rel(dev.get_volume(), ref.recon)); e.append(rel(dev.get_volume(VOL_YK), ref.yk))
+    dev.remove_momentum()
     # two-stream SART == one chain (bitwise where the sub-slabs keep the slab's vector width, else an ulp per step)
     v0 = None
     for ns in (1, 2):
