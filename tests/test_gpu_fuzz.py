@@ -53,3 +53,26 @@ def test_random_shape(gpu, N, P, Nx, seed):
     # CGLS runs and the Landweber path through the ctvlib-style entry
     dev.CGLS(2)
     assert np.isfinite(dev.get_volume()).all() and dev.get_volume().min() >= 0
+    # the FISTA driver loop (gpu/reconstructor.py:121-155) with the next A yk formed by linearity after every cost evaluation
+    from tomo_tv_amd import pytvlib
+    from tomo_tv_amd._lib import VOL_YK
+    dev.restart_recon()
+    ref.restart_recon()
+    pytvlib.initialize_algorithm(dev, "fista")
+    ref.initialize_fista()
+    t0 = 1.0
+    for _ in range(3):
+        pytvlib.run(dev, "fista")
+        dev.tv_fgp(3, 0.05, vol=VOL_YK)
+        ref.SIRT_norm(1, target="yk")
+        ref.recon, ref.yk = ref.yk, ref.recon               # the oracle's tv_fgp acts on .recon
+        ref.tv_fgp(3, 0.05)
+        ref.recon, ref.yk = ref.yk, ref.recon
+        tk = 0.5 * (1 + np.sqrt(1 + 4 * t0 ** 2))
+        dev.fista_momentum((t0 - 1) / tk)
+        ref.fista_momentum((t0 - 1) / tk)
+        t0 = tk
+        cost = 0.5 * ref.data_distance(normalize=False) ** 2 + 0.05 * ref.tv()
+        assert abs(0.5 * dev.data_distance() ** 2 + 0.05 * dev.tv() - cost) <= 2e-5 * max(cost, 1e-6)
+        assert dev.fista_project_yk()
+    assert rel_l2(dev.get_volume(), ref.recon) < TOL and rel_l2(dev.get_volume(VOL_YK), ref.yk) < TOL
