@@ -3,6 +3,9 @@
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tomo_tv_amd import _lib as _tl
+if os.environ.get("TOMO_LIB"):                      # A/B against another build of the library (tools only)
+    _tl.LIB_PATH = os.path.abspath(os.environ["TOMO_LIB"])
 from tomo_tv_amd.engine import tomoengine
 from tomo_tv_amd.phantom import ellipsoids, tilt_angles
 from tomo_tv_amd._lib import VOL_ORIGINAL
