@@ -131,12 +131,12 @@ def cpu_baselines(n, nproj, budget_s=14.0):
     if "OMP_NUM_THREADS" not in os.environ:
         oracle.set_num_threads(oracle.usable_cpus())   # the baseline uses every CPU the host grants
     threads = oracle.num_threads()
-    kind = f"port ({oracle.BUILD_FLAGS['timed']}; OpenMP over slices like ctvlib.cpp:207; oracle/tomo_oracle.c)"
+    build = f"{oracle.BUILD_FLAGS['timed']}; OpenMP over slices like ctvlib.cpp:207; oracle/tomo_oracle.c"
     ns = max(8, 2 * threads)
     ref = _oracle_setup(ns, n, nproj)
     st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(ns * n * nproj)}
     iters, el = _timed(lambda: asd_pocs_step(ref, st), budget_s, 5)
-    head = {"value": ns * n * n * iters / el / 1e9, "unit": "Gvoxel-updates/s", "cores": threads, "kind": kind,
+    head = {"value": ns * n * n * iters / el / 1e9, "unit": "Gvoxel-updates/s", "cores": threads, "kind": "port", "build": build,
             "sample": f"{iters} ASD-POCS iterations (SART sweep + 10 TV-GD steps) on a {ns}x{n}x{n} slab of the workload, "
                       f"{nproj} tilts",
             "iters_per_s_full_volume_equiv": iters / el * ns / n}
