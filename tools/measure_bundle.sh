@@ -1,7 +1,7 @@
 # Measurement bundle of a round (tools/measure_bundle.sh r03) (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats of the same
 # command, PMC traffic passes (FETCH_SIZE / WRITE_SIZE in separate runs, no tracing domains besides the kernel trace).
 R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; O=$R/gpurun_out/$TAG; mkdir -p $O
-cd $R && python3 bench.py > $O/bench.json 2> $O/bench.err
+cd $R && python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err   # the driver's command
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --quick > $O/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -- python3 $R/bench.py --no-cpu-baseline > $O/bench_trace_full.log 2>&1
