@@ -34,7 +34,10 @@ enum tomo_volume { TOMO_VOL_RECON = 0, TOMO_VOL_TEMP = 1, TOMO_VOL_ORIGINAL = 2,
 /* sinograms held by the engine (tomoengine.hpp:53: b = measured, g = re-projection) */
 enum tomo_sinogram { TOMO_SINO_B = 0, TOMO_SINO_G = 1, TOMO_SINO_R = 2 /* residual scratch */,
                      TOMO_SINO_USER0 = 3,   /* caller-managed extra sinograms (per-element bChem, multimodal.hpp) */
-                     TOMO_SINO_SLOTS = 3 + 40 };
+                     TOMO_SINO_SLOTS = 3 + 40,
+                     /* read-only pseudo-slot of tomo_get_sinogram: A * yk as tomo_fista_project_yk formed it (TOMO_ERR_STATE when
+                      * no such projection is in hand); TOMO_SINO_G itself always stays A * recon (tomoengine.cpp:410-427,459) */
+                     TOMO_SINO_YK_MODEL = 1000 };
 
 /* slots of the device scalar buffer (doubles); each holds THIS slab's partial sum */
 enum tomo_scalar { TOMO_S_DD = 0,      /* sum (A x - b)^2            data_distance  */

@@ -518,7 +518,9 @@ static double tv_grad(int nx, int ny, int nz, const float *vol, float *g, float 
             for (int k = 0; k < nz; k++) {
                 int kp = (k + 1) % nz, km = (k - 1 + nz) % nz;
                 float c = V(i, j, k);
-                float v1n = 3.0f * c - V(ip, j, k) - V(i, jp, k) - V(i, j, kp);
+                /* ctvlib.cpp:431 writes 3.0*recon[i](j,k) - ...: the literal is a double, so the whole numerator is
+                 * evaluated in double and rounded to float ONCE (round 3 had 3.0f * c: three float roundings) */
+                float v1n = (float)(3.0 * (double)c - (double)V(ip, j, k) - (double)V(i, jp, k) - (double)V(i, j, kp));
                 float v1d = sqrtf(eps + (c - V(ip, j, k)) * (c - V(ip, j, k))
                                       + (c - V(i, jp, k)) * (c - V(i, jp, k))
                                       + (c - V(i, j, kp)) * (c - V(i, j, kp)));

@@ -89,17 +89,21 @@ def oracle_asd_iteration(ref, beta, dPOCS, ng, alpha, first):
 
 
 def tv_descent_stage(t, ref, start, dPOCS, label, seed=0):
-    """tv_gd from the SAME start on both sides.  Five steps are held to 1e-5 of the oracle.  Ten steps of fixed length along
+    """tv_gd from the SAME start on both sides.  Five steps are held to 1e-6 of the oracle (round 4: the numerator of the first
+    gradient term as the sum of the three forward differences, like the reference's double-evaluated 3.0*recon - ...: 2-4e-7
+    measured; round 3: 1-2e-6 against a bound of 1e-5).  Ten steps of fixed length along
     g/|g| with g = sum v/sqrt(eps + ...) are ill-conditioned ON THIS DATA: one ulp on the start moves the oracle's own
     ten-step result by 1.5e-5...5.6e-5 at 512^3 (printed below), so two fp32 evaluations cannot be held to 1e-5 of each
     other there -- not the reference against itself either.  What is held instead: the HIP result is no further (x 2) from
     the binary64 evaluation of the same descent (oracle.tv_gd_f64, the exact-arithmetic trajectory) than the reference's own
-    fp32 arithmetic is.  Measured (tools/diag_tv_fullsize.py, 64 x 512^2): HIP 1.65e-5, oracle 1.50e-5 from fp64."""
+    fp32 arithmetic is.  The ratio itself is a draw from a wide distribution, not a property of the arithmetic: over eight
+    64-slice slabs it ranges 0.62 ... 2.59 (v_rsq_f32 with a Newton step: 0.67 ... 9.0), profiles/r04_tv_arith_variants.md;
+    on this fixed input it is deterministic (1.32 at 512^3 after sweep 1)."""
     ref.recon[:] = start
     t.set_volume(start)
     tv_r, tv_d = ref.tv_gd(5, dPOCS), t.tv_gd(5, dPOCS)
     e5 = rel_l2(t.get_volume(), ref.recon)
-    assert close(tv_d, tv_r) and e5 < TOL, (label, e5)
+    assert close(tv_d, tv_r) and e5 < 1e-6, (label, e5)      # round 4: 2.4e-7 at 512^3 with the difference form of the first numerator (round 3: 1.2e-6)
     ref.recon[:] = start
     t.set_volume(start)
     t.copy_recon()

@@ -313,7 +313,7 @@ def test_fista_projects_the_extrapolated_point_by_linearity(gpu, golden):
     """tomo_fista_project_yk: A yk = (1 + beta) A r - beta A r_old from the two projections the cost evaluations made.  The shortcut
     must (a) actually be taken in the driver loop from the second iteration on, (b) stay within the parity tolerance of the loop
     that projects yk every time, and (c) refuse whenever a volume it relies on was touched in between."""
-    from tomo_tv_amd._lib import SINO_G, VOL_YK, VOL_RECON_OLD
+    from tomo_tv_amd._lib import SINO_G, SINO_YK_MODEL, VOL_RECON, VOL_YK, VOL_RECON_OLD
     N, P, Nx = 32, 9, 4
     A = golden(f"A_N{N}_P{P}.npz")
     g = golden(f"trace_N{N}_P{P}_Nx{Nx}.npz")
@@ -351,9 +351,15 @@ def test_fista_projects_the_extrapolated_point_by_linearity(gpu, golden):
         t.tv_fgp(3, 0.1, vol=VOL_YK)
         t.fista_momentum(beta)
         t.data_distance()
+        g_before = t.get_model_projections()             # (reading G drops its claim: project recon again)
+        t.data_distance()
         assert t.fista_project_yk()
         lin = np.zeros((Nx, N * P), np.float32)
-        t.be.c("get_sinogram", SINO_G, lin.ctypes.data)
+        t.be.c("get_sinogram", SINO_YK_MODEL, lin.ctypes.data)
+        # the model sinogram stays A * recon after the shortcut (tomoengine.cpp:410-427,459), bit for bit
+        assert np.array_equal(t.get_model_projections(), g_before)
+        t.be.c("forward_projection", VOL_RECON, SINO_G)
+        assert np.array_equal(t.get_model_projections(), g_before)
         t.be.c("forward_projection", VOL_YK, SINO_G)
         direct = np.zeros_like(lin)
         t.be.c("get_sinogram", SINO_G, direct.ctypes.data)

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libtomo_hip.so")
 # enum mirrors (include/tomo_hip.h)
 VOL_RECON, VOL_TEMP, VOL_ORIGINAL, VOL_YK, VOL_RECON_OLD = 0, 1, 2, 3, 4
 SINO_B, SINO_G, SINO_R, SINO_USER0 = 0, 1, 2, 3
+SINO_YK_MODEL = 1000     # read-only: A * yk as tomo_fista_project_yk formed it
 VOL_USER0 = 5
 S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_DIFF2, S_GNORM_ALL, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 16
 FIELD_FGP_D, FIELD_FGP_P1 = 100, 101

@@ -530,13 +530,15 @@ __global__ __launch_bounds__(256) void k_sino_resid(const float *__restrict__ b,
     }
 }
 
-// p <- (1 + beta) g - beta p : the projection of the Nesterov point y = r + beta (r - r_old) by linearity from A r (g) and A r_old (p)
-__global__ __launch_bounds__(256) void k_sino_extrapolate(const VecOf<4>::T *__restrict__ g, VecOf<4>::T *__restrict__ p, float beta,
-                                                          int64_t n4)
+// q <- (1 + beta) g - beta p, p <- g : the projection of the Nesterov point y = r + beta (r - r_old) by linearity from A r (g) and
+// A r_old (p), and A r saved as the next step's A r_old, in one pass.  g = the model sinogram G is only read: it stays A * recon.
+__global__ __launch_bounds__(256) void k_sino_extrapolate(const VecOf<4>::T *__restrict__ g, VecOf<4>::T *__restrict__ p,
+                                                          VecOf<4>::T *__restrict__ q, float beta, int64_t n4)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         VecOf<4>::T a = g[i], b = p[i];
-        p[i] = a + beta * (a - b);
+        q[i] = a + beta * (a - b);
+        p[i] = a;
     }
 }
 
@@ -1740,7 +1742,7 @@ __global__ __launch_bounds__(256) void k_tv_grad(const float *__restrict__ x, Ha
             float x_ip = ldx(x, h, p, s + 1, nx, sx);
             float x_jp = x[(size_t)pjp * sx + s];
             float x_kp = x[(size_t)pkp * sx + s];
-            float v1n = 3.0f * c - x_ip - x_jp - x_kp;
+            float v1n = ((c - x_ip) + (c - x_jp)) + (c - x_kp);   // 3 c - x_ip - x_jp - x_kp without the cancellation at 2c (tv_v1n)
             float v1d = sqrtf(eps + (c - x_ip) * (c - x_ip) + (c - x_jp) * (c - x_jp) + (c - x_kp) * (c - x_kp));
             float a = ldx(x, h, p, s - 1, nx, sx);
             float a_jp = ldx(x, h, pjp, s - 1, nx, sx);
@@ -1835,7 +1837,30 @@ __device__ __forceinline__ v2f nc_sub2(v2f a, v2f b)
 #pragma clang fp contract(off)
     return a - b;
 }
+__device__ __forceinline__ v2f nc_add2(v2f a, v2f b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// The numerator of the first term, 3 c - x_ip - x_jp - x_kp (ctvlib.cpp:431).  The reference writes it with the double literal
+// 3.0, so it is evaluated in binary64 and rounded once: no cancellation error.  In fp32 `fma(3, c, -x_ip) - x_jp - x_kp` rounds at
+// the magnitude of 2c (an absolute error of ~1e-7 on a numerator that is a small difference of neighbouring voxels: 1e-4 ... 0.1
+// relative); the sum of the three forward differences (c - x_ip) + (c - x_jp) + (c - x_kp) -- which the march has in hand, they
+// are what R is made of, and which are exact wherever neighbours lie within a factor of two (Sterbenz) -- rounds at the magnitude
+// of the numerator itself and costs one instruction less (round 4; TV_V1N_DIFFS 0 restores the round-3 expression for A/B runs).
+#ifndef TV_V1N_DIFFS
+#define TV_V1N_DIFFS 1
+#endif
+__device__ __forceinline__ float tv_v1n(float c, float xip, float xjp, float xkp)
+{
+#if TV_V1N_DIFFS
+    return nc_add(nc_add(nc_sub(c, xip), nc_sub(c, xjp)), nc_sub(c, xkp));
+#else
+    return nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), xjp), xkp);
+#endif
+}
 
 __device__ __forceinline__ float tv_gval(float c, float xip, float xjp, float xkp, float r0, float xim, float rim,
                                           float xjm, float rjm, float xkm, float rkm)
@@ -1845,7 +1870,7 @@ __device__ __forceinline__ float tv_gval(float c, float xip, float xjp, float xk
     // take the three backward terms from where they are cheapest: (c - x_im) R(p-i) is the product (x_ip - c) R formed at the
     // neighbouring slice (one lane shift of a product instead of two shifts of its factors), (c - x_jm) R(p-j) the product formed
     // one row earlier, (c - x_km) R(p-k) the one formed one column earlier.  Same operands, same roundings: bit-identical.
-    float v1n = nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), xjp), xkp);
+    float v1n = tv_v1n(c, xip, xjp, xkp);
     float gv = nc_mul(v1n, r0);
     gv = nc_add(gv, nc_mul(nc_sub(c, xim), rim));
     gv = nc_add(gv, nc_mul(nc_sub(c, xjm), rjm));
@@ -1875,7 +1900,10 @@ __device__ __forceinline__ float tv_rsqrt(float q)
 // IEEE division per voxel was ~10 of the ~40 vector instructions a voxel of the update pass costs (round 3).  At most 1.5 ulp of
 // the STEP away from the reference's expression.  One definition for every form (march, stored-gradient update, halo planes),
 // so they stay bit-identical to each other.
-__device__ __forceinline__ float tv_step_len(float dPOCS, const double *gnorm2) { return __fdiv_rn(dPOCS, (float)sqrt(*gnorm2)); }
+// (the length is capped at FLT_MAX: with ||g|| zero or denormal dPOCS / ||g|| overflows and -g * inf would turn a voxel whose gradient
+// is zero into NaN, where the reference's (dPOCS * g) / ||g|| stays finite unless every g is zero -- and there the capped form leaves the
+// volume as it is instead of the reference's 0 / 0)
+__device__ __forceinline__ float tv_step_len(float dPOCS, const double *gnorm2) { return fminf(__fdiv_rn(dPOCS, (float)sqrt(*gnorm2)), 3.402823466e38f); }
 __device__ __forceinline__ float tv_step(float c, float gv, float len) { return __fmaf_rn(-gv, len, c); }
 
 constexpr int TVL_TZ = 8;          // z-columns per workgroup of the FGP kernel (2 per wave)
@@ -2370,7 +2398,11 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                     const v2f ti = nc_mul2(d1, r);              // -(x_ip - c) R: minus the -slice term of the lane above
                     const v2f tn = nc_mul2(d2, r);              // -(x_jp - c) R: minus the -y term of the next row
                     Tn[j] = tn.x; Tn[j + 1] = tn.y;
+                    #if TV_V1N_DIFFS
+                    const v2f g1 = nc_mul2(nc_add2(nc_add2(d1, d2), d3), r);   // tv_v1n: the three forward differences R is made of
+#else
                     const v2f g1 = nc_mul2(nc_sub2(nc_sub2(fma2(v2f{3.0f, 3.0f}, c, -xip), jp), kp), r);
+#endif
                     const v2f t2 = {shr(col(TEp, j), ti.x), shr(col(TEp, j + 1), ti.y)};
                     const v2f tp = {Tp[j], Tp[j + 1]}, tkp = {tk_prev, tk.x};
                     const v2f gv = nc_sub2(nc_sub2(nc_sub2(g1, t2), tp), tkp);   // the terms are kept negated and subtracted: a - (-t) == a + t
@@ -2404,7 +2436,11 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 if (j >= 1 && MODE != TVM_VALUE) {
                     const float ti = nc_mul(d1, r);             // -(x_ip - c) R: minus the -slice term of the lane above
                     Tn[j] = nc_mul(d2, r);                      // -(x_jp - c) R: minus the -y term of the next row
+                    #if TV_V1N_DIFFS
+                    const float g1 = nc_mul(nc_add(nc_add(d1, d2), d3), r);     // tv_v1n: d1..d3 are c - x_ip, c - x_jp, c - x_kp
+#else
                     const float g1 = nc_mul(nc_sub(nc_sub(__fmaf_rn(3.0f, c, -xip), cp[j]), c0[j + 1]), r);
+#endif
                     const float t2 = shr(col(TEp, j), ti);
                     const float gv = nc_sub(nc_sub(nc_sub(g1, t2), Tp[j]), tk_prev);   // the terms are kept negated and subtracted: a - (-t) == a + t
                     const bool ok = !EDGE || (z0 + j - 1 < n && s < nx);

@@ -685,4 +685,302 @@ void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, 
     for (int i = 0; i < P; ++i) { if (bad[i]) t.st_ok = false; t.st_max_ids = std::max(t.st_max_ids, ids_of[i]); }
 }
 
+
+// ---- sheared-strip tables of the all-angle forward projector (see sysmat.h; kernel: k_fp_strip) -------------------------------
+namespace {
+struct FsSeg {                 // one ray inside one strip
+    uint32_t row, q;           // matrix row; index of this strip in the row's ascending-strip list
+    int32_t ang, j;            // angle, ray number within the angle
+    uint32_t t0, t1;           // first / last tile with entries
+    uint32_t off, cnt;         // entries [off, off + cnt) of the per-pass sorted entry arrays
+    int32_t wave, k, sub;      // accumulator slot
+};
+struct FsRowSeg { int32_t strip; uint32_t off, cnt, t0, t1; };
+struct FsWork {                // per item, between the sizing and the emission phase
+    std::vector<FsSeg> segs;
+    std::vector<uint8_t> nb;   // [ntiles][WAVES][16]
+    uint32_t tile0 = 0, ntiles = 0, quads = 0;
+    uint32_t wave_batches[Tables::FS_WAVES] = {0};
+    uint32_t group_segs[Tables::FS_GROUPS] = {0};
+    int32_t pass = 0, strip = 0;
+};
+template <typename F> void fs_parallel(size_t n, unsigned nth, F f)
+{
+    nth = (unsigned)std::max<size_t>(1, std::min<size_t>(nth, n));
+    std::vector<std::thread> thr;
+    for (unsigned th = 1; th < nth; ++th) thr.emplace_back([&, th] { for (size_t i = n * th / nth; i < n * (th + 1) / nth; ++i) f(i); });
+    for (size_t i = 0; i < n / nth; ++i) f(i);
+    for (auto &x : thr) x.join();
+}
+}  // namespace
+
+bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std::string &why)
+{
+    constexpr int W = Tables::FS_W, H = Tables::FS_H, WAVES = Tables::FS_WAVES, GROUPS = Tables::FS_GROUPS, KMAX = Tables::FS_KMAX;
+    constexpr int NB = Tables::TILE_BATCH;
+    static_assert(GROUPS == WAVES * 4 && KMAX <= 16, "slot layout");
+    t.fs_ok = false;
+    const int64_t nrows = (int64_t)N * P;
+    const int64_t nnz = m.ptr[nrows];
+    if (N < 1 || P < 1 || nnz <= 0 || N > 32768) { why = "empty geometry"; return false; }
+    const unsigned hw = std::min(builder_threads(), 32u);
+    // ---- 1. direction of every angle, from the matrix itself (a user matrix has no angle list): orientation = the axis its
+    // longest ray advances along, slope = least-squares dv/du of that ray's pixels
+    std::vector<int> orient(P, 0);
+    std::vector<double> slope(P, 0.0);
+    for (int i = 0; i < P; ++i) {
+        int64_t best = (int64_t)i * N;
+        for (int j = 0; j < N; ++j) { int64_t r = (int64_t)i * N + j; if (m.ptr[r + 1] - m.ptr[r] > m.ptr[best + 1] - m.ptr[best]) best = r; }
+        const int64_t b = m.ptr[best], e = m.ptr[best + 1];
+        if (e - b < 2) continue;
+        int ymin = N, ymax = -1, zmin = N, zmax = -1;
+        for (int64_t k = b; k < e; ++k) { int y = (int)(m.col[k] / (uint32_t)N), z = (int)(m.col[k] % (uint32_t)N); ymin = std::min(ymin, y); ymax = std::max(ymax, y); zmin = std::min(zmin, z); zmax = std::max(zmax, z); }
+        orient[i] = (ymax - ymin >= zmax - zmin) ? 0 : 1;
+        double su = 0, sv = 0, suu = 0, suv = 0; const double n = (double)(e - b);
+        for (int64_t k = b; k < e; ++k) {
+            int y = (int)(m.col[k] / (uint32_t)N), z = (int)(m.col[k] % (uint32_t)N);
+            double u = orient[i] ? z : y, v = orient[i] ? y : z;
+            su += u; sv += v; suu += u * u; suv += u * v;
+        }
+        const double den = n * suu - su * su;
+        slope[i] = den > 0 ? (n * suv - su * sv) / den : 0.0;
+    }
+    // ---- 2. passes: angles of one orientation, neighbouring slopes
+    struct Pass { int orient; double tg; std::vector<int> ang; };
+    std::vector<Pass> passes;
+    auto form_passes = [&](double dt_max, int amax) {
+        passes.clear();
+        for (int o = 0; o < 2; ++o) {
+            std::vector<int> a;
+            for (int i = 0; i < P; ++i) if (orient[i] == o) a.push_back(i);
+            std::sort(a.begin(), a.end(), [&](int x, int y) { return slope[x] != slope[y] ? slope[x] < slope[y] : x < y; });
+            size_t k = 0;
+            while (k < a.size()) {
+                size_t e = k + 1;
+                while (e < a.size() && (int)(e - k) < amax && slope[a[e]] - slope[a[k]] <= dt_max) ++e;
+                Pass ps; ps.orient = o; ps.tg = 0.5 * (slope[a[k]] + slope[a[e - 1]]);
+                ps.ang.assign(a.begin() + k, a.begin() + e);
+                passes.push_back(std::move(ps));
+                k = e;
+            }
+        }
+    };
+    double dt_max = 0.72; int amax = 24;
+    if (const char *sdt = std::getenv("TOMO_FS_DT")) { double v = std::atof(sdt); if (v > 0) dt_max = v; }
+    if (const char *sa = std::getenv("TOMO_FS_AMAX")) { int v = std::atoi(sa); if (v > 0) amax = v; }
+    // per-ray sorted entries (every ray belongs to exactly one pass, so one set of arrays serves all passes)
+    std::vector<uint16_t> eu(nnz);
+    std::vector<uint8_t> elv(nnz);
+    std::vector<float> ew(nnz);
+    std::vector<std::vector<FsRowSeg>> rsegs;
+    std::vector<FsWork> work;
+    std::vector<int32_t> shift;
+    const int OFF = N;                                     // keeps v - shift + OFF in [0, 3N) (|shift| <= N)
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        form_passes(dt_max, amax);
+        const int npass = (int)passes.size();
+        shift.assign((size_t)npass * N, 0);
+        std::vector<int> pass_of(P, 0);
+        for (int ps = 0; ps < npass; ++ps) {
+            for (int a : passes[ps].ang) pass_of[a] = ps;
+            for (int u = 0; u < N; ++u) {
+                double sh = passes[ps].tg * (u - 0.5 * (N - 1));
+                sh = std::max(-(double)N, std::min((double)N, sh));
+                shift[(size_t)ps * N + u] = (int32_t)std::floor(sh + 0.5);
+            }
+        }
+        // ---- 3. every ray: entries sorted by (strip, march coordinate, cross coordinate), cut into strips
+        rsegs.assign(nrows, {});
+        fs_parallel((size_t)nrows, hw, [&](size_t r) {
+            const int i = (int)(r / N), ps = pass_of[i], o = passes[ps].orient;
+            const int32_t *sh = shift.data() + (size_t)ps * N;
+            const int64_t b = m.ptr[r], e = m.ptr[r + 1];
+            const int n = (int)(e - b);
+            if (n == 0) return;
+            struct K { int32_t strip; uint16_t u; uint8_t lv; float w; };
+            std::vector<K> key(n);
+            for (int k = 0; k < n; ++k) {
+                uint32_t p = m.col[b + k];
+                int y = (int)(p / (uint32_t)N), z = (int)(p % (uint32_t)N);
+                int u = o ? z : y, v = o ? y : z;
+                int vs = v - sh[u] + OFF;
+                key[k] = {vs / W, (uint16_t)u, (uint8_t)(vs % W), m.val[b + k]};
+            }
+            std::sort(key.begin(), key.end(), [](const K &a, const K &c) { return a.strip != c.strip ? a.strip < c.strip : a.u != c.u ? a.u < c.u : a.lv < c.lv; });
+            auto &rs = rsegs[r];
+            for (int k = 0; k < n; ++k) {
+                eu[b + k] = key[k].u; elv[b + k] = key[k].lv; ew[b + k] = key[k].w;
+                if (rs.empty() || rs.back().strip != key[k].strip) rs.push_back({key[k].strip, (uint32_t)(b + k), 0u, (uint32_t)key[k].u / H, 0u});
+                rs.back().cnt++; rs.back().t1 = (uint32_t)key[k].u / H;
+            }
+        });
+        // ---- 4. bucket the ray segments by (pass, strip)
+        const int nstrip_max = (3 * N + W - 1) / W + 2;
+        std::vector<uint32_t> iptr((size_t)npass * nstrip_max + 1, 0);
+        for (int64_t r = 0; r < nrows; ++r) { const int ps = pass_of[r / N]; for (auto &sg : rsegs[r]) iptr[(size_t)ps * nstrip_max + sg.strip + 1]++; }
+        for (size_t k = 0; k + 1 < iptr.size(); ++k) iptr[k + 1] += iptr[k];
+        struct Ref { uint32_t row, q; };
+        std::vector<Ref> refs(iptr.back() ? iptr.back() : 1);
+        {
+            std::vector<uint32_t> fill(iptr.begin(), iptr.end() - 1);
+            for (int64_t r = 0; r < nrows; ++r) {
+                const int ps = pass_of[r / N];
+                for (uint32_t q = 0; q < rsegs[r].size(); ++q) refs[fill[(size_t)ps * nstrip_max + rsegs[r][q].strip]++] = {(uint32_t)r, q};
+            }
+        }
+        std::vector<size_t> bucket;                        // non-empty (pass, strip) buckets = items
+        for (size_t k = 0; k + 1 < iptr.size(); ++k) if (iptr[k + 1] > iptr[k]) bucket.push_back(k);
+        work.assign(bucket.size(), {});
+        // ---- 5. per item: accumulator slots and batch counts (sizing phase)
+        std::vector<uint8_t> over(bucket.size(), 0);
+        fs_parallel(bucket.size(), hw, [&](size_t it) {
+            FsWork &wk = work[it];
+            const size_t bk = bucket[it];
+            wk.pass = (int32_t)(bk / nstrip_max); wk.strip = (int32_t)(bk % nstrip_max);
+            auto &segs = wk.segs;
+            segs.reserve(iptr[bk + 1] - iptr[bk]);
+            uint32_t lo = 0xFFFFFFFFu, hi = 0;
+            for (uint32_t x = iptr[bk]; x < iptr[bk + 1]; ++x) {
+                const Ref &f = refs[x];
+                const FsRowSeg &rs = rsegs[f.row][f.q];
+                segs.push_back({f.row, f.q, (int32_t)(f.row / N), (int32_t)(f.row % N), rs.t0, rs.t1, rs.off, rs.cnt, 0, 0, 0});
+                lo = std::min(lo, rs.t0); hi = std::max(hi, rs.t1);
+            }
+            wk.tile0 = lo; wk.ntiles = hi - lo + 1;
+            std::sort(segs.begin(), segs.end(), [](const FsSeg &a, const FsSeg &c) { return a.ang != c.ang ? a.ang < c.ang : a.j < c.j; });
+            uint32_t qbase = 0;
+            std::vector<int> jmin(wk.ntiles), jmax(wk.ntiles);
+            for (size_t a = 0; a < segs.size();) {
+                size_t e = a;
+                while (e < segs.size() && segs[e].ang == segs[a].ang) ++e;
+                std::fill(jmin.begin(), jmin.end(), 1 << 30); std::fill(jmax.begin(), jmax.end(), -1);
+                for (size_t x = a; x < e; ++x) for (uint32_t tt = segs[x].t0; tt <= segs[x].t1; ++tt) { jmin[tt - lo] = std::min(jmin[tt - lo], segs[x].j); jmax[tt - lo] = std::max(jmax[tt - lo], segs[x].j); }
+                int span = 1;
+                for (uint32_t tt = 0; tt < wk.ntiles; ++tt) if (jmax[tt] >= 0) span = std::max(span, jmax[tt] - jmin[tt] + 1);
+                const int M = (span + 3) & ~3;
+                for (size_t x = a; x < e; ++x) {
+                    const int slot = segs[x].j % M;
+                    const uint32_t quad = qbase + (uint32_t)(slot >> 2);
+                    segs[x].sub = slot & 3; segs[x].wave = (int32_t)(quad % WAVES); segs[x].k = (int32_t)(quad / WAVES);
+                }
+                qbase += (uint32_t)(M >> 2);
+                a = e;
+            }
+            wk.quads = qbase;
+            if (qbase > (uint32_t)(WAVES * KMAX)) { over[it] = 1; return; }
+            wk.nb.assign((size_t)wk.ntiles * WAVES * 16, 0);
+            for (auto &sg : segs) {
+                wk.group_segs[sg.wave * 4 + sg.sub]++;
+                uint32_t x = sg.off, end = sg.off + sg.cnt;
+                while (x < end) {
+                    const uint32_t tt = eu[x] / H;
+                    uint32_t c = 0;
+                    while (x < end && (uint32_t)eu[x] / H == tt) { ++x; ++c; }
+                    uint8_t &slotnb = wk.nb[((size_t)(tt - lo) * WAVES + sg.wave) * 16 + sg.k];
+                    slotnb = (uint8_t)std::max<uint32_t>(slotnb, std::min<uint32_t>(255u, (c + NB - 1) / NB));
+                }
+            }
+            for (uint32_t tt = 0; tt < wk.ntiles; ++tt) for (int w = 0; w < WAVES; ++w) for (int k = 0; k < 16; ++k) wk.wave_batches[w] += wk.nb[((size_t)tt * WAVES + w) * 16 + k];
+        });
+        bool any_over = false;
+        for (uint8_t o : over) any_over |= o != 0;
+        if (!any_over) break;
+        if (attempt == 5) { why = "a strip needs more accumulator slots than a workgroup has"; return false; }
+        dt_max *= 0.7; amax = std::max(1, amax * 3 / 4);   // narrower passes: fewer rays alive per strip
+    }
+    const int npass = (int)passes.size();
+    // ---- 6. layout: items heaviest first; per-item offsets
+    const size_t nitems = work.size();
+    std::vector<uint32_t> order(nitems);
+    for (size_t i = 0; i < nitems; ++i) order[i] = (uint32_t)i;
+    auto crit = [&](const FsWork &w) { uint32_t c = 0; for (int k = 0; k < WAVES; ++k) c = std::max(c, w.wave_batches[k]); return c + 4 * w.ntiles; };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { uint32_t ca = crit(work[a]), cb = crit(work[b]); return ca != cb ? ca > cb : a < b; });
+    t.fs_item.assign(nitems, {});
+    t.fs_gstart.assign(nitems * GROUPS + 1, 0);
+    t.fs_gseg0.assign(nitems * GROUPS + 1, 0);
+    uint64_t nbatch = 0, nseg = 0, ncnt = 0;
+    int kused = 1;
+    for (size_t o = 0; o < nitems; ++o) {
+        const FsWork &wk = work[order[o]];
+        Tables::FsItem &itx = t.fs_item[o];
+        itx.pass = wk.pass; itx.v0 = wk.strip * W - OFF; itx.tile0 = wk.tile0; itx.ntiles = wk.ntiles;
+        itx.cnt0 = (uint32_t)ncnt; itx.g0 = (uint32_t)(o * GROUPS); itx.work = crit(wk); itx.pad = 0;
+        ncnt += (uint64_t)wk.ntiles * WAVES;
+        kused = std::max<int>(kused, (int)((wk.quads + WAVES - 1) / WAVES));
+        for (int g = 0; g < GROUPS; ++g) {
+            t.fs_gstart[o * GROUPS + g] = (uint32_t)nbatch; t.fs_gseg0[o * GROUPS + g] = (uint32_t)nseg;
+            nbatch += wk.wave_batches[g >> 2]; nseg += wk.group_segs[g];
+        }
+    }
+    if (nbatch + 8 >= (1ull << 32) / NB || nseg >= (1ull << 32) || ncnt >= (1ull << 28)) { why = "strip tables exceed 32-bit offsets"; return false; }
+    t.fs_gstart[nitems * GROUPS] = (uint32_t)nbatch; t.fs_gseg0[nitems * GROUPS] = (uint32_t)nseg;
+    t.fs_kused = kused;
+    t.fs_nseg = (uint32_t)nseg;
+    t.fs_cnt.assign((size_t)ncnt * 16 + 16, 0);
+    const uint32_t zero_off = (uint32_t)(W * H) * (uint32_t)pixel_bytes;
+    t.fs_off.assign((size_t)(nbatch + 8) * NB, zero_off);     // + the kernel's prefetch distance past the last stream
+    t.fs_w.assign((size_t)(nbatch + 8) * NB, 0.f);
+    t.fs_rseg_ptr.assign(nrows + 1, 0);
+    for (int64_t r = 0; r < nrows; ++r) t.fs_rseg_ptr[r + 1] = t.fs_rseg_ptr[r] + (uint32_t)rsegs[r].size();
+    t.fs_rseg_idx.assign(nseg ? nseg : 1, 0);
+    // ---- 7. emission (threads over items)
+    std::vector<uint64_t> real_of(nitems, 0);
+    fs_parallel(nitems, hw, [&](size_t o) {
+        FsWork &wk = work[order[o]];
+        const Tables::FsItem &itx = t.fs_item[o];
+        std::memcpy(t.fs_cnt.data() + (size_t)itx.cnt0 * 16, wk.nb.data(), wk.nb.size());
+        // segments of every accumulator slot in the order of their stay
+        std::vector<std::vector<uint32_t>> of_slot((size_t)GROUPS * 16);
+        for (uint32_t x = 0; x < wk.segs.size(); ++x) of_slot[(size_t)(wk.segs[x].wave * 4 + wk.segs[x].sub) * 16 + wk.segs[x].k].push_back(x);
+        for (auto &v : of_slot) std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return wk.segs[a].t0 < wk.segs[b].t0; });
+        for (int g = 0; g < GROUPS; ++g) {
+            const int wave = g >> 2;
+            size_t ob = (size_t)t.fs_gstart[itx.g0 + g] * NB;
+            uint32_t id = t.fs_gseg0[itx.g0 + g];
+            size_t cur[16] = {0};                            // per slot: the segment whose stay is current / next
+            std::vector<uint32_t> pos(wk.segs.size(), 0);    // per segment: entries consumed (only this group's are touched)
+            for (uint32_t tt = 0; tt < wk.ntiles; ++tt) {
+                const uint32_t tile = wk.tile0 + tt;
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t n = wk.nb[((size_t)tt * WAVES + wave) * 16 + k];
+                    auto &lst = of_slot[(size_t)g * 16 + k];
+                    while (cur[k] < lst.size() && wk.segs[lst[cur[k]]].t1 < tile) ++cur[k];
+                    if (n == 0) continue;
+                    uint32_t c = 0, base = 0, si = 0xFFFFFFFFu;
+                    if (cur[k] < lst.size() && wk.segs[lst[cur[k]]].t0 <= tile) {
+                        si = lst[cur[k]];
+                        const FsSeg &sg = wk.segs[si];
+                        base = sg.off + pos[si];
+                        while (pos[si] + c < sg.cnt && (uint32_t)eu[base + c] / H == tile) ++c;
+                        pos[si] += c;
+                    }
+                    const bool ends = si != 0xFFFFFFFFu && wk.segs[si].t1 == tile;
+                    const uint32_t last_batch = c ? (c - 1) / NB : 0;
+                    for (uint32_t e = 0; e < n * NB; ++e, ++ob) {
+                        const uint32_t flag = (ends && e / NB == last_batch) ? 0x80000000u : 0u;
+                        if (e < c) {
+                            const uint32_t lu = (uint32_t)eu[base + e] % H, lv = elv[base + e];
+                            t.fs_off[ob] = ((lu * W + lv) * (uint32_t)pixel_bytes) | flag; t.fs_w[ob] = ew[base + e];
+                        } else { t.fs_off[ob] = zero_off | flag; t.fs_w[ob] = 0.f; }
+                    }
+                    real_of[o] += c;
+                    if (ends) { const FsSeg &sg = wk.segs[si]; t.fs_rseg_idx[t.fs_rseg_ptr[sg.row] + sg.q] = id++; }
+                }
+            }
+        }
+    });
+    t.fs_npass = npass;
+    t.fs_orient.assign(npass, 0);
+    for (int ps = 0; ps < npass; ++ps) t.fs_orient[ps] = passes[ps].orient;
+    t.fs_shift = shift;
+    t.fs_real_entries = 0;
+    for (uint64_t v : real_of) t.fs_real_entries += v;
+    t.fs_slots = nbatch * NB;
+    t.fs_staged_pixels = 0;
+    for (auto &itx : t.fs_item) t.fs_staged_pixels += (uint64_t)itx.ntiles * W * H;
+    if ((int64_t)t.fs_real_entries != nnz) { why = "strip streams do not cover the matrix"; return false; }
+    t.fs_ok = true;
+    return true;
+}
+
 }  // namespace tomo

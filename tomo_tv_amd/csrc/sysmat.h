@@ -80,6 +80,38 @@ struct Tables {
     std::vector<uint32_t> st_win, st_segid, st_off, st_row_first, st_row_nseg;
     std::vector<uint32_t> st_seg;                // 2 words per slot
     std::vector<float> st_w;
+    // Sheared-strip all-angle forward projector (k_fp_strip, round 4).  The angles are split into "passes" of rays that run in
+    // nearly the same direction; inside a pass the image is cut into strips of FS_W pixels across the rays' mean direction
+    // (columns for rays closer to the y axis, rows otherwise), sheared with that direction: fs_shift[pass][u] is the integer
+    // offset of the strip pattern at march coordinate u, so a ray stays inside ONE strip for a long stretch.  A workgroup
+    // marches one strip tile by tile (FS_H march steps x FS_W pixels x 64 slices in LDS) with the ray sums of the rays inside
+    // the strip RESIDENT IN REGISTERS: a ray owns accumulator slot (wave, k, lane group) from the tile where it enters the strip
+    // to the tile where it leaves, and emits ONE partial sum per strip it crosses (~6 per ray instead of ~27 per ray for
+    // 32 x 16 tiles).  Slots of one angle are dealt round-robin by ray number (ray j -> slot j mod M, M = the widest window of
+    // rays of that angle alive in one tile, rounded up to 4), four neighbouring rays forming the four lane groups of one
+    // (wave, k): they have the same number of entry batches per tile but for the ends, which is what the per-(tile, wave, k)
+    // batch counts fs_cnt (wave-uniform loop bounds) are padded to.
+    //   fs_item[i]      one strip of one pass (sorted by work, heaviest first)
+    //   fs_cnt          16 bytes per (tile, wave): batches of slot k = byte k
+    //   fs_gstart/gseg0 per (item, lane group): first batch of its entry stream / first partial-sum id
+    //   fs_off / fs_w   entry batches of TILE_BATCH entries {LDS byte offset | flush flag << 31, weight}; a flagged batch ends a
+    //                   ray's stay in the strip: the accumulator is stored as the group's next partial sum and cleared
+    //   fs_rseg_*       per ray the partial-sum ids of its strips, ascending strip (the reduce kernel's fixed order)
+    static constexpr int FS_W = 16, FS_H = 16, FS_WAVES = 8, FS_GROUPS = 32, FS_KMAX = 16;
+    struct FsItem { int32_t pass, v0; uint32_t tile0, ntiles, cnt0, g0, work, pad; };
+    bool fs_ok = false;
+    int fs_npass = 0, fs_kused = 0;
+    uint32_t fs_nseg = 0;
+    uint64_t fs_real_entries = 0;                // statistics: matrix entries / padded entry slots / volume pixels staged
+    uint64_t fs_slots = 0, fs_staged_pixels = 0;
+    std::vector<int32_t> fs_orient;              // [npass] 0: march along y (strips of columns), 1: march along z
+    std::vector<int32_t> fs_shift;               // [npass * N]
+    std::vector<FsItem> fs_item;
+    std::vector<uint8_t> fs_cnt;
+    std::vector<uint32_t> fs_gstart, fs_gseg0;
+    std::vector<uint32_t> fs_off;
+    std::vector<float> fs_w;
+    std::vector<uint32_t> fs_rseg_ptr, fs_rseg_idx;
 };
 
 void build_parallel_ray(int N, int P, const double *angles_rad, Coo &out);
@@ -92,5 +124,6 @@ void build_segments(int N, int P, int seg_len, Tables &t);
 void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t);
 void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, int pixel_bytes, Tables &t);
 void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t);
+bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std::string &why);
 
 }  // namespace tomo

@@ -9,7 +9,19 @@
 #include "sysmat.h"
 
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL development headers still builds the engine: librccl is only ever opened with dlopen
+// (rccl_load), so the handful of opaque types and constants of its C API that the tomo_comm_* entries use are restated here
+// (nccl.h: ncclUniqueId is 128 opaque bytes; ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0, ncclSuccess = 0).
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -124,6 +136,7 @@ struct tomo_engine {
     int tv_yseg = 0;                              // rows per wave of the register march; 0 = by slab size (tv_rows_per_wave)
     int tv_march4 = 1;                            // norm / update passes by k_tv_march4 (no row rotation) instead of k_tv_grad_reg
     int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
+    double *gnorm_override = nullptr;             // tomo_comm_tv_gd: the all-reduced sum g^2 (the slot itself keeps the slab's partial sum)
     hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
     float tv_last_eps = 1e-6f;
     float *tv_alt = nullptr, *halo_lo_alt = nullptr, *halo_hi_alt = nullptr;
@@ -221,6 +234,8 @@ struct tomo_engine {
     int fp_reuse = 1;
     // FISTA: the projection of the extrapolated point by linearity (tomo_fista_project_yk)
     float *g_prev = nullptr;                      // A * (the iterate before the last Nesterov step)
+    float *g_yk = nullptr;                        // A * yk formed by linearity; G itself stays A * recon (tomoengine.cpp:410-427,459)
+    struct { bool valid = false; uint64_t ver = 0; } yk_claim;   // g_yk is A * (volume YK at this write-version)
     bool g_prev_valid = false, mom_p_ok = false;
     uint64_t g_prev_recon_ver = 0;
     struct { float beta = 0.f; uint64_t ver_recon = 0, ver_yk = 0, ver_old = 0; bool set = false; } mom;
@@ -236,6 +251,8 @@ struct tomo_engine {
     size_t vol_elems() const { return (size_t)npix * sx; }
     size_t sino_elems() const { return (size_t)nrows * sx; }
 };
+
+static inline double *gnorm_ptr(const tomo_engine *e) { return e->gnorm_override ? e->gnorm_override : e->d_scal + e->gnorm_slot; }
 
 static int dev_alloc(void **p, size_t bytes, bool zero, hipStream_t st)
 {
@@ -259,6 +276,14 @@ static bool g_is_projection_of(const tomo_engine *e, int vol)
     if (!e->fp_reuse || vol < 0 || vol >= TOMO_VOL_SLOTS || !e->sino[TOMO_SINO_G]) return false;
     for (int k = 0; k < 2; ++k) if (e->g_valid[k].vol == vol && e->g_valid[k].ver == e->vol_version[vol]) return true;
     return false;
+}
+
+// the sinogram that holds A * (volume vol as it stands), or nullptr: G through its claim, or the extrapolated point's own buffer
+static const float *projection_in_hand(const tomo_engine *e, int vol)
+{
+    if (g_is_projection_of(e, vol)) return e->sino[TOMO_SINO_G];
+    if (e->fp_reuse && vol == TOMO_VOL_YK && e->g_yk && e->yk_claim.valid && e->yk_claim.ver == e->vol_version[TOMO_VOL_YK]) return e->g_yk;
+    return nullptr;
 }
 
 // After a Nesterov step recon_old == recon (tomoengine.cpp:381-384 copies the prox result into both).  The step keeps that as a
@@ -1036,6 +1061,8 @@ static void free_geometry(tomo_engine *e)
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
     if (e->g_prev) { (void)hipFree(e->g_prev); e->g_prev = nullptr; }
+    if (e->g_yk) { (void)hipFree(e->g_yk); e->g_yk = nullptr; }
+    e->yk_claim.valid = false;
     e->g_prev_valid = e->mom_p_ok = e->mom.set = false;
     e->geometry_released = true;
 }
@@ -1170,6 +1197,11 @@ int tomo_get_sinogram(tomo_engine *e, int which, float *out)
 {
     NEED(e);
     if (!out) return fail(TOMO_ERR_ARG, "null output");
+    if (which == TOMO_SINO_YK_MODEL) {                   // the extrapolated point's projection, while it is one
+        const float *yk = projection_in_hand(e, TOMO_VOL_YK);
+        if (!yk) return fail(TOMO_ERR_STATE, "no projection of the extrapolated point in hand (tomo_fista_project_yk)");
+        return download(e, yk, out, e->nrows);
+    }
     float *src;
     int rc = sino_slot(e, which, &src);
     if (rc) return rc;
@@ -1307,11 +1339,12 @@ int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter)
 {
     NEED(e);
     float *x, *r, *b; int rc;
-    const bool reuse = niter > 0 && sino_b != TOMO_SINO_G && g_is_projection_of(e, vol);   // G is A * this volume, as it stands
+    const float *have = (niter > 0 && sino_b != TOMO_SINO_G) ? projection_in_hand(e, vol) : nullptr;   // A * this volume, as it stands
+    const bool reuse = have != nullptr;
     if (reuse) { if ((rc = order_after_async(e))) return rc; }                            // (an evaluation on the second stream made it)
     if ((rc = get_vol(e, vol, &x)) || (rc = get_sino(e, &e->sino[TOMO_SINO_R], &r)) || (rc = sino_slot(e, sino_b, &b))) return rc;
     for (int it = 0; it < niter; ++it) {
-        if (it == 0 && reuse) { if ((rc = launch_sino_resid<FP_RESID_NORM>(e, b, e->sino[TOMO_SINO_G], r))) return rc; }
+        if (it == 0 && reuse) { if ((rc = launch_sino_resid<FP_RESID_NORM>(e, b, have, r))) return rc; }
         else if ((rc = launch_fp_all<FP_RESID_NORM>(e, x, b, r))) return rc;
         if ((rc = launch_bp_all(e, x, r, e->d_colsum_all, 1.f, 1.f, 1))) return rc;
     }
@@ -1796,27 +1829,27 @@ int tomo_fista_project_yk(tomo_engine *e, int *done)
     if (!e->fp_reuse || !g_is_projection_of(e, TOMO_VOL_RECON) || !e->mom.set) return TOMO_OK;
     if (e->vol_version[TOMO_VOL_RECON] != e->mom.ver_recon || e->vol_version[TOMO_VOL_YK] != e->mom.ver_yk) return TOMO_OK;
     { int rc_ = order_after_async(e); if (rc_) return rc_; }
-    int rc; float *p;
-    if ((rc = get_sino(e, &e->g_prev, &p))) return rc;
-    float *g = e->sino[TOMO_SINO_G];
+    int rc; float *p, *q;
+    if ((rc = get_sino(e, &e->g_prev, &p)) || (rc = get_sino(e, &e->g_yk, &q))) return rc;
+    const float *g = e->sino[TOMO_SINO_G];
     const int64_t n4 = (int64_t)e->sino_elems() / 4;
     const bool have_prev = e->mom_p_ok;
-    if (have_prev) {
-        hipLaunchKernelGGL(k_sino_extrapolate, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const VecOf<4>::T *)g, (VecOf<4>::T *)p, e->mom.beta, n4);
+    e->yk_claim.valid = false;
+    if (have_prev) {   // q = A yk = (1 + beta) A r - beta A r_old; p = A r (the saved projection of the next step): one pass
+        hipLaunchKernelGGL(k_sino_extrapolate, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (const VecOf<4>::T *)g, (VecOf<4>::T *)p, (VecOf<4>::T *)q, e->mom.beta, n4);
         LAUNCHCHK();
-        e->sino[TOMO_SINO_G] = p;                           // A yk; the buffer that held A r becomes the saved projection
-        e->g_prev = g;
     } else {
         HIPCHK(hipMemcpyAsync(p, g, e->sino_elems() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));   // first step: only save A r
     }
     e->g_prev_valid = true;
     e->g_prev_recon_ver = e->vol_version[TOMO_VOL_RECON];
-    if (have_prev || e->mom.beta == 0.f) {                  // (beta = 0: yk is r, bit for bit)
-        g_set(e, TOMO_VOL_YK);
+    // G is untouched: it stays A * recon, with its claim, and get_model_projections() returns what the reference's would
+    if (have_prev) {
+        e->yk_claim.valid = true; e->yk_claim.ver = e->vol_version[TOMO_VOL_YK];
         if (done) *done = 1;
-    } else {
-        g_clear(e);
-        g_set(e, TOMO_VOL_RECON);
+    } else if (e->mom.beta == 0.f) {                        // yk is r, bit for bit: G is A * yk as well (the claim a copy inherits)
+        e->g_valid[1].vol = TOMO_VOL_YK; e->g_valid[1].ver = e->vol_version[TOMO_VOL_YK];
+        if (done) *done = 1;
     }
     return TOMO_OK;
 }
@@ -2187,7 +2220,7 @@ int tomo_tv_halo_apply(tomo_engine *e, float dPOCS, int clamp, const void *g_lo,
     NEED(e);
     if (!g_lo || !g_hi) return fail(TOMO_ERR_ARG, "null plane buffer");
     hipLaunchKernelGGL(k_halo_apply, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, e->halo_lo, e->halo_hi,
-                       (const float *)g_lo, (const float *)g_hi, e->d_scal + e->gnorm_slot, dPOCS, clamp, (int)e->npix);
+                       (const float *)g_lo, (const float *)g_hi, gnorm_ptr(e), dPOCS, clamp, (int)e->npix);
     LAUNCHCHK();
     return TOMO_OK;
 }
@@ -2227,7 +2260,7 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
             wh = e->halo_hi == e->halo_hi_own ? e->halo_hi_alt : e->halo_hi_own;
         }
         Halo h{e->halo_lo, e->halo_hi};
-        TvUpd up{alt, e->d_scal + e->gnorm_slot, dPOCS, clamp, track, wl, wh, slab_streams(e) ? 1 : 0};
+        TvUpd up{alt, gnorm_ptr(e), dPOCS, clamp, track, wl, wh, slab_streams(e) ? 1 : 0};
         {
             ProfScope ps(e, TOMO_K_TV_UPDATE);
             const int yseg = tv_rows_per_wave(e, e->tv_tz == 4 ? 4 : 8);
@@ -2256,8 +2289,8 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
     {
         ProfScope ps(e, TOMO_K_TV_UPDATE);
         float *wl = wrap ? e->halo_lo : plane_last, *wh = wrap ? e->halo_hi : plane_first;
-        if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + e->gnorm_slot, dPOCS, clamp, n4, (f4 *)track, e->d_part, wl, wh, e->nx, e->sx / 4);
-        else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, e->d_scal + e->gnorm_slot, dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr, wl, wh, e->nx, e->sx / 4);
+        if (track) hipLaunchKernelGGL(k_tv_update<true>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, gnorm_ptr(e), dPOCS, clamp, n4, (f4 *)track, e->d_part, wl, wh, e->nx, e->sx / 4);
+        else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, gnorm_ptr(e), dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr, wl, wh, e->nx, e->sx / 4);
     }
     LAUNCHCHK();
     return track ? reduce_end(e, slot) : TOMO_OK;
@@ -2545,14 +2578,27 @@ static int comm_buffers(tomo_engine *e)
 
 // ring exchange inside an open group: my last plane(s) -> next's lo, my first plane(s) -> prev's hi.  With prev == next (two
 // ranks) the two messages to the one peer match in posting order on both sides; with one rank they are self-sends.
-static int comm_ring(tomo_engine *e, const float *first, size_t nfirst, const float *last, size_t nlast, float *lo, float *hi)
+static ncclResult_t comm_ring(tomo_engine *e, const float *first, size_t nfirst, const float *last, size_t nlast, float *lo, float *hi)
 {
     const CommRef *c = e->comm;
     const int nxt = (c->rank + 1) % c->world, prv = (c->rank + c->world - 1) % c->world;
-    NCCLCHK(g_rccl.Send(last, nlast, ncclFloat32, nxt, c->comm, e->stream));
-    NCCLCHK(g_rccl.Send(first, nfirst, ncclFloat32, prv, c->comm, e->stream));
-    NCCLCHK(g_rccl.Recv(lo, nlast, ncclFloat32, prv, c->comm, e->stream));
-    NCCLCHK(g_rccl.Recv(hi, nfirst, ncclFloat32, nxt, c->comm, e->stream));
+    // (inside an open group: no early return -- the caller must reach ncclGroupEnd whatever happens, or every later RCCL call of this
+    // thread, torch.distributed's included, is queued into a group that never closes)
+    ncclResult_t r[4] = {g_rccl.Send(last, nlast, ncclFloat32, nxt, c->comm, e->stream),
+                         g_rccl.Send(first, nfirst, ncclFloat32, prv, c->comm, e->stream),
+                         g_rccl.Recv(lo, nlast, ncclFloat32, prv, c->comm, e->stream),
+                         g_rccl.Recv(hi, nfirst, ncclFloat32, nxt, c->comm, e->stream)};
+    for (ncclResult_t x : r) if (x != ncclSuccess) return x;
+    return ncclSuccess;
+}
+// one group around `body` (which returns the first failing ncclResult_t of what it enqueued): GroupEnd is always reached
+static int comm_group(const char *what, const std::function<ncclResult_t()> &body)
+{
+    NCCLCHK(g_rccl.GroupStart());
+    const ncclResult_t r = body();
+    const ncclResult_t rend = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return fail(TOMO_ERR_HIP, std::string(what) + ": " + g_rccl.GetErrorString(r));
+    if (rend != ncclSuccess) return fail(TOMO_ERR_HIP, std::string(what) + " (ncclGroupEnd): " + g_rccl.GetErrorString(rend));
     return TOMO_OK;
 }
 #define NEED_COMM(e) do { NEED(e); if (!(e)->comm) return fail(TOMO_ERR_STATE, "engine has no communicator (tomo_comm_init)"); { int rc_ = comm_buffers(e); if (rc_) return rc_; } } while (0)
@@ -2613,10 +2659,7 @@ int tomo_comm_exchange_halo(tomo_engine *e, int field)
     NEED_COMM(e);
     int rc;
     if ((rc = tomo_halo_pack_both(e, field, e->comm_send_first, e->comm_send_last))) return rc;
-    NCCLCHK(g_rccl.GroupStart());
-    rc = comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->halo_lo, e->halo_hi);
-    NCCLCHK(g_rccl.GroupEnd());
-    return rc;
+    return comm_group("halo exchange", [&] { return comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->halo_lo, e->halo_hi); });
 }
 
 // all slots of the scalar buffer summed over the ranks into a COPY (the buffer itself keeps this slab's partial sums), read back:
@@ -2673,19 +2716,22 @@ int tomo_comm_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps, int track_vo
     }
     for (int g = 0; g < ng; ++g) {
         if ((rc = tomo_tv_grad_planes(e, eps, g == 0, e->comm_send_first, e->comm_send_last))) return rc;
-        NCCLCHK(g_rccl.GroupStart());
-        ncclResult_t r = g_rccl.AllReduce(e->d_scal + TOMO_S_GNORM, e->d_scal + TOMO_S_GNORM, 1, ncclFloat64, ncclSum, e->comm->comm, e->stream);
-        rc = comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->comm_g_lo, e->comm_g_hi);
-        NCCLCHK(g_rccl.GroupEnd());
-        if (r != ncclSuccess) return fail(TOMO_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+        // the global sum g^2 lands in comm_scal[GNORM]; TOMO_S_GNORM itself keeps this slab's partial sum, so a later
+        // tomo_comm_read_scalars (which sums every slot over the ranks) returns the global norm once, not world times
+        rc = comm_group("tv_gd round", [&] {
+            ncclResult_t r = g_rccl.AllReduce(e->d_scal + TOMO_S_GNORM, e->comm_scal + TOMO_S_GNORM, 1, ncclFloat64, ncclSum, e->comm->comm, e->stream);
+            ncclResult_t r2 = comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->comm_g_lo, e->comm_g_hi);
+            return r != ncclSuccess ? r : r2; });
         if (rc) return rc;
+        e->gnorm_override = e->comm_scal + TOMO_S_GNORM;
         if (g == ng - 1) {
             rc = track_vol >= 0 ? tomo_tv_update_tracked(e, dPOCS, 1, track_vol, slot) : tomo_tv_update(e, dPOCS, 1);
-            if (rc) return rc;
         } else {
-            if ((rc = tomo_tv_update(e, dPOCS, 0))) return rc;                                   // reads the old halo planes ...
-            if ((rc = tomo_tv_halo_apply(e, dPOCS, 0, e->comm_g_lo, e->comm_g_hi))) return rc;  // ... which then follow the neighbours
+            rc = tomo_tv_update(e, dPOCS, 0);                                                    // reads the old halo planes ...
+            if (!rc) rc = tomo_tv_halo_apply(e, dPOCS, 0, e->comm_g_lo, e->comm_g_hi);          // ... which then follow the neighbours
         }
+        e->gnorm_override = nullptr;
+        if (rc) return rc;
     }
     return TOMO_OK;
 }
@@ -2696,10 +2742,7 @@ int tomo_comm_fgp_exchange(tomo_engine *e)
 {
     NEED_COMM(e);
     if (!e->fgp_lo) return fail(TOMO_ERR_STATE, "slab-sharded fused FGP needs tomo_bind_fgp_halo");
-    NCCLCHK(g_rccl.GroupStart());
-    int rc = comm_ring(e, e->fgp_send_first, 4 * (size_t)e->npix, e->fgp_send_last, (size_t)e->npix, e->fgp_lo, e->fgp_hi);
-    NCCLCHK(g_rccl.GroupEnd());
-    return rc;
+    return comm_group("fgp exchange", [&] { return comm_ring(e, e->fgp_send_first, 4 * (size_t)e->npix, e->fgp_send_last, (size_t)e->npix, e->fgp_lo, e->fgp_hi); });
 }
 
 int tomo_set_option(tomo_engine *e, const char *name, int value)
@@ -2713,7 +2756,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
 #ifdef TOMO_WHATIF
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
-    if (std::strcmp(name, "fp_reuse") == 0) { e->fp_reuse = value != 0; g_clear(e); return TOMO_OK; }
+    if (std::strcmp(name, "fp_reuse") == 0) { e->fp_reuse = value != 0; g_clear(e); e->yk_claim.valid = false; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_pipe") == 0) { e->fp_tile_pipe = std::max(0, value); return TOMO_OK; }
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? std::min(value, (int)tomo_engine::MAX_CHAINS) : (value == 1 ? 1 : 0); return TOMO_OK; }
     if (std::strcmp(name, "art_tile") == 0) { e->art_tile = value ? 1 : 0; return TOMO_OK; }
