@@ -287,9 +287,16 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     projected from (tomo_forward_projection into TOMO_SINO_G, tomo_data_distance_sq; tracked by slot and
  *                     write-version, inherited by tomo_copy_volume) starts from that sinogram instead of projecting again:
  *                     bit-identical.  Also gates tomo_fista_project_yk.  0 = every projection recomputed
+ *   "fp_strip" (1):   all-angle forward projection by sheared strips with the ray sums resident in registers (k_fp_strip) when the
+ *                     engine built the strip tables (large slabs; "fp_strip_ready" of tomo_get_option); setting "fp_tile"
+ *                     explicitly also sets "fp_strip" = 0, so that the tile / ray-driven forms can be selected
  *   "fp_tile_pipe" (0): experimental, P >= 2: the tile projector runs as P groups of 64-slice chunks, the reduce pass of one
  *                     group on a second stream beside the tile pass of the next (no gain measured) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
+/* read back a switch, or a fact about the engine: "fp_strip", "fp_tile", "bp_tile", "fp_reuse", "sart_tile", and
+ * "fp_strip_ready" (1: the sheared-strip tables were built at creation -- by the slab-size rule or TOMO_FP_STRIP=1 -- so
+ * "fp_strip" = 1 takes effect), "fp_strip_slots" (accumulator slots per lane group the strip kernel runs with) */
+int tomo_get_option(tomo_engine *e, const char *name, int *value);
 /* ---- native communicator: the slab-sharded path over RCCL on the engine's own stream ---------------------------------------
  * Replaces, for a C / C++ host as for the Python one, the MPI calls of the reference's sharded CPU engine (mpi_ctvlib.cpp:400-422
  * ring exchange of boundary slices, :455 / :547 MPI_Allreduce of the norms) and the OpenMP-over-GPUs loop of multigpuengine.cpp:

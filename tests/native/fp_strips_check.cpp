@@ -48,11 +48,15 @@ int main(int argc, char **argv)
                 const uint8_t *cnt = t.fs_cnt.data() + ((size_t)I.cnt0 + (size_t)tt * WAVES + wave) * 16;
                 for (int k = 0; k < 16; ++k) {
                     REQUIRE(k < t.fs_kused || cnt[k] == 0, "slot %d beyond fs_kused = %d has batches", k, t.fs_kused);
-                    for (int q = 0; q < cnt[k]; ++q, ++b) {
+                    const int h = cnt[k], units = (h + 1) >> 1;              // half batches; a trailing half batch is a unit stored twice
+                    for (int q = 0; q < units; ++q, ++b) {
+                        const bool half = q >= (h >> 1);
                         bool last = false;
                         for (int j = 0; j < NB; ++j) {
-                            uint32_t off = t.fs_off[b * NB + j]; float w = t.fs_w[b * NB + j];
+                            const size_t at = b * NB + j;
+                            uint32_t off = t.fs_off[at]; float w = t.fs_w[at];
                             if (j == 0) last = off >> 31; else REQUIRE((off >> 31) == (uint32_t)last, "flag differs inside batch %zu", b);
+                            if (half && j >= NB / 2) { REQUIRE(off == t.fs_off[at - NB / 2] && w == t.fs_w[at - NB / 2], "half batch %zu is not stored twice", b); continue; }
                             uint32_t lp = (off & 0x7FFFFFFFu) / PIXB;
                             REQUIRE((off & 0x7FFFFFFFu) % PIXB == 0 && lp <= (uint32_t)(W * H), "bad offset");
                             if (lp == (uint32_t)(W * H)) { REQUIRE(w == 0.f, "padding entry with weight"); continue; }
@@ -97,6 +101,23 @@ int main(int argc, char **argv)
             for (int w = 0; w < WAVES; ++w) { uint64_t nb = t.fs_gstart[I.g0 + 4 * w + 1] - t.fs_gstart[I.g0 + 4 * w]; mx = std::max(mx, nb); all += nb; }
             crit += mx * WAVES;
         }
+        // a workgroup meets at a barrier after every tile: the tile costs its slowest wave
+        uint64_t tile_crit = 0, tile_all = 0, empty_slots = 0, used_slots = 0;
+        for (size_t it = 0; it < t.fs_item.size(); ++it) {
+            const Tables::FsItem &I = t.fs_item[it];
+            for (uint32_t tt = 0; tt < I.ntiles; ++tt) {
+                uint64_t mx = 0;
+                for (int w = 0; w < WAVES; ++w) {
+                    const uint8_t *cnt = t.fs_cnt.data() + ((size_t)I.cnt0 + (size_t)tt * WAVES + w) * 16;
+                    uint64_t nb = 0;
+                    for (int k = 0; k < 16; ++k) { nb += cnt[k]; if (k < t.fs_kused) { if (cnt[k]) ++used_slots; else ++empty_slots; } }
+                    mx = std::max(mx, nb); tile_all += nb;
+                }
+                tile_crit += mx * WAVES;
+            }
+        }
+        std::printf("per-tile wave balance %.3f (sum over tiles of the mean wave / the slowest wave); slots in use per tile %.2f of %d\n",
+                    (double)tile_all / tile_crit, (double)used_slots / (used_slots + empty_slots) * t.fs_kused, t.fs_kused);
         std::printf("N=%d P=%d: %d passes, %zu items, K used %d; partial sums %u = %.2f per ray; entries %ld, padded slots %lu (fill %.3f); "
                     "wave balance inside items %.3f; volume staged %.2f x\n",
                     N, P, t.fs_npass, t.fs_item.size(), t.fs_kused, t.fs_nseg, (double)t.fs_nseg / nrows, (long)nnz, (unsigned long)t.fs_slots,

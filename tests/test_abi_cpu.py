@@ -145,6 +145,22 @@ def test_tile_tables_replay_the_matrix(tmp_path, N, P, amax):
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
 
 
+def test_strip_tables_replay_the_matrix(tmp_path):
+    """Host tables of the sheared-strip forward projector (sysmat.cpp: build_fp_strips), replayed on the CPU by
+    tests/native/fp_strips_check.cpp exactly as k_fp_strip walks them (entry streams, per-(tile, wave, slot) batch counts, K
+    accumulators, flush flags, row lists): every matrix entry in exactly one stream, every partial sum written once and
+    used by exactly one row, forward = CSR product; odd sizes, one angle, axis-aligned and steep angles."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fsc")
+    src = [os.path.join(root, "tests", "native", "fp_strips_check.cpp"), os.path.join(root, "tomo_tv_amd", "csrc", "sysmat.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "tomo_tv_amd", "csrc"), *src, "-lpthread", "-o", exe],
+                   check=True)
+    for N, P, amax in [(50, 9, 89.0), (96, 17, 70.0), (33, 4, 45.0), (7, 3, 60.0), (64, 1, 0.0), (16, 5, 70.0), (129, 12, 80.0), (256, 60, 70.0)]:
+        r = subprocess.run([exe, str(N), str(P), str(amax)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.rstrip().endswith("ok"), (N, P, amax, r.stdout + r.stderr)
+
+
 def test_facades_carry_every_method_of_the_reference_tables(golden):
     """tests/golden/method_tables.json holds the method NAMES of the reference's five pybind11 classes; every one of
     them must exist on the class of the same name here (the drop-in boundary of SURVEY.md section 8b)."""

@@ -112,6 +112,30 @@ def test_tile_projectors_equal_ray_and_pixel_driven_forms(big):
     assert np.array_equal(out[0], out[1])
 
 
+def test_strip_projector_equals_tile_form_at_full_size(big):
+    """The sheared-strip forward projector (k_fp_strip: the form large slabs run by default, round 4) against the tile form:
+    the same matrix entries summed in a different order."""
+    t, x, (nx, n, p), ang = big
+    if not t.get_option("fp_strip_ready"):
+        pytest.skip("the engine built no strip tables for this slab (slab-size rule)")
+    out = {}
+    for strip in (1, 0):
+        if strip:
+            t.set_option("fp_strip", 1)
+        else:
+            t.set_option("fp_tile", 1)
+        t.restart_recon()
+        t.create_projections()
+        b = t.get_projections()
+        t.SIRT(2)
+        out[strip] = (b, t.get_volume(), t.data_distance())
+    t.set_option("fp_strip", 1)
+    t.create_projections()                      # the fixture's tilt series as the default form makes it
+    t.restart_recon()
+    assert rel_l2(out[1][0], out[0][0]) < 1e-6
+    assert rel_l2(out[1][1], out[0][1]) < 2e-6 and abs(out[1][2] - out[0][2]) <= 1e-5 * out[0][2]
+
+
 @pytest.fixture(scope="module", params=[(512, 512), (128, 1024)], ids=["config3_512cube", "config4_shard_128x1024sq"])
 def tvbig(request, gpu):
     """TV / FGP never touch the projector tables: two tilts keep the engine small at the BASELINE volume sizes."""

@@ -872,6 +872,44 @@ def test_tile_projectors_match_row_and_pixel_driven_forms(gpu, N, P, Nx):
     assert np.array_equal(t0.get_volume(), t1.get_volume())
 
 
+@pytest.mark.parametrize("N,P,Nx,amax", [(40, 7, 70, 70), (96, 13, 128, 68), (33, 5, 256, 60), (16, 1, 64, 0), (64, 16, 64, 89), (128, 31, 64, 70),
+                                          (50, 4, 100, 45)])
+def test_strip_forward_projector_matches_tile_and_row_forms(gpu, monkeypatch, N, P, Nx, amax):
+    """k_fp_strip (sheared strips, ray sums resident in registers; round 4: the all-angle forward projector of large slabs) against
+    the tile-stationary and the ray-driven forms: the same matrix entries summed in a different order (<= 1e-6), in every epilogue
+    mode the reduce kernel has (store, normalised residual inside SIRT, data distance, Poisson step), and against the oracle."""
+    monkeypatch.setenv("TOMO_FP_STRIP", "1")        # (the engine builds the strip tables by itself only for large slabs)
+    ang = np.linspace(-amax, amax + 1.5, P) if P > 1 else np.array([17.0])
+    x = ellipsoids(Nx, N, seed=5)
+    out = {}
+    for form in ("strip", "tile", "rows"):
+        t = tomoengine(Nx, N, ang * np.pi / 180)
+        assert t.get_option("fp_strip_ready") == 1
+        if form != "strip":
+            t.set_option("fp_tile", 1 if form == "tile" else 0)
+        t.set_volume(x, VOL_ORIGINAL)
+        t.create_projections()
+        b = t.get_projections()
+        t.SIRT(3)
+        v = t.get_volume()
+        dd = t.data_distance()
+        t.initialize_poisson_ML()
+        t.restart_recon()
+        cost = t.poisson_ML(0.7)
+        out[form] = (b, v, dd, t.get_volume(), cost)
+    for other in ("tile", "rows"):
+        assert rel_l2(out["strip"][0], out[other][0]) < 1e-6, other
+        assert rel_l2(out["strip"][1], out[other][1]) < 1e-5, other
+        assert abs(out["strip"][2] - out[other][2]) <= 1e-5 * out[other][2], other
+        assert rel_l2(out["strip"][3], out[other][3]) < 1e-5, other
+        assert abs(out["strip"][4] - out[other][4]) <= 1e-5 * abs(out[other][4]), other
+    ref = oracle.ctvlib(Nx, N, P)
+    ref.load_A(oracle.parallel_ray(N, ang))
+    ref.original_volume = x.copy()
+    ref.create_projections()
+    assert rel_l2(out["strip"][0], ref.b) < 1e-6
+
+
 @pytest.mark.parametrize("N,P,Nx", [(40, 7, 70), (100, 9, 128), (16, 1, 64)])
 def test_tile_sart_step_matches_ray_walk_form_and_oracle(gpu, N, P, Nx):
     """k_sart_tile (streamed tiles) against k_sart_seg (ray walk) and the oracle, natural and permuted angle order."""

@@ -89,6 +89,7 @@ SIGNATURES = {
     "tomo_tv_gd": [_p, _i, _f, _f],
     "tomo_tv_fgp": [_p, _i, _f],
     "tomo_set_option": [_p, ctypes.c_char_p, _i],
+    "tomo_get_option": [_p, ctypes.c_char_p, ctypes.POINTER(_i)],
     "tomo_set_sinogram": [_p, _i, _p],
     "tomo_cgls": [_p, _i, _i],
     "tomo_fbp": [_p, _p, _f, _i],

@@ -440,6 +440,144 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
 #undef FT_LD1
 }
 
+// ---- forward projector, sheared-strip form: the ray sums stay in registers while a workgroup marches a strip ------------------
+// k_fp_tile emits one partial sum per (ray, 32 x 16 tile): 27.5 per ray at 512^2 x 90, 5.3 of the 6.1 GB the projection moves
+// (written, then read again by the reduce kernel).  The partial sums are fewer the longer a ray stays with one workgroup, and
+// what bounds that is where the running sums live: here they live in REGISTERS (K accumulators of 64 slices per 16-lane
+// group: 128 KB per workgroup on top of its 64 KB of LDS).  The angles are split into passes of similar direction (host:
+// sysmat.cpp build_fp_strips); a workgroup owns one strip of FS_W pixels across the pass's mean ray direction, sheared along
+// it, and marches it tile by tile (FS_H march steps): stage the tile in LDS (each pixel a 256-byte image, conflict-free
+// ds_read_b128 as in k_fp_tile), then every 16-lane group walks its entry stream -- slot by slot, the slot's batches of this
+// tile into the slot's accumulator -- and a ray that leaves the strip is flushed as ONE partial sum (flag in its last batch).
+// A ray owns its slot from the tile where it enters to the tile where it leaves; the four lane groups of a wave hold four
+// neighbouring rays of one angle per slot, so the batch counts per (tile, wave, slot) are wave-uniform loop bounds (scalar).
+// 5.4 partial sums per ray at 512^2 x 90 in 5 passes (the volume is staged 5 times instead of once).
+// Entry sharing inside a batch is k_fp_tile's: 8 entries per group and batch, lane l takes them in the rotated order (DPP).
+constexpr int FS_W = 16, FS_H = 16, FS_PIX = FS_W * FS_H, FS_THREADS = 512, FS_WAVES = FS_THREADS / 64, FS_GROUPS = FS_THREADS / 16;
+constexpr int FS_RING = 7;                               // entry batches in flight per lane group (LDS ring slots of 64 B)
+struct FsItemD { int pass, v0; uint32_t tile0, ntiles, cnt0, g0, work, pad; };
+#ifndef FS_WHATIF
+#define FS_WHATIF 0
+#endif
+
+// The entry stream of a lane group (8 entries of 8 bytes per batch) comes from L2 at best, and from HBM for whichever of an
+// item's chunk workgroups touches a line first; the batch loops have run-time trip counts, so a register ring cannot be kept
+// ahead of them (rotating it by moves makes the waitcnt pass wait for the youngest load: measured, the kernel then sits on the
+// table's latency -- 1.79 ms against 1.25 ms with the loads taken out).  The stream is therefore fetched by LDS-DMA
+// (global_load_lds_dword: 64 lanes x 4 bytes = one batch for each of the wave's four lane groups per instruction, no vector
+// register touched) into a per-wave ring of FS_RING slots, FS_RING - 1 batches ahead of the batch being worked on; the entry of
+// the NEXT batch is read from the ring (ds_read_b64, issued by inline asm: the waitcnt pass would otherwise drain the DMAs in
+// flight before every LDS read it cannot tell apart from their destination -- the ring is an LDS object of its own for the same
+// reason, so the tile reads are not held back) while the current batch's pixel images are read.
+template <int K>
+__global__ __launch_bounds__(FS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, const int *__restrict__ orient,
+                const int *__restrict__ shift, const uint4 *__restrict__ cnt, const uint32_t *__restrict__ gstart,
+                const uint32_t *__restrict__ gseg0, const uint2 *__restrict__ ent, float *__restrict__ part, int n, int sx,
+                int nitems, int chunk0, int ncp)
+{
+    typedef VecOf<4>::T V;
+    static_assert(K >= 1 && K <= 16, "slots per lane group");
+    __shared__ V fs_tile[(FS_PIX + 1) * 16];            // the tile, 256-byte pixel images, + the zero pixel of the padding entries
+    __shared__ uint2 fs_ring[FS_WAVES * FS_RING * 32];  // [wave][slot][lane group][8 entries]: two workgroups per CU (80,128 B each)
+    // all chunks of an item run back to back on one XCD (workgroups b and b+8 share an XCD): they read the same tables
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int it = (l / ncp) * 8 + xcd, c = l % ncp;
+    if (it >= nitems) return;
+    const FsItemD I = items[it];
+    const int t = threadIdx.x, gl = t & 15, g = t >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int o = orient[I.pass];
+    const int *sh = shift + (size_t)I.pass * n;
+    const float *xc = x + (size_t)(chunk0 + c) * 64 + gl * 4;
+    // LDS-DMA source of this lane: 4 bytes of its group's batch (16 lanes x 4 B = the batch's 64 bytes); destination: the wave's slot
+    const char *gsrc = reinterpret_cast<const char *>(ent + (size_t)gstart[I.g0 + g] * FT_BATCH) + gl * 4;
+    uint2 *ring_w = fs_ring + wave * (FS_RING * 32);
+    const uint32_t ring_l = (uint32_t)(size_t)(__attribute__((address_space(3))) uint2 *)(ring_w + ((t >> 4) & 3) * 8 + (gl & 7));
+#define FS_DMA(SLOT) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, \
+                                                      (__attribute__((address_space(3))) void *)(ring_w + (SLOT) * 32), 4, 0, 0); gsrc += 64;
+#pragma unroll
+    for (int b = 0; b < FS_RING; ++b) { FS_DMA(b) }     // batches 0 .. FS_RING-1 (the table is padded past its last stream)
+    float *pp = part + ((size_t)gseg0[I.g0 + g] * ncp + c) * 64 + gl * 4;
+    const size_t pstep = (size_t)ncp * 64;
+    V acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = vzero<4>();
+    const char *base = reinterpret_cast<const char *>(fs_tile) + gl * 16;
+    const uint4 *cp = cnt + I.cnt0 + wave;
+    if (t < 16) fs_tile[FS_PIX * 16 + t] = vzero<4>();
+    uint32_t slot = 0;                                  // wave-uniform: ring slot of the batch whose entry `en` holds
+    uint2 en;
+    asm volatile("s_waitcnt vmcnt(%1)\n\tds_read_b64 %0, %2" : "=v"(en) : "n"(FS_RING - 1), "v"(ring_l) : "memory");
+    for (uint32_t tt = 0; tt < I.ntiles; ++tt) {
+        if (tt) __syncthreads();                        // every group is done with the previous tile
+        {
+            const int u0 = (int)(I.tile0 + tt) * FS_H;
+            V v[FS_PIX / FS_GROUPS];
+#pragma unroll
+            for (int i = 0; i < FS_PIX / FS_GROUPS; ++i) {
+                const int q = g + FS_GROUPS * i;
+                const int u = u0 + q / FS_W;
+                const int vv = I.v0 + sh[min(u, n - 1)] + q % FS_W;
+                const bool ok = u < n && (unsigned)vv < (unsigned)n;
+                const size_t pix = o ? (size_t)vv * n + u : (size_t)u * n + vv;
+#if FS_WHATIF & 2
+                v[i] = (ok && tt == 0) ? nt_ld<16>(reinterpret_cast<const V *>(xc + pix * sx)) : vzero<4>();   // timing experiment: one tile staged
+#else
+                v[i] = ok ? nt_ld<16>(reinterpret_cast<const V *>(xc + pix * sx)) : vzero<4>();
+#endif
+            }
+#pragma unroll
+            for (int i = 0; i < FS_PIX / FS_GROUPS; ++i) fs_tile[(g + FS_GROUPS * i) * 16 + gl] = v[i];
+        }
+        __syncthreads();
+        const uint4 c4 = cp[(size_t)tt * FS_WAVES];
+        // One stream unit: the entry of the unit after it is read from the ring while this one's pixel images are read.  FULL: a
+        // batch of 8 entries; !FULL: a half batch, 4 entries stored twice in the unit, so the first four rotations meet all of them.
+#define FS_LD1(J) xv[J] = *reinterpret_cast<const V *>(base + row_ror<J>(off));
+#define FS_FM1(J) acc[k] += __uint_as_float(row_ror<J>(wb)) * xv[J];
+#if FS_WHATIF & 1
+#define FS_NEXT slot = slot == FS_RING - 1 ? 0u : slot + 1u;
+#else
+#define FS_NEXT                                                                                           \
+        FS_DMA(slot)           /* this unit's slot is free (its entry is in registers): fetch the unit FS_RING ahead into it */ \
+        slot = slot == FS_RING - 1 ? 0u : slot + 1u;                                                      \
+        /* the NEXT unit's entry: its DMA is the oldest of the FS_RING now in flight */                    \
+        asm volatile("s_waitcnt vmcnt(%1)\n\tds_read_b64 %0, %2" : "=v"(en) : "n"(FS_RING - 1), "v"(ring_l + slot * 256u) : "memory");
+#endif
+#define FS_UNIT(FULL)                                                                                     \
+        {                                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(en) : : "memory");   /* the ring read issued one unit ago */ \
+            const uint2 e = en;                                                                           \
+            FS_NEXT                                                                                       \
+            const uint32_t off = e.x & 0x7FFFFFFFu, wb = e.y;                                             \
+            V xv[FT_BATCH];                                                                               \
+            FS_LD1(0) FS_LD1(1) FS_LD1(2) FS_LD1(3)                                                       \
+            if (FULL) { FS_LD1(4) FS_LD1(5) FS_LD1(6) FS_LD1(7) }                                         \
+            FS_FM1(0) FS_FM1(1) FS_FM1(2) FS_FM1(3)                                                       \
+            if (FULL) { FS_FM1(4) FS_FM1(5) FS_FM1(6) FS_FM1(7) }                                         \
+            if (!(FS_WHATIF & 1) && (e.x >> 31)) {   /* the ray leaves the strip: its sum is this group's next partial sum */ \
+                nt_st<32>(acc[k], reinterpret_cast<V *>(pp));                                             \
+                acc[k] = vzero<4>();                                                                      \
+                pp += pstep;                                                                              \
+            }                                                                                             \
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t word = k < 4 ? c4.x : k < 8 ? c4.y : k < 12 ? c4.z : c4.w;
+            const uint32_t h = __builtin_amdgcn_readfirstlane((word >> (8 * (k & 3))) & 0xFFu);   // half batches of slot k in this tile
+            for (uint32_t b = h >> 1; b > 0; --b) FS_UNIT(true)
+            if (h & 1) FS_UNIT(false)
+        }
+#undef FS_UNIT
+#undef FS_NEXT
+#undef FS_FM1
+#undef FS_LD1
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(en) : : "memory");   // nothing of this wave's is in flight when its LDS is released
+#undef FS_DMA
+}
+
 // row sums of the tile partials + epilogue.  LPR lanes x float4 cover LPR/16 chunks of one row; part = [seg][ncp][64]
 template <int LPR, int MODE>
 __global__ __launch_bounds__(256) void k_fp_tile_reduce(const float *__restrict__ part, const uint32_t *__restrict__ rsptr,

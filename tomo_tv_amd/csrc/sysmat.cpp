@@ -700,7 +700,7 @@ struct FsWork {                // per item, between the sizing and the emission 
     std::vector<FsSeg> segs;
     std::vector<uint8_t> nb;   // [ntiles][WAVES][16]
     uint32_t tile0 = 0, ntiles = 0, quads = 0;
-    uint32_t wave_batches[Tables::FS_WAVES] = {0};
+    uint32_t wave_batches[Tables::FS_WAVES] = {0}, wave_halves[Tables::FS_WAVES] = {0}, kused = 0;
     uint32_t group_segs[Tables::FS_GROUPS] = {0};
     int32_t pass = 0, strip = 0;
 };
@@ -850,6 +850,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
             std::sort(segs.begin(), segs.end(), [](const FsSeg &a, const FsSeg &c) { return a.ang != c.ang ? a.ang < c.ang : a.j < c.j; });
             uint32_t qbase = 0;
             std::vector<int> jmin(wk.ntiles), jmax(wk.ntiles);
+            std::vector<uint32_t> quad_of(segs.size());
             for (size_t a = 0; a < segs.size();) {
                 size_t e = a;
                 while (e < segs.size() && segs[e].ang == segs[a].ang) ++e;
@@ -860,27 +861,59 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
                 const int M = (span + 3) & ~3;
                 for (size_t x = a; x < e; ++x) {
                     const int slot = segs[x].j % M;
-                    const uint32_t quad = qbase + (uint32_t)(slot >> 2);
-                    segs[x].sub = slot & 3; segs[x].wave = (int32_t)(quad % WAVES); segs[x].k = (int32_t)(quad / WAVES);
+                    quad_of[x] = qbase + (uint32_t)(slot >> 2);
+                    segs[x].sub = slot & 3;
                 }
                 qbase += (uint32_t)(M >> 2);
                 a = e;
             }
             wk.quads = qbase;
             if (qbase > (uint32_t)(WAVES * KMAX)) { over[it] = 1; return; }
-            wk.nb.assign((size_t)wk.ntiles * WAVES * 16, 0);
-            for (auto &sg : segs) {
-                wk.group_segs[sg.wave * 4 + sg.sub]++;
-                uint32_t x = sg.off, end = sg.off + sg.cnt;
-                while (x < end) {
-                    const uint32_t tt = eu[x] / H;
+            // half-batches (4 entries) of every quad in every tile: the four rays of a quad run the same loop, so the longest counts
+            std::vector<uint8_t> hq((size_t)qbase * wk.ntiles, 0);
+            for (size_t x = 0; x < segs.size(); ++x) {
+                const FsSeg &sg = segs[x];
+                uint32_t p = sg.off, end = sg.off + sg.cnt;
+                while (p < end) {
+                    const uint32_t tt = eu[p] / H;
                     uint32_t c = 0;
-                    while (x < end && (uint32_t)eu[x] / H == tt) { ++x; ++c; }
-                    uint8_t &slotnb = wk.nb[((size_t)(tt - lo) * WAVES + sg.wave) * 16 + sg.k];
-                    slotnb = (uint8_t)std::max<uint32_t>(slotnb, std::min<uint32_t>(255u, (c + NB - 1) / NB));
+                    while (p < end && (uint32_t)eu[p] / H == tt) { ++p; ++c; }
+                    uint8_t &h = hq[(size_t)quad_of[x] * wk.ntiles + (tt - lo)];
+                    h = (uint8_t)std::max<uint32_t>(h, std::min<uint32_t>(254u, (c + NB / 2 - 1) / (NB / 2)));
                 }
             }
-            for (uint32_t tt = 0; tt < wk.ntiles; ++tt) for (int w = 0; w < WAVES; ++w) for (int k = 0; k < 16; ++k) wk.wave_batches[w] += wk.nb[((size_t)tt * WAVES + w) * 16 + k];
+            // quads -> (wave, slot): heaviest first, each to the wave (with a free slot) that keeps the per-tile loads most even --
+            // the workgroup meets at a barrier after every tile, so a tile costs its slowest wave
+            std::vector<uint32_t> qorder(qbase), qwork(qbase, 0), qwave(qbase), qk(qbase);
+            for (uint32_t q = 0; q < qbase; ++q) { qorder[q] = q; for (uint32_t tt = 0; tt < wk.ntiles; ++tt) qwork[q] += hq[(size_t)q * wk.ntiles + tt]; }
+            std::sort(qorder.begin(), qorder.end(), [&](uint32_t x, uint32_t y) { return qwork[x] != qwork[y] ? qwork[x] > qwork[y] : x < y; });
+            std::vector<uint32_t> load((size_t)WAVES * wk.ntiles, 0);
+            int used[WAVES] = {0};
+            for (uint32_t q : qorder) {
+                int best = -1; uint64_t bestc = ~0ull;
+                for (int w = 0; w < WAVES; ++w) {
+                    if (used[w] >= KMAX) continue;
+                    uint64_t cst = 0;
+                    for (uint32_t tt = 0; tt < wk.ntiles; ++tt) { uint64_t v = load[(size_t)w * wk.ntiles + tt] + hq[(size_t)q * wk.ntiles + tt]; cst += v * v - (uint64_t)load[(size_t)w * wk.ntiles + tt] * load[(size_t)w * wk.ntiles + tt]; }
+                    if (cst < bestc) { bestc = cst; best = w; }
+                }
+                qwave[q] = (uint32_t)best; qk[q] = (uint32_t)used[best]++;
+                for (uint32_t tt = 0; tt < wk.ntiles; ++tt) load[(size_t)best * wk.ntiles + tt] += hq[(size_t)q * wk.ntiles + tt];
+            }
+            wk.kused = 0;
+            for (int w = 0; w < WAVES; ++w) wk.kused = std::max(wk.kused, (uint32_t)used[w]);
+            wk.nb.assign((size_t)wk.ntiles * WAVES * 16, 0);
+            for (uint32_t q = 0; q < qbase; ++q)
+                for (uint32_t tt = 0; tt < wk.ntiles; ++tt) wk.nb[((size_t)tt * WAVES + qwave[q]) * 16 + qk[q]] = hq[(size_t)q * wk.ntiles + tt];
+            for (size_t x = 0; x < segs.size(); ++x) {
+                segs[x].wave = (int32_t)qwave[quad_of[x]]; segs[x].k = (int32_t)qk[quad_of[x]];
+                wk.group_segs[segs[x].wave * 4 + segs[x].sub]++;
+            }
+            // stream units (64 bytes: a batch of 8 entries, or a half batch stored twice) and work (half-batches) per wave
+            for (uint32_t tt = 0; tt < wk.ntiles; ++tt) for (int w = 0; w < WAVES; ++w) for (int k = 0; k < 16; ++k) {
+                const uint32_t h = wk.nb[((size_t)tt * WAVES + w) * 16 + k];
+                wk.wave_batches[w] += (h + 1) >> 1; wk.wave_halves[w] += h;
+            }
         });
         bool any_over = false;
         for (uint8_t o : over) any_over |= o != 0;
@@ -893,7 +926,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
     const size_t nitems = work.size();
     std::vector<uint32_t> order(nitems);
     for (size_t i = 0; i < nitems; ++i) order[i] = (uint32_t)i;
-    auto crit = [&](const FsWork &w) { uint32_t c = 0; for (int k = 0; k < WAVES; ++k) c = std::max(c, w.wave_batches[k]); return c + 4 * w.ntiles; };
+    auto crit = [&](const FsWork &w) { uint32_t c = 0; for (int k = 0; k < WAVES; ++k) c = std::max(c, w.wave_halves[k]); return c + 8 * w.ntiles; };
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { uint32_t ca = crit(work[a]), cb = crit(work[b]); return ca != cb ? ca > cb : a < b; });
     t.fs_item.assign(nitems, {});
     t.fs_gstart.assign(nitems * GROUPS + 1, 0);
@@ -906,7 +939,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
         itx.pass = wk.pass; itx.v0 = wk.strip * W - OFF; itx.tile0 = wk.tile0; itx.ntiles = wk.ntiles;
         itx.cnt0 = (uint32_t)ncnt; itx.g0 = (uint32_t)(o * GROUPS); itx.work = crit(wk); itx.pad = 0;
         ncnt += (uint64_t)wk.ntiles * WAVES;
-        kused = std::max<int>(kused, (int)((wk.quads + WAVES - 1) / WAVES));
+        kused = std::max<int>(kused, (int)wk.kused);
         for (int g = 0; g < GROUPS; ++g) {
             t.fs_gstart[o * GROUPS + g] = (uint32_t)nbatch; t.fs_gseg0[o * GROUPS + g] = (uint32_t)nseg;
             nbatch += wk.wave_batches[g >> 2]; nseg += wk.group_segs[g];
@@ -918,8 +951,8 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
     t.fs_nseg = (uint32_t)nseg;
     t.fs_cnt.assign((size_t)ncnt * 16 + 16, 0);
     const uint32_t zero_off = (uint32_t)(W * H) * (uint32_t)pixel_bytes;
-    t.fs_off.assign((size_t)(nbatch + 8) * NB, zero_off);     // + the kernel's prefetch distance past the last stream
-    t.fs_w.assign((size_t)(nbatch + 8) * NB, 0.f);
+    t.fs_off.assign((size_t)(nbatch + 16) * NB, zero_off);    // + the kernel's prefetch distance past the last stream
+    t.fs_w.assign((size_t)(nbatch + 16) * NB, 0.f);
     t.fs_rseg_ptr.assign(nrows + 1, 0);
     for (int64_t r = 0; r < nrows; ++r) t.fs_rseg_ptr[r + 1] = t.fs_rseg_ptr[r] + (uint32_t)rsegs[r].size();
     t.fs_rseg_idx.assign(nseg ? nseg : 1, 0);
@@ -935,17 +968,17 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
         for (auto &v : of_slot) std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return wk.segs[a].t0 < wk.segs[b].t0; });
         for (int g = 0; g < GROUPS; ++g) {
             const int wave = g >> 2;
-            size_t ob = (size_t)t.fs_gstart[itx.g0 + g] * NB;
+            size_t oe = (size_t)t.fs_gstart[itx.g0 + g] * NB;          // next entry slot of this stream
             uint32_t id = t.fs_gseg0[itx.g0 + g];
             size_t cur[16] = {0};                            // per slot: the segment whose stay is current / next
             std::vector<uint32_t> pos(wk.segs.size(), 0);    // per segment: entries consumed (only this group's are touched)
             for (uint32_t tt = 0; tt < wk.ntiles; ++tt) {
                 const uint32_t tile = wk.tile0 + tt;
                 for (int k = 0; k < 16; ++k) {
-                    const uint32_t n = wk.nb[((size_t)tt * WAVES + wave) * 16 + k];
+                    const uint32_t h = wk.nb[((size_t)tt * WAVES + wave) * 16 + k];   // half-batches of this slot in this tile
                     auto &lst = of_slot[(size_t)g * 16 + k];
                     while (cur[k] < lst.size() && wk.segs[lst[cur[k]]].t1 < tile) ++cur[k];
-                    if (n == 0) continue;
+                    if (h == 0) continue;
                     uint32_t c = 0, base = 0, si = 0xFFFFFFFFu;
                     if (cur[k] < lst.size() && wk.segs[lst[cur[k]]].t0 <= tile) {
                         si = lst[cur[k]];
@@ -955,13 +988,19 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
                         pos[si] += c;
                     }
                     const bool ends = si != 0xFFFFFFFFu && wk.segs[si].t1 == tile;
-                    const uint32_t last_batch = c ? (c - 1) / NB : 0;
-                    for (uint32_t e = 0; e < n * NB; ++e, ++ob) {
-                        const uint32_t flag = (ends && e / NB == last_batch) ? 0x80000000u : 0u;
-                        if (e < c) {
-                            const uint32_t lu = (uint32_t)eu[base + e] % H, lv = elv[base + e];
-                            t.fs_off[ob] = ((lu * W + lv) * (uint32_t)pixel_bytes) | flag; t.fs_w[ob] = ew[base + e];
-                        } else { t.fs_off[ob] = zero_off | flag; t.fs_w[ob] = 0.f; }
+                    // h >> 1 whole batches, then (h odd) a half batch: its 4 entries stored twice, so that the rotated reads of
+                    // the 8 lanes that share a batch (lane l takes entry l, l+1, l+2, l+3 mod 8) meet all four in every lane
+                    const uint32_t nfull = h >> 1, units = (h + 1) >> 1;
+                    const uint32_t last_unit = c ? std::min((c - 1) / NB, units - 1) : 0;
+                    for (uint32_t un = 0; un < units; ++un) {
+                        const uint32_t flag = (ends && un == last_unit) ? 0x80000000u : 0u;
+                        for (uint32_t j = 0; j < (uint32_t)NB; ++j, ++oe) {
+                            const uint32_t e = un < nfull ? un * NB + j : nfull * NB + j % (NB / 2);
+                            if (e < c) {
+                                const uint32_t lu = (uint32_t)eu[base + e] % H, lv = elv[base + e];
+                                t.fs_off[oe] = ((lu * W + lv) * (uint32_t)pixel_bytes) | flag; t.fs_w[oe] = ew[base + e];
+                            } else { t.fs_off[oe] = zero_off | flag; t.fs_w[oe] = 0.f; }
+                        }
                     }
                     real_of[o] += c;
                     if (ends) { const FsSeg &sg = wk.segs[si]; t.fs_rseg_idx[t.fs_rseg_ptr[sg.row] + sg.q] = id++; }
@@ -975,7 +1014,8 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
     t.fs_shift = shift;
     t.fs_real_entries = 0;
     for (uint64_t v : real_of) t.fs_real_entries += v;
-    t.fs_slots = nbatch * NB;
+    t.fs_slots = 0;
+    for (auto &wk : work) for (int w = 0; w < WAVES; ++w) t.fs_slots += (uint64_t)wk.wave_halves[w] * (NB / 2) * 4;   // entry slots the kernel walks
     t.fs_staged_pixels = 0;
     for (auto &itx : t.fs_item) t.fs_staged_pixels += (uint64_t)itx.ntiles * W * H;
     if ((int64_t)t.fs_real_entries != nnz) { why = "strip streams do not cover the matrix"; return false; }

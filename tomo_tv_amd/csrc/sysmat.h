@@ -92,7 +92,8 @@ struct Tables {
     // (wave, k): they have the same number of entry batches per tile but for the ends, which is what the per-(tile, wave, k)
     // batch counts fs_cnt (wave-uniform loop bounds) are padded to.
     //   fs_item[i]      one strip of one pass (sorted by work, heaviest first)
-    //   fs_cnt          16 bytes per (tile, wave): batches of slot k = byte k
+    //   fs_cnt          16 bytes per (tile, wave): HALF batches of slot k = byte k (h >> 1 whole batches, then, h odd, one half batch:
+    //                   a stream unit whose 4 entries are stored twice)
     //   fs_gstart/gseg0 per (item, lane group): first batch of its entry stream / first partial-sum id
     //   fs_off / fs_w   entry batches of TILE_BATCH entries {LDS byte offset | flush flag << 31, weight}; a flagged batch ends a
     //                   ray's stay in the strip: the accumulator is stored as the group's next partial sum and cleared

@@ -153,6 +153,16 @@ struct tomo_engine {
     uint32_t *d_ft_slot_ptr = nullptr, *d_ft_slot_seg0 = nullptr, *d_ft_rsptr = nullptr, *d_ft_rsidx = nullptr;
     uint2 *d_ft_tent = nullptr;
     float *ft_part = nullptr, *ft_part_aux = nullptr;
+    // sheared-strip all-angle FP (k_fp_strip, round 4): ray sums resident in registers, ~5 partial sums per ray instead of ~27
+    int fp_strip = 1, fs_nitems = 0, fs_kused = 0, fs_ncp = 0;
+    bool fs_ok = false, attr_fs = false;
+    uint32_t fs_nseg = 0;
+    FsItemD *d_fs_items = nullptr;
+    int *d_fs_orient = nullptr, *d_fs_shift = nullptr;
+    uint4 *d_fs_cnt = nullptr;
+    uint32_t *d_fs_gstart = nullptr, *d_fs_gseg0 = nullptr, *d_fs_rsptr = nullptr, *d_fs_rsidx = nullptr;
+    uint2 *d_fs_ent = nullptr;
+    float *fs_part = nullptr, *fs_part_aux = nullptr;
     // all-angle FP as a two-stage pipeline over groups of 64-slice chunks ("fp_tile_pipe"): [0] main stream, [1] second stream
     int fp_tile_pipe = 0;   // off: measured (round 3) 1.50 vs 1.52 ms at 512^3 x 90, 1.91 vs 1.83 ms at 128 x 1024^2 x 120, 0.127 vs 0.154 ms at 256^3 x 60
     hipStream_t fp_red_stream[2] = {nullptr, nullptr};
@@ -453,10 +463,64 @@ static int launch_fp(tomo_engine *e, const float *x, int row0, int nrows, const 
     return TOMO_OK;
 }
 
-// all-angle FP: tile-stationary form (k_fp_tile + k_fp_tile_reduce) unless switched off, else the ray-driven form
+template <int MODE>
+static void launch_fp_reduce(tomo_engine *e, hipStream_t rs, const float *part, const uint32_t *rsptr, const uint32_t *rsidx, const float *b,
+                             float *out, int c0, int ncp)
+{
+    int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
+    int64_t items = (int64_t)e->nrows * (ncp * 16 / lpr);
+    int64_t waves = (items + 64 / lpr - 1) / (64 / lpr);
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (lpr) {
+    case 64: hipLaunchKernelGGL((k_fp_tile_reduce<64, MODE>), grid, block, 0, rs, part, rsptr, rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+    case 32: hipLaunchKernelGGL((k_fp_tile_reduce<32, MODE>), grid, block, 0, rs, part, rsptr, rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+    default: hipLaunchKernelGGL((k_fp_tile_reduce<16, MODE>), grid, block, 0, rs, part, rsptr, rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
+    }
+}
+
+// all-angle FP, sheared-strip form (k_fp_strip + k_fp_tile_reduce on the strips' row lists)
+template <int MODE>
+static int launch_fp_strip(tomo_engine *e, const float *x, const float *b, float *out)
+{
+    const int nchunk = e->sxc / 64;
+    if (!e->fs_ncp) {
+        size_t per_chunk = (size_t)std::max<uint32_t>(1, e->fs_nseg) * 64 * sizeof(float);
+        int ncp = (int)std::min<size_t>(nchunk, std::max<size_t>(1, e->ft_scratch_cap / per_chunk));
+        if (e->ft_ncp_forced > 0) ncp = std::min(nchunk, e->ft_ncp_forced);
+        else if (ncp >= 4) ncp &= ~3; else if (ncp >= 2) ncp &= ~1;
+        e->fs_ncp = ncp;
+    }
+    const int which = (e->aux && e->stream == e->aux) ? 1 : 0;
+    float **slot = which ? &e->fs_part_aux : &e->fs_part;
+    if (!*slot) {
+        int rc = dev_alloc((void **)slot, (size_t)std::max<uint32_t>(1, e->fs_nseg) * e->fs_ncp * 64 * sizeof(float), false, e->stream);
+        if (rc) return rc;
+    }
+    for (int c0 = 0; c0 < nchunk; c0 += e->fs_ncp) {
+        const int ncp = std::min(e->fs_ncp, nchunk - c0);
+        {
+            ProfScope ps(e, TOMO_K_FP_TILE);
+            dim3 grid((unsigned)(8 * ((e->fs_nitems + 7) / 8) * ncp)), block(FS_THREADS);
+#define FS_LAUNCH(KK) hipLaunchKernelGGL((k_fp_strip<KK>), grid, block, 0, e->stream, x, e->d_fs_items, e->d_fs_orient, e->d_fs_shift, e->d_fs_cnt, \
+                                         e->d_fs_gstart, e->d_fs_gseg0, e->d_fs_ent, *slot, e->n, e->sx, e->fs_nitems, c0, ncp)
+            if (e->fs_kused <= 8) FS_LAUNCH(8); else if (e->fs_kused <= 12) FS_LAUNCH(12); else FS_LAUNCH(16);
+#undef FS_LAUNCH
+            LAUNCHCHK();
+        }
+        {
+            ProfScope ps(e, TOMO_K_FP_REDUCE);
+            launch_fp_reduce<MODE>(e, e->stream, *slot, e->d_fs_rsptr, e->d_fs_rsidx, b, out, c0, ncp);
+            LAUNCHCHK();
+        }
+    }
+    return TOMO_OK;
+}
+
+// all-angle FP: sheared-strip form, else the tile-stationary form (k_fp_tile + k_fp_tile_reduce) unless switched off, else the ray-driven form
 template <int MODE>
 static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *out)
 {
+    if (e->fp_strip && e->fs_ok) return launch_fp_strip<MODE>(e, x, b, out);
     if (!e->fp_tile) return launch_fp<MODE>(e, x, 0, (int)e->nrows, b, out, e->fp_all_lpr);
     const int nchunk = e->sxc / 64;
     if (!e->ft_ncp) {
@@ -519,15 +583,7 @@ static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *
         }
         {
             ProfScope ps(e, TOMO_K_FP_REDUCE, rs);
-            int lpr = (ncp % 4 == 0) ? 64 : (ncp % 2 == 0) ? 32 : 16;
-            int64_t items = (int64_t)e->nrows * (ncp * 16 / lpr);
-            int64_t waves = (items + 64 / lpr - 1) / (64 / lpr);
-            dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-            switch (lpr) {
-            case 64: hipLaunchKernelGGL((k_fp_tile_reduce<64, MODE>), grid, block, 0, rs, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
-            case 32: hipLaunchKernelGGL((k_fp_tile_reduce<32, MODE>), grid, block, 0, rs, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
-            default: hipLaunchKernelGGL((k_fp_tile_reduce<16, MODE>), grid, block, 0, rs, part, e->d_ft_rsptr, e->d_ft_rsidx, b, e->d_rowsum, out, e->d_part, (int)e->nrows, e->sx, c0, ncp); break;
-            }
+            launch_fp_reduce<MODE>(e, rs, part, e->d_ft_rsptr, e->d_ft_rsidx, b, out, c0, ncp);
             LAUNCHCHK();
         }
         if (pipe) HIPCHK(hipEventRecord(e->ev_fp_red[which][half], rs));
@@ -851,6 +907,42 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_ft_rsptr, t.rseg_ptr.data(), t.rseg_ptr.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
         release(tent); release(t.tile_off); release(t.tile_w); release(t.rseg_idx); release(t.rseg_ptr); release(t.tile_slot_ptr); release(t.tile_slot_seg0);
+        {   // sheared-strip tables of the all-angle FP; a geometry they cannot hold (a user matrix whose rays are no lines) keeps the tile form
+            std::string why;
+            static_assert(Tables::FS_W == FS_W && Tables::FS_H == FS_H && Tables::FS_WAVES == FS_WAVES && Tables::FS_GROUPS == FS_GROUPS, "strip shape");
+            static_assert(sizeof(Tables::FsItem) == sizeof(FsItemD), "strip item layout");
+            // Measured (round 4, MI355X, FP alone, strips against tiles): 1024^3 x 120 12.1 / 14.6 ms, 1024 x 512^2 x 90 2.55 / 2.82,
+            // 512^3 x 90 1.28 / 1.37 -- and 256 x 512^2 0.76 / 0.70, 128 x 1024^2 x 120 1.89 / 1.68, 256^3 x 60 0.18 / 0.12: a strip is one
+            // long sequential march, so the form pays once there are several rounds of workgroups (~0.4 N strips x chunks of 64 slices
+            // over 512 resident workgroups).  TOMO_FP_STRIP = 0 / 1 overrides the rule (tests build the tables at small sizes).
+            bool want = (int64_t)e->n * (e->sxc / 64) >= 4000;
+            if (const char *env = std::getenv("TOMO_FP_STRIP")) want = std::atoi(env) != 0;
+            e->fs_ok = want && build_fp_strips(m, e->n, e->np, 256, t, why);
+            if (e->fs_ok) {
+                e->fs_nitems = (int)t.fs_item.size(); e->fs_kused = t.fs_kused; e->fs_nseg = t.fs_nseg;
+                std::vector<uint2> sent(t.fs_off.size());
+                for (size_t k = 0; k < sent.size(); ++k) { uint32_t bits; std::memcpy(&bits, &t.fs_w[k], 4); sent[k] = make_uint2(t.fs_off[k], bits); }
+                if ((rc = dev_alloc((void **)&e->d_fs_items, t.fs_item.size() * sizeof(FsItemD), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_orient, t.fs_orient.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_shift, t.fs_shift.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_cnt, t.fs_cnt.size(), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_gstart, t.fs_gstart.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_gseg0, t.fs_gseg0.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_ent, sent.size() * sizeof(uint2), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_rsptr, t.fs_rseg_ptr.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_rsidx, t.fs_rseg_idx.size() * 4, false, e->stream))) return rc;
+                HIPCHK(hipMemcpy(e->d_fs_items, t.fs_item.data(), t.fs_item.size() * sizeof(FsItemD), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_orient, t.fs_orient.data(), t.fs_orient.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_shift, t.fs_shift.data(), t.fs_shift.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_cnt, t.fs_cnt.data(), t.fs_cnt.size(), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_gstart, t.fs_gstart.data(), t.fs_gstart.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_gseg0, t.fs_gseg0.data(), t.fs_gseg0.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_ent, sent.data(), sent.size() * sizeof(uint2), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_rsptr, t.fs_rseg_ptr.data(), t.fs_rseg_ptr.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_rsidx, t.fs_rseg_idx.data(), t.fs_rseg_idx.size() * 4, hipMemcpyHostToDevice));
+            }
+            release(t.fs_off); release(t.fs_w); release(t.fs_cnt); release(t.fs_rseg_idx); release(t.fs_rseg_ptr); release(t.fs_gstart); release(t.fs_gseg0);
+        }
         build_sart_tiles(m, e->n, e->np, ST_TY, ST_TZ, ST_MAXR, 256, t);
         static_assert(Tables::ST_MAXSEG == ST_MAXSEG, "segment slots per tile");
         e->st_ok = t.st_ok;
@@ -1057,7 +1149,9 @@ static void free_geometry(tomo_engine *e)
                      (void **)&e->ft_part, (void **)&e->ft_part_aux, (void **)&e->cg_w, (void **)&e->fbp_h, (void **)&e->d_seg_exec,
                      (void **)&e->d_row_first, (void **)&e->d_row_nseg, (void **)&e->seg_partial, (void **)&e->d_wptr, (void **)&e->d_went,
                      (void **)&e->d_rptr, (void **)&e->d_rent, (void **)&e->d_rowsum, (void **)&e->d_rowinner, (void **)&e->d_colsum_all,
-                     (void **)&e->d_rowcross, (void **)&e->d_cell};
+                     (void **)&e->d_rowcross, (void **)&e->d_cell,
+                     (void **)&e->d_fs_items, (void **)&e->d_fs_orient, (void **)&e->d_fs_shift, (void **)&e->d_fs_cnt, (void **)&e->d_fs_gstart,
+                     (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
     if (e->g_prev) { (void)hipFree(e->g_prev); e->g_prev = nullptr; }
@@ -2745,6 +2839,19 @@ int tomo_comm_fgp_exchange(tomo_engine *e)
     return comm_group("fgp exchange", [&] { return comm_ring(e, e->fgp_send_first, 4 * (size_t)e->npix, e->fgp_send_last, (size_t)e->npix, e->fgp_lo, e->fgp_hi); });
 }
 
+int tomo_get_option(tomo_engine *e, const char *name, int *value)
+{
+    if (!e || !name || !value) return fail(TOMO_ERR_ARG, "null argument");
+    if (std::strcmp(name, "fp_strip") == 0) { *value = e->fp_strip; return TOMO_OK; }
+    if (std::strcmp(name, "fp_strip_ready") == 0) { *value = e->fs_ok ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_strip_slots") == 0) { *value = e->fs_ok ? e->fs_kused : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_tile") == 0) { *value = e->fp_tile; return TOMO_OK; }
+    if (std::strcmp(name, "bp_tile") == 0) { *value = e->bp_tile; return TOMO_OK; }
+    if (std::strcmp(name, "fp_reuse") == 0) { *value = e->fp_reuse; return TOMO_OK; }
+    if (std::strcmp(name, "sart_tile") == 0) { *value = e->sart_tile; return TOMO_OK; }
+    return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
+}
+
 int tomo_set_option(tomo_engine *e, const char *name, int value)
 {
     if (!e || !name) return fail(TOMO_ERR_ARG, "null argument");
@@ -2765,14 +2872,17 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_coop") == 0) { e->sart_coop = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
-    if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; return TOMO_OK; }
+    // all-angle FP form: "fp_strip" = 1 (default) sheared strips; asking for "fp_tile" = 1 / 0 explicitly selects the tile-stationary /
+    // the ray-driven form (and takes the strips out of the way until "fp_strip" = 1 is set again)
+    if (std::strcmp(name, "fp_strip") == 0) { e->fp_strip = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; e->fp_strip = 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_chunks_per_pass") == 0) {   // any count >= 1 (0 = from the scratch cap); before the first projection
-        if (value < 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_chunks_per_pass must be set before the first projection");
-        e->ft_ncp_forced = value; e->ft_ncp = 0; return TOMO_OK;
+        if (value < 0 || e->ft_part || e->ft_part_aux || e->fs_part || e->fs_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_chunks_per_pass must be set before the first projection");
+        e->ft_ncp_forced = value; e->ft_ncp = 0; e->fs_ncp = 0; return TOMO_OK;
     }
     if (std::strcmp(name, "fp_tile_scratch_mib") == 0) {   // cap of the partial-sum scratch; takes effect before the first all-angle FP
-        if (value <= 0 || e->ft_part || e->ft_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
-        e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; return TOMO_OK;
+        if (value <= 0 || e->ft_part || e->ft_part_aux || e->fs_part || e->fs_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
+        e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; e->fs_ncp = 0; return TOMO_OK;
     }
     if (std::strcmp(name, "tv_gnorm_slot") == 0) {
         if (value < 0 || value >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");

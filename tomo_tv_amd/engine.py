@@ -844,6 +844,13 @@ class _EngineBase:
         self.be.c("set_option", name.encode(), int(value))
         self._options[name] = int(value)
 
+    def get_option(self, name):
+        """A switch or a fact about the (first sub-slab) engine (include/tomo_hip.h: tomo_get_option)."""
+        v = ctypes.c_int(0)
+        kid = getattr(self.be, "kids", [self.be])[0]
+        check(kid.L.tomo_get_option(kid.h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
+
     # ---- simulation edges shared by every engine class ---------------------------------------------------------
     def poisson_noise(self, Nc, seed=4321):
         """Poisson noise on the tilt series at a mean of ``Nc`` counts per sample, total intensity preserved
