@@ -201,7 +201,7 @@ def test_sart_two_stream_sub_slabs_equal_one_chain(big):
     assert np.array_equal(res[1][1], res[2][1])
 
 
-def test_config4_whole_volume_on_one_gpu(gpu):
+def test_config4_whole_volume_on_one_gpu(gpu, monkeypatch):
     """BASELINE config 4 unsharded: 1024^3, 120 tilts on ONE GPU (4 GiB per volume, every byte offset beyond 2^31).
     The phantom is the 128-slice shard phantom tiled 8 times along the tilt axis, so every 128-slice block of the whole-
     volume result must equal what a 128 x 1024^2 engine makes of one block (slices share the system matrix): SART sweep
@@ -212,6 +212,9 @@ def test_config4_whole_volume_on_one_gpu(gpu):
     nx, n, p, blk = 1024, 1024, 120, 128
     ang = np.deg2rad(tilt_angles(p))
     xb = ellipsoids(blk, n)
+    # the whole volume projects by sheared strips (slab-size rule, round 4): give the 128-slice engine the same form, so that the
+    # two sum every ray in the same order and the comparison below can stay bit for bit
+    monkeypatch.setenv("TOMO_FP_STRIP", "1")
     small = tomoengine(blk, n, ang)
     small.set_volume(xb, VOL_ORIGINAL)
     small.create_projections()

@@ -1,0 +1,87 @@
+"""The in-process multi-GPU facade (tomo_tv_amd/inprocess.py) on CPU: K slab engines behind ONE method table, one host thread
+per engine, composed like the ranks of a job ("one call -> enqueue on all GPUs -> one sync"; reference:
+tomofusion/__init__.py:21-34, gpu/reconstructor.py:23-33, multigpuengine.cpp:140-193).
+
+The per-slab kernels are replaced by tests/slab_double.py (numpy + oracle), so what is under test is the product's host logic:
+every facade call is forwarded to all slab engines at once, scalars come back all-reduced, getters assemble the whole array, plain
+attributes are written to every rank, an exception on one rank surfaces on the caller and leaves the world usable.  The sharded
+result must equal the single-process oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import oracle  # noqa: E402
+from slab_double import OracleSlabBackend  # noqa: E402
+from tomo_tv_amd import engine  # noqa: E402
+from tomo_tv_amd._lib import VOL_TEMP  # noqa: E402
+from tomo_tv_amd.inprocess import InProcessMultiGPU  # noqa: E402
+from tomo_tv_amd.phantom import ellipsoids  # noqa: E402
+
+
+class ShardedEngine(engine.tomoengine):
+    _backend_cls = OracleSlabBackend
+
+
+def rel(a, b):
+    return float(np.linalg.norm((a.astype(np.float64) - b).ravel()) / np.linalg.norm(b.astype(np.float64).ravel()))
+
+
+@pytest.mark.parametrize("world,Nx", [(2, 6), (3, 7), (1, 4)])
+def test_facade_over_threads_equals_single_process_oracle(world, Nx):
+    N, P = 16, 5
+    ang = np.linspace(-65, 65, P)
+    x = ellipsoids(Nx, N, seed=21)
+    full = oracle.ctvlib(Nx, N, P)
+    full.load_A(oracle.parallel_ray(N, ang))
+    full.original_volume = x.copy()
+    full.create_projections()
+    t = InProcessMultiGPU(lambda comm, dev: ShardedEngine(Nx, N, ang * np.pi / 180, device=dev, comm=comm), [0] * world)
+    try:
+        assert t.get_gpu_ids() == [0] * world and t.is_multi_gpu_enabled() == (world > 1)
+        t.tv_eps = full.tv_eps = 1e-6                     # written to every rank
+        assert all(e.tv_eps == 1e-6 for e in t._engines)
+        t.set_tilt_series(full.b)                         # the GLOBAL array; every rank keeps its slab
+        t.copy_recon(); full.copy_recon()
+        t.SART(0.5, 1); full.SART(0.5, 1)
+        assert abs(t.matrix_2norm() - full.matrix_2norm()) <= 1e-5 * full.matrix_2norm()
+        assert abs(t.data_distance() - full.data_distance(normalize=False)) <= 1e-5 * full.data_distance(normalize=False)
+        assert abs(t.tv() - full.tv()) <= 1e-5 * full.tv()
+        t.copy_recon(); full.copy_recon()
+        tv0, tv0_ref = t.tv_gd(4, 0.3), full.tv_gd(4, 0.3)
+        assert abs(tv0 - tv0_ref) <= 1e-5 * tv0_ref
+        got = t.get_volume()
+        assert got.shape == (Nx, N, N) and rel(got, full.recon) < 1e-5
+        assert rel(t.get_recon(Nx // 2), full.recon[Nx // 2]) < 1e-5     # collective: broadcast from the owner
+        t.copy_recon(); full.copy_recon()
+        dp = t.SART_tracked(0.5, 1)
+        full.SART(0.5, 1)
+        assert abs(dp - full.matrix_2norm()) <= 1e-5 * full.matrix_2norm()
+        assert rel(t.get_volume(VOL_TEMP), full.recon) < 1e-5
+        # an exception on the ranks surfaces on the caller, and the world stays usable afterwards
+        with pytest.raises(ValueError):
+            t.set_tilt_series(np.zeros((Nx + 1, N * P), np.float32))
+        assert abs(t.tv() - full.tv()) <= 1e-5 * full.tv()
+    finally:
+        t.close()
+
+
+def test_plain_process_config_follows_the_visible_devices(monkeypatch):
+    """determine_gpu_config (tomofusion/__init__.py:21-34): 'multigpu' when no device is named and more than one is visible."""
+    from tomo_tv_amd import reconstructor
+    monkeypatch.setattr(reconstructor, "device_count", lambda: [0, 1, 2, 3])
+    assert reconstructor.determine_gpu_config(-1) == "multigpu"
+    assert reconstructor.determine_gpu_config(2) == "singleconfig"
+    monkeypatch.setenv("TOMO_SINGLE_GPU", "1")
+    assert reconstructor.determine_gpu_config(-1) == "singleconfig"
+    monkeypatch.delenv("TOMO_SINGLE_GPU")
+    monkeypatch.setattr(reconstructor, "device_count", lambda: [0])
+    assert reconstructor.determine_gpu_config(-1) == "singleconfig"
+    monkeypatch.setattr(reconstructor, "device_count", lambda: [])
+    with pytest.raises(ValueError):
+        reconstructor.determine_gpu_config(-1)

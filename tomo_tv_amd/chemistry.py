@@ -312,7 +312,17 @@ class multigpufusion(multimodal):
     in every rank of a ``torchrun`` job with the GLOBAL sizes.  Unlike the reference (where only ``poisson_ml`` is really
     multi-GPU, quirk Q14, and the fusion step drops a factor, quirk Q12) every method runs on the slabs."""
 
-    def __init__(self, Nslice, Nray, Nelements, haadfAngles, chemAngles, group=None):
+    def __new__(cls, Nslice, Nray, Nelements, haadfAngles, chemAngles, group=None, devices=None):
+        # a plain process spreads the slabs over the visible GPUs by itself, one host thread per device (inprocess.py), like the
+        # reference's class (multigpufusion.cpp:140-193); inside a torchrun job every rank constructs its own slab
+        from . import inprocess
+        if group is None and inprocess.process_group_world() <= 1:
+            devs = list(devices) if devices is not None else inprocess.visible_devices()
+            return inprocess.InProcessMultiGPU(
+                lambda comm, dev: multimodal(Nslice, Nray, Nelements, haadfAngles, chemAngles, device=dev, comm=comm), devs)
+        return super().__new__(cls)
+
+    def __init__(self, Nslice, Nray, Nelements, haadfAngles, chemAngles, group=None, devices=None):
         from .distributed import SlabComm
         super().__init__(Nslice, Nray, Nelements, haadfAngles, chemAngles, device=None, comm=SlabComm(group))
 
@@ -334,8 +344,13 @@ class ChemicalTomo:
         self.nx, self.ny, _ = haadf.shape
         self.elements = list(chem)
         self.nz = len(chem)
-        self.tomo = multimodal(self.nx, self.ny, self.nz, np.deg2rad(haadfTiltAngles), np.deg2rad(chemTiltAngles),
-                               device=(None if gpu_id < 0 else gpu_id), comm=comm)   # None: the rank's current device
+        from .reconstructor import determine_gpu_config
+        if comm is None and determine_gpu_config(gpu_id) == "multigpu":
+            # more than one GPU and no explicit choice: the sharded class, as chemistry/reconstructor.py:44-88 picks it
+            self.tomo = multigpufusion(self.nx, self.ny, self.nz, np.deg2rad(haadfTiltAngles), np.deg2rad(chemTiltAngles))
+        else:
+            self.tomo = multimodal(self.nx, self.ny, self.nz, np.deg2rad(haadfTiltAngles), np.deg2rad(chemTiltAngles),
+                                   device=(None if gpu_id < 0 else gpu_id), comm=comm)   # None: the rank's current device
         self.NprojHAADF, self.NprojCHEM = len(haadfTiltAngles), len(chemTiltAngles)
         self.set_haadf_projections(haadf)
         self.set_chemical_projections(chem)

@@ -76,6 +76,11 @@ class SlabComm:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return t
 
+    def allreduce_min(self, t):
+        if self.world > 1 or self.force:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t
+
     def broadcast(self, t, src):
         if self.world > 1 or self.force:
             self.dist.broadcast(t, src=self.global_rank(src), group=self.group)

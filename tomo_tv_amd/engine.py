@@ -107,8 +107,7 @@ class _SlabBackend:
 
         def all_ok(ok):
             flag = torch.tensor([ok], dtype=torch.int32, device=self.tdev)
-            if comm.world > 1 or comm.force:
-                comm.dist.all_reduce(flag, op=comm.dist.ReduceOp.MIN, group=comm.group)
+            comm.allreduce_min(flag)
             return int(flag.item()) == 1
         idbuf = (ctypes.c_ubyte * 128)()
         # every rank makes an id (only rank 0's is used): the call that opens librccl, so a rank without it is found BEFORE
@@ -1066,12 +1065,25 @@ class tomoengine(_EngineBase):
 
 
 class multigpuengine(tomoengine):
-    """Slab-sharded engine: construct it in every rank of a ``torchrun`` job with the GLOBAL sizes.
+    """Slab-sharded engine with the GLOBAL sizes.
 
-    Replaces the OpenMP-thread-per-GPU class of tomofusion/gpu/utils/multigpuengine.cpp (host-resident volume,
-    dynamic per-slice scheduling, TV on one GPU) by static device-resident slabs + RCCL."""
+    * In a plain process (no ``torch.distributed`` job) it spreads the slices over every visible GPU by itself, like the
+      reference's class does (tomofusion/gpu/utils/multigpuengine.cpp:140-193: an OpenMP team, one thread per GPU): one slab
+      engine per device, each driven by its own host thread, composed like the ranks of a job (``inprocess.py``).  ``devices=``
+      names the devices (default: all visible).
+    * Inside a ``torchrun`` job construct it in every rank: one slab per rank, RCCL over the process group.
 
-    def __init__(self, Nslice, Nray, pyAngles=None, group=None, force_collectives=False):
+    Replaces the host-resident volume, dynamic per-slice scheduling and single-GPU TV of the reference's class by static
+    device-resident slabs + RCCL."""
+
+    def __new__(cls, Nslice, Nray, pyAngles=None, group=None, force_collectives=False, devices=None):
+        from . import inprocess
+        if group is None and not force_collectives and inprocess.process_group_world() <= 1:
+            devs = list(devices) if devices is not None else inprocess.visible_devices()
+            return inprocess.InProcessMultiGPU(lambda comm, dev: tomoengine(Nslice, Nray, pyAngles, device=dev, comm=comm), devs)
+        return super().__new__(cls)
+
+    def __init__(self, Nslice, Nray, pyAngles=None, group=None, force_collectives=False, devices=None):
         super().__init__(Nslice, Nray, pyAngles, device=None, comm=SlabComm(group, force=force_collectives))
 
     def get_gpu_ids(self):

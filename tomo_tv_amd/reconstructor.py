@@ -18,15 +18,21 @@ def device_count():
 
 
 def determine_gpu_config(gpu_id=-1):
-    """tomofusion/__init__.py:21-34; 'multigpu' here means: running under torch.distributed with >1 rank."""
-    if len(device_count()) == 0:
+    """tomofusion/__init__.py:21-34: 'multigpu' whenever no device was named (``gpu_id < 0``) and there is more than one to use --
+    several visible GPUs in a plain process (the engine then spreads the slices over them by itself, one host thread per device:
+    ``inprocess.py``) or a ``torch.distributed`` job of several ranks (one slab per rank).  ``TOMO_SINGLE_GPU=1`` keeps a plain
+    process on one device."""
+    import os
+    n = len(device_count())
+    if n == 0:
         raise ValueError("An AMD GPU is needed for this package!")
-    try:
-        import torch.distributed as dist
-        if gpu_id < 0 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return "multigpu"
-    except ImportError:
-        pass
+    if gpu_id >= 0:
+        return "singleconfig"
+    from .inprocess import process_group_world
+    if process_group_world() > 1:
+        return "multigpu"
+    if n > 1 and os.environ.get("TOMO_SINGLE_GPU", "0") != "1":
+        return "multigpu"
     return "singleconfig"
 
 
