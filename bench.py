@@ -521,11 +521,80 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     return out
 
 
+def comm_rounds(t):
+    """RCCL rounds this rank's engine has enqueued so far (tomo_get_option "comm_rounds"); None off the GPU / without the library."""
+    try:
+        return t.get_option("comm_rounds")
+    except Exception:  # noqa: BLE001 -- the numpy slab double of the launcher test
+        return None
+
+
+def sharded_run_record(t, comm, rank, world, nglobal, n, nproj, ang, args, rounds0, rounds1):
+    """What a sharded run can prove about itself (collective: every rank calls it).  The native communicator's world and
+    this rank's place in it (tomo_comm_info), the device every rank sits on, the RCCL rounds a step enqueued (counted by
+    the library), and a PARITY CHECK: one ASD-POCS iteration from zero on the sharded engine against the same iteration
+    on ONE engine holding the whole volume (rank 0's device), compared on rank 0's first 64 slices (bound 2e-6, the
+    sharded == whole-slab bar of tests/test_gpu_sharded_tv.py)."""
+    import ctypes
+    from tomo_tv_amd._lib import check
+    rec = {"torch_world": world, "backend": args.backend}
+    w, r = ctypes.c_int(0), ctypes.c_int(0)
+    try:
+        check(t.be.L.tomo_comm_info(t.be.h, ctypes.byref(w), ctypes.byref(r)))
+        rec["native_world"], rec["native_rank_of_rank0"] = int(w.value), int(r.value)
+    except Exception as e:  # noqa: BLE001
+        rec["native_world"] = None
+        rec["native_error"] = str(e)
+    rec["native_collectives"] = bool(t._native())
+    rec["device_of_rank"] = [int(d) for d in t.get_gpu_ids()]
+    if rounds0 is not None and rounds1 is not None:
+        rec["rccl_rounds_per_step"] = (rounds1 - rounds0) / max(1, args.steps)
+    if args.no_validate:
+        rec["parity"] = None
+        return rec
+    # one iteration from zero, sharded
+    b_full = t._sino(0, dst=0)                                    # the tilt series assembled on rank 0 (gather)
+    t.restart_recon()
+    st = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
+    asd_pocs_step(t, st)
+    asd_pocs_flush(t, st)
+    take = min(64, t.nloc)
+    mine = t.get_volume_local()[:take]
+    if rank == 0:
+        from tomo_tv_amd.engine import tomoengine
+        one = tomoengine(nglobal, n, ang, device=t.gpuID)
+        for o in args.opt:
+            k, v = o.split("=")
+            one.set_option(k, int(v))
+        one.set_tilt_series(b_full)
+        one.initialize_SART("sequential")
+        st1 = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(one.Nslice_ * one.Nrow)}
+        asd_pocs_step(one, st1)
+        asd_pocs_flush(one, st1)
+        ref = one.get_volume_local()[:take]
+        den = float(np.linalg.norm(ref.astype(np.float64).ravel()))
+        err = float(np.linalg.norm((mine.astype(np.float64) - ref).ravel())) / (den if den > 0 else 1.0)
+        rec["parity"] = {"what": f"one ASD-POCS iteration from zero: sharded over {world} rank(s) vs one engine holding all {nglobal} slices, "
+                                 f"slices 0..{take - 1} of rank 0", "rel_l2": err, "bound": 2e-6, "ok": bool(err <= 2e-6)}
+        del one
+    comm.barrier()
+    return rec
+
+
 # ---- launcher: a plain `python bench.py --gpus N` starts its own N ranks ---------------------------------------------------
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT initialising one (the launcher must stay GPU-free: its children are the ranks)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:  # noqa: BLE001 -- no torch: let the ranks find out
+        return 1 << 30
 
 
 def spawn_ranks(n, argv):
@@ -580,6 +649,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="headline only: no secondary configs, no CPU baselines")
     ap.add_argument("--no-kernel-log", action="store_true", help="experiment: time the steps without the per-launch HIP events (no roofline)")
     ap.add_argument("--force-dist", action="store_true", help="use the slab-sharded engine + its communicator even with one rank")
+    ap.add_argument("--no-validate", action="store_true", help="sharded runs: skip the parity check against one whole-volume engine")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL); tests drive the launcher with gloo")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tomo_set_option), repeatable")
     ap.add_argument("--sub-slabs", type=int, default=1,
@@ -588,6 +658,11 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
+        if args.backend == "nccl":
+            ndev = visible_gpu_count()
+            if args.gpus > ndev:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible on this node "
+                                 "(one rank per GPU; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES restrict the list)")
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     # the one JSON line goes to the real stdout; everything else a library prints there (RCCL's version banner) is sent
     # to stderr
@@ -620,6 +695,8 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             from tomo_tv_amd.engine import multigpuengine
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU: {torch.cuda.device_count()} visible")
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             t = multigpuengine(nglobal, n, ang, force_collectives=args.force_dist)   # one rank: still issue the RCCL calls
@@ -682,12 +759,14 @@ def main():
     log = (KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}, LOG_STRIDE)
            if on_gpu and not args.no_kernel_log else None)
     sync()
+    rounds0 = comm_rounds(t)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         asd_pocs_step(t, st)
     dd, tv = asd_pocs_flush(t, st)          # the last step's scalars (inside the timed region)
     sync()
     el = time.perf_counter() - t0
+    rounds1 = comm_rounds(t)
     prof = log.read() if log else {}
     iso = None
     chains = sart_chains(t)          # launch chains per sweep of this rank's slab, as the engine runs them now
@@ -726,6 +805,10 @@ def main():
             allv = t.be.tensor([mine if r == rank else 0.0 for r in range(world)])
             comm.allreduce_sum(allv)
             per_rank = [float(v) for v in allv.tolist()]
+
+    comm_record = None
+    if comm is not None and on_gpu:
+        comm_record = sharded_run_record(t, comm, rank, world, nglobal, n, nproj, ang, args, rounds0, rounds1)
 
     if rank == 0:
         vox_total = float(nglobal) * n * n
@@ -790,6 +873,8 @@ def main():
                 "ms_per_step_with_every_voxel_stored": el_all * 1e3,
                 "note": "k_sart_tile (in place) skips the store of 256-byte pieces whose bits did not change; bit-identical results; the "
                         "gain depends on the data (zero background of the synthetic phantom); --opt sart_skip_same=0 times the other form"},
+            # N > 1 (and --force-dist): what the run itself can prove about its communication
+            "comm": comm_record,
             "roofline": dominant,
             "roofline_bp_angle": roofs.get(K_BP_NAME),
             "roofline_fp_angle": roofs.get(K_FP_NAME),

@@ -295,7 +295,8 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
 int tomo_set_option(tomo_engine *e, const char *name, int value);
 /* read back a switch, or a fact about the engine: "fp_strip", "fp_tile", "bp_tile", "fp_reuse", "sart_tile", and
  * "fp_strip_ready" (1: the sheared-strip tables were built at creation -- by the slab-size rule or TOMO_FP_STRIP=1 -- so
- * "fp_strip" = 1 takes effect), "fp_strip_slots" (accumulator slots per lane group the strip kernel runs with) */
+ * "fp_strip" = 1 takes effect), "fp_strip_slots" (accumulator slots per lane group the strip kernel runs with),
+ * "comm_rounds" (RCCL rounds -- one ncclGroup or one lone collective each -- this engine has enqueued since creation) */
 int tomo_get_option(tomo_engine *e, const char *name, int *value);
 /* ---- native communicator: the slab-sharded path over RCCL on the engine's own stream ---------------------------------------
  * Replaces, for a C / C++ host as for the Python one, the MPI calls of the reference's sharded CPU engine (mpi_ctvlib.cpp:400-422

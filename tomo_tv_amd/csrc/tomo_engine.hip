@@ -234,6 +234,7 @@ struct tomo_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool async_pending = false;
     struct CommRef *comm = nullptr;               // native RCCL communicator (tomo_comm_init / tomo_comm_share); see the comm section
+    int64_t comm_rounds = 0;                      // RCCL rounds (one ncclGroup or one lone collective) this engine has enqueued: bench.py's rccl_rounds_per_step
     float *comm_send_first = nullptr, *comm_send_last = nullptr, *comm_g_lo = nullptr, *comm_g_hi = nullptr;   // N*N planes
     float *comm_fgp = nullptr;                    // the engine's own planes of the fused FGP exchange when the host binds none
     double *comm_scal = nullptr;                  // TOMO_S_COUNT doubles: the all-reduced copy of the scalar buffer
@@ -2686,8 +2687,9 @@ static ncclResult_t comm_ring(tomo_engine *e, const float *first, size_t nfirst,
     return ncclSuccess;
 }
 // one group around `body` (which returns the first failing ncclResult_t of what it enqueued): GroupEnd is always reached
-static int comm_group(const char *what, const std::function<ncclResult_t()> &body)
+static int comm_group(tomo_engine *e, const char *what, const std::function<ncclResult_t()> &body)
 {
+    ++e->comm_rounds;
     NCCLCHK(g_rccl.GroupStart());
     const ncclResult_t r = body();
     const ncclResult_t rend = g_rccl.GroupEnd();
@@ -2753,7 +2755,7 @@ int tomo_comm_exchange_halo(tomo_engine *e, int field)
     NEED_COMM(e);
     int rc;
     if ((rc = tomo_halo_pack_both(e, field, e->comm_send_first, e->comm_send_last))) return rc;
-    return comm_group("halo exchange", [&] { return comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->halo_lo, e->halo_hi); });
+    return comm_group(e, "halo exchange", [&] { return comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->halo_lo, e->halo_hi); });
 }
 
 // all slots of the scalar buffer summed over the ranks into a COPY (the buffer itself keeps this slab's partial sums), read back:
@@ -2762,6 +2764,7 @@ static int comm_sum_scalars(tomo_engine *e)
 {
     { int rc = tomo_async_wait(e); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(e->comm_scal, e->d_scal, TOMO_S_COUNT * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    ++e->comm_rounds;
     NCCLCHK(g_rccl.AllReduce(e->comm_scal, e->comm_scal, TOMO_S_COUNT, ncclFloat64, ncclSum, e->comm->comm, e->stream));
     return TOMO_OK;
 }
@@ -2812,7 +2815,7 @@ int tomo_comm_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps, int track_vo
         if ((rc = tomo_tv_grad_planes(e, eps, g == 0, e->comm_send_first, e->comm_send_last))) return rc;
         // the global sum g^2 lands in comm_scal[GNORM]; TOMO_S_GNORM itself keeps this slab's partial sum, so a later
         // tomo_comm_read_scalars (which sums every slot over the ranks) returns the global norm once, not world times
-        rc = comm_group("tv_gd round", [&] {
+        rc = comm_group(e, "tv_gd round", [&] {
             ncclResult_t r = g_rccl.AllReduce(e->d_scal + TOMO_S_GNORM, e->comm_scal + TOMO_S_GNORM, 1, ncclFloat64, ncclSum, e->comm->comm, e->stream);
             ncclResult_t r2 = comm_ring(e, e->comm_send_first, (size_t)e->npix, e->comm_send_last, (size_t)e->npix, e->comm_g_lo, e->comm_g_hi);
             return r != ncclSuccess ? r : r2; });
@@ -2836,7 +2839,7 @@ int tomo_comm_fgp_exchange(tomo_engine *e)
 {
     NEED_COMM(e);
     if (!e->fgp_lo) return fail(TOMO_ERR_STATE, "slab-sharded fused FGP needs tomo_bind_fgp_halo");
-    return comm_group("fgp exchange", [&] { return comm_ring(e, e->fgp_send_first, 4 * (size_t)e->npix, e->fgp_send_last, (size_t)e->npix, e->fgp_lo, e->fgp_hi); });
+    return comm_group(e, "fgp exchange", [&] { return comm_ring(e, e->fgp_send_first, 4 * (size_t)e->npix, e->fgp_send_last, (size_t)e->npix, e->fgp_lo, e->fgp_hi); });
 }
 
 int tomo_get_option(tomo_engine *e, const char *name, int *value)
@@ -2849,6 +2852,7 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "bp_tile") == 0) { *value = e->bp_tile; return TOMO_OK; }
     if (std::strcmp(name, "fp_reuse") == 0) { *value = e->fp_reuse; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { *value = e->sart_tile; return TOMO_OK; }
+    if (std::strcmp(name, "comm_rounds") == 0) { *value = (int)std::min<int64_t>(e->comm_rounds, 0x7FFFFFFF); return TOMO_OK; }
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
 
