@@ -3,7 +3,7 @@
 // tile and slot by slot with the per-(tile, wave, slot) batch counts, K accumulators, a partial sum emitted at every flagged
 // batch -- in double precision on one slice, and compares with the plain CSR product.  Also prints the tables' statistics
 // (passes, partial sums per ray, padding, accumulator slots, volume pixels staged).
-// Usage: fp_strips_check N P max_abs_angle_deg [quiet]
+// Usage: fp_strips_check N P max_abs_angle_deg [nchunk] [quiet]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,14 +17,15 @@ int main(int argc, char **argv)
 {
     int N = argc > 1 ? std::atoi(argv[1]) : 50, P = argc > 2 ? std::atoi(argv[2]) : 9;
     double amax = argc > 3 ? std::atof(argv[3]) : 70.0;
-    const bool quiet = argc > 4;
+    const int nchunk = argc > 4 ? std::atoi(argv[4]) : 8;
+    const bool quiet = argc > 5;
     const int PIXB = 256;
     constexpr int W = Tables::FS_W, H = Tables::FS_H, WAVES = Tables::FS_WAVES, GROUPS = Tables::FS_GROUPS, NB = Tables::TILE_BATCH;
     std::vector<double> ang(P);
     for (int i = 0; i < P; ++i) ang[i] = (P > 1 ? -amax + 2 * amax * i / (P - 1) : 0.0) * M_PI / 180;
     Coo m; build_parallel_ray(N, P, ang.data(), m); sort_rows(m);
     Tables t; std::string why;
-    REQUIRE(build_fp_strips(m, N, P, PIXB, t, why), "build_fp_strips: %s", why.c_str());
+    REQUIRE(build_fp_strips(m, N, P, PIXB, nchunk, t, why), "build_fp_strips: %s", why.c_str());
     const int64_t nrows = (int64_t)N * P, npix = (int64_t)N * N, nnz = m.ptr[nrows];
     std::mt19937 rng(7); std::uniform_real_distribution<double> U(0.0, 1.0);
     std::vector<double> x(npix), g(nrows, 0.0);

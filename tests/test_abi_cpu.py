@@ -156,9 +156,10 @@ def test_strip_tables_replay_the_matrix(tmp_path):
     src = [os.path.join(root, "tests", "native", "fp_strips_check.cpp"), os.path.join(root, "tomo_tv_amd", "csrc", "sysmat.cpp")]
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "tomo_tv_amd", "csrc"), *src, "-lpthread", "-o", exe],
                    check=True)
-    for N, P, amax in [(50, 9, 89.0), (96, 17, 70.0), (33, 4, 45.0), (7, 3, 60.0), (64, 1, 0.0), (16, 5, 70.0), (129, 12, 80.0), (256, 60, 70.0)]:
-        r = subprocess.run([exe, str(N), str(P), str(amax)], capture_output=True, text=True)
-        assert r.returncode == 0 and r.stdout.rstrip().endswith("ok"), (N, P, amax, r.stdout + r.stderr)
+    for N, P, amax, nchunk in [(50, 9, 89.0, 1), (96, 17, 70.0, 2), (33, 4, 45.0, 8), (7, 3, 60.0, 1), (64, 1, 0.0, 4), (16, 5, 70.0, 1),
+                               (129, 12, 80.0, 3), (256, 60, 70.0, 4), (256, 60, 70.0, 16)]:
+        r = subprocess.run([exe, str(N), str(P), str(amax), str(nchunk), "q"], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.rstrip().endswith("ok"), (N, P, amax, nchunk, r.stdout + r.stderr)
 
 
 def test_facades_carry_every_method_of_the_reference_tables(golden):

@@ -69,3 +69,44 @@ def test_mpi_save_results_single_rank(tmp_path, monkeypatch):
     p = tio.mpi_save_results(("out", "rec"), _FakeTomo(vol, 5), True, meta={"alg": 1}, results={"dd": [1.0, 0.5]})
     t = _read(p)
     assert np.array_equal(t["Reconstruction/recon"], vol) and np.allclose(t["results/dd"], [1.0, 0.5])
+
+
+def _write_plain_tiff(path, stack, bo="<"):
+    """A minimal multi-page uncompressed TIFF (one strip per page), the form the built-in reader of tomo_tv_amd/io.py handles."""
+    import struct
+    stack = np.asarray(stack)
+    kind = {"u": 1, "i": 2, "f": 3}[stack.dtype.kind]
+    bits = stack.dtype.itemsize * 8
+    out = bytearray(b"II" if bo == "<" else b"MM") + struct.pack(bo + "HI", 42, 8)
+    for k, page in enumerate(stack):
+        data = page.astype(stack.dtype.newbyteorder(bo)).tobytes()
+        ifd = len(out)
+        tags = [(256, 4, page.shape[1]), (257, 4, page.shape[0]), (258, 3, bits), (259, 3, 1), (262, 3, 1),
+                (273, 4, ifd + 2 + 12 * 10 + 4), (277, 3, 1), (278, 4, page.shape[0]), (279, 4, len(data)), (339, 3, kind)]
+        out += struct.pack(bo + "H", len(tags))
+        for tag, typ, val in tags:
+            out += struct.pack(bo + "HHI", tag, typ, 1) + (struct.pack(bo + "I", val) if typ == 4 else struct.pack(bo + "HH", val, 0))
+        nxt = ifd + 2 + 12 * len(tags) + 4 + len(data) if k + 1 < len(stack) else 0
+        out += struct.pack(bo + "I", nxt) + data
+    open(path, "wb").write(bytes(out))
+
+
+@pytest.mark.parametrize("dtype,bo", [(np.float32, "<"), (np.uint16, ">"), (np.uint8, "<")])
+def test_load_data_reads_tiff_tilt_series(tmp_path, monkeypatch, dtype, bo):
+    """pytvlib.py:57-79: a .tif / .tiff stack loads as (z, y, x) and is swapped to (x, y, z).  Checked through whatever reader
+    the image offers AND through the built-in reader of uncompressed stacks (scikit-image, tifffile and Pillow hidden)."""
+    from tomo_tv_amd import io as tio
+    rng = np.random.default_rng(3)
+    stack = (rng.random((5, 7, 9)) * 200).astype(dtype)                  # (angles, y, x)
+    d = tmp_path / "Tilt_Series"
+    d.mkdir()
+    for ext in (".tif", ".tiff"):
+        _write_plain_tiff(str(d / f"256_phantom_tiltser{ext}"), stack, bo)
+        name, ts = tio.load_data("256", f"phantom_tiltser{ext}", dir=str(d) + "/")
+        assert name == "phantom" and ts.dtype == np.float32 and ts.shape == (9, 7, 5)
+        assert np.array_equal(ts, np.swapaxes(stack.astype(np.float32), 0, 2))
+    plain = tio._read_plain_tiff(str(d / "256_phantom_tiltser.tif"))
+    assert plain.shape == stack.shape and np.array_equal(plain.astype(dtype), stack)
+    with pytest.raises(ValueError):
+        open(str(d / "bad.tif"), "wb").write(b"not a tiff file at all")
+        tio._read_plain_tiff(str(d / "bad.tif"))

@@ -714,7 +714,7 @@ template <typename F> void fs_parallel(size_t n, unsigned nth, F f)
 }
 }  // namespace
 
-bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std::string &why)
+bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Tables &t, std::string &why)
 {
     constexpr int W = Tables::FS_W, H = Tables::FS_H, WAVES = Tables::FS_WAVES, GROUPS = Tables::FS_GROUPS, KMAX = Tables::FS_KMAX;
     constexpr int NB = Tables::TILE_BATCH;
@@ -776,6 +776,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
     std::vector<FsWork> work;
     std::vector<int32_t> shift;
     const int OFF = N;                                     // keeps v - shift + OFF in [0, 3N) (|shift| <= N)
+    int nsegs = 1, seglen = 1 << 30;                       // segments per strip, tiles per segment
     for (int attempt = 0; attempt < 6; ++attempt) {
         form_passes(dt_max, amax);
         const int npass = (int)passes.size();
@@ -789,7 +790,20 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
                 shift[(size_t)ps * N + u] = (int32_t)std::floor(sh + 0.5);
             }
         }
-        // ---- 3. every ray: entries sorted by (strip, march coordinate, cross coordinate), cut into strips
+        // A strip is one long sequential march, and a launch wants several rounds of workgroups (512 are resident): strips are cut
+        // along the march into `nsegs` segments of `seglen` tiles, each an item of its own, so that items x chunks of 64 slices
+        // reaches ~6 rounds.  A ray pays one more partial sum per cut it crosses.
+        {
+            const int tiles_per_strip = (N + H - 1) / H;
+            const double total_tiles = (double)npass * 1.3 * ((double)N / W) * tiles_per_strip;
+            const double items_wanted = 3072.0 / std::max(1, nchunk);
+            int len = (int)std::floor(total_tiles / std::max(1.0, items_wanted));
+            if (const char *sl = std::getenv("TOMO_FS_SEGLEN")) { int v = std::atoi(sl); if (v > 0) len = v; }
+            len = std::max(4, std::min(len, tiles_per_strip));
+            nsegs = (tiles_per_strip + len - 1) / len;
+            seglen = (tiles_per_strip + nsegs - 1) / nsegs;
+        }
+        // ---- 3. every ray: entries sorted by (strip segment, march coordinate, cross coordinate), cut into strip segments
         rsegs.assign(nrows, {});
         fs_parallel((size_t)nrows, hw, [&](size_t r) {
             const int i = (int)(r / N), ps = pass_of[i], o = passes[ps].orient;
@@ -804,7 +818,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
                 int y = (int)(p / (uint32_t)N), z = (int)(p % (uint32_t)N);
                 int u = o ? z : y, v = o ? y : z;
                 int vs = v - sh[u] + OFF;
-                key[k] = {vs / W, (uint16_t)u, (uint8_t)(vs % W), m.val[b + k]};
+                key[k] = {(vs / W) * nsegs + (u / H) / seglen, (uint16_t)u, (uint8_t)(vs % W), m.val[b + k]};
             }
             std::sort(key.begin(), key.end(), [](const K &a, const K &c) { return a.strip != c.strip ? a.strip < c.strip : a.u != c.u ? a.u < c.u : a.lv < c.lv; });
             auto &rs = rsegs[r];
@@ -815,7 +829,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
             }
         });
         // ---- 4. bucket the ray segments by (pass, strip)
-        const int nstrip_max = (3 * N + W - 1) / W + 2;
+        const int nstrip_max = ((3 * N + W - 1) / W + 2) * nsegs;     // (strip, segment) keys
         std::vector<uint32_t> iptr((size_t)npass * nstrip_max + 1, 0);
         for (int64_t r = 0; r < nrows; ++r) { const int ps = pass_of[r / N]; for (auto &sg : rsegs[r]) iptr[(size_t)ps * nstrip_max + sg.strip + 1]++; }
         for (size_t k = 0; k + 1 < iptr.size(); ++k) iptr[k + 1] += iptr[k];
@@ -936,7 +950,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std
     for (size_t o = 0; o < nitems; ++o) {
         const FsWork &wk = work[order[o]];
         Tables::FsItem &itx = t.fs_item[o];
-        itx.pass = wk.pass; itx.v0 = wk.strip * W - OFF; itx.tile0 = wk.tile0; itx.ntiles = wk.ntiles;
+        itx.pass = wk.pass; itx.v0 = (wk.strip / nsegs) * W - OFF; itx.tile0 = wk.tile0; itx.ntiles = wk.ntiles;
         itx.cnt0 = (uint32_t)ncnt; itx.g0 = (uint32_t)(o * GROUPS); itx.work = crit(wk); itx.pad = 0;
         ncnt += (uint64_t)wk.ntiles * WAVES;
         kused = std::max<int>(kused, (int)wk.kused);

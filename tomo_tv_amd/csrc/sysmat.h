@@ -125,6 +125,6 @@ void build_segments(int N, int P, int seg_len, Tables &t);
 void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t);
 void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, int pixel_bytes, Tables &t);
 void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t);
-bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, Tables &t, std::string &why);
+bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Tables &t, std::string &why);   // nchunk: 64-slice chunks of the slab
 
 }  // namespace tomo

@@ -918,7 +918,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             // over 512 resident workgroups).  TOMO_FP_STRIP = 0 / 1 overrides the rule (tests build the tables at small sizes).
             bool want = (int64_t)e->n * (e->sxc / 64) >= 4000;
             if (const char *env = std::getenv("TOMO_FP_STRIP")) want = std::atoi(env) != 0;
-            e->fs_ok = want && build_fp_strips(m, e->n, e->np, 256, t, why);
+            e->fs_ok = want && build_fp_strips(m, e->n, e->np, 256, e->sxc / 64, t, why);
             if (e->fs_ok) {
                 e->fs_nitems = (int)t.fs_item.size(); e->fs_kused = t.fs_kused; e->fs_nseg = t.fs_nseg;
                 std::vector<uint2> sent(t.fs_off.size());

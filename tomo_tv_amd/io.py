@@ -1,7 +1,8 @@
 """Data in / results out: the file helpers either side of the reconstruction path (tomofusion/pytvlib.py:57-162).
 
 Same function names, argument meaning and on-disk naming as the reference: tilt series under ``Tilt_Series/`` as
-``<vol_size>_<file_name>`` (``.npy``; ``.tif/.tiff`` when scikit-image is importable; ``.h5`` with datasets
+``<vol_size>_<file_name>`` (``.npy``; ``.tif/.tiff`` through scikit-image, tifffile or Pillow when importable, else a built-in
+reader of uncompressed stacks; ``.h5`` with datasets
 ``tiltSeries`` / ``tiltAngles`` when h5py is importable), results under ``results/<dir>/<name>.h5`` with the groups
 ``parameters`` (attributes), ``results`` (float32 datasets) and ``Reconstruction/recon`` (+ ``Nslice, Nray, Nproj``
 attributes).  Where h5py is absent (this image) the same tree is written to ``<name>.npz`` with ``/``-joined keys
@@ -24,16 +25,64 @@ TILT_DIR = "Tilt_Series/"
 RESULT_DIR = "results/"
 
 
+def _read_tiff_stack(path):
+    """A (pages, rows, columns) array from a TIFF stack -- what ``skimage.io.imread`` returns for the reference's tilt series
+    (pytvlib.py:64-71).  scikit-image if present, else tifffile, else Pillow, else a reader for plain uncompressed strips (the form
+    microscope exports and numpy-side tools write): 8 / 16 / 32-bit unsigned, signed or IEEE samples, either byte order."""
+    if _skio is not None:
+        return np.asarray(_skio.imread(path))
+    try:
+        import tifffile
+        return np.asarray(tifffile.imread(path))
+    except ImportError:
+        pass
+    try:
+        from PIL import Image, ImageSequence
+        with Image.open(path) as im:
+            return np.stack([np.array(page) for page in ImageSequence.Iterator(im)])
+    except ImportError:
+        pass
+    return _read_plain_tiff(path)
+
+
+def _read_plain_tiff(path):
+    import struct
+    raw = open(path, "rb").read()
+    bo = {b"II": "<", b"MM": ">"}.get(raw[:2])
+    if bo is None or struct.unpack(bo + "H", raw[2:4])[0] != 42:
+        raise ValueError(f"{path}: not a (classic) TIFF file")
+    size = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 7: 1, 8: 2, 9: 4, 10: 8, 11: 4, 12: 8, 16: 8}
+    fmt = {1: "B", 3: "H", 4: "I", 6: "b", 8: "h", 9: "i", 16: "Q"}
+    pages, off = [], struct.unpack(bo + "I", raw[4:8])[0]
+    while off:
+        n = struct.unpack(bo + "H", raw[off:off + 2])[0]
+        tags = {}
+        for k in range(n):
+            tag, typ, cnt = struct.unpack(bo + "HHI", raw[off + 2 + 12 * k:off + 10 + 12 * k])
+            nbytes = size.get(typ, 1) * cnt
+            pos = off + 10 + 12 * k if nbytes <= 4 else struct.unpack(bo + "I", raw[off + 10 + 12 * k:off + 14 + 12 * k])[0]
+            if typ in fmt:
+                tags[tag] = struct.unpack(bo + fmt[typ] * cnt, raw[pos:pos + nbytes])
+        w, h = tags[256][0], tags[257][0]
+        bits, comp, spp = tags.get(258, (1,))[0], tags.get(259, (1,))[0], tags.get(277, (1,))[0]
+        kind = tags.get(339, (1,))[0]                        # SampleFormat: 1 unsigned, 2 signed, 3 IEEE
+        if comp != 1 or spp != 1 or bits not in (8, 16, 32, 64):
+            raise ValueError(f"{path}: only uncompressed single-sample TIFF pages are read without scikit-image / tifffile / Pillow")
+        dt = np.dtype({1: "u", 2: "i", 3: "f"}[kind] + str(bits // 8)).newbyteorder(bo)
+        data = b"".join(raw[o:o + c] for o, c in zip(tags[273], tags[279]))
+        pages.append(np.frombuffer(data, dtype=dt, count=w * h).reshape(h, w))
+        off = struct.unpack(bo + "I", raw[off + 2 + 12 * n:off + 6 + 12 * n])[0]
+    return np.stack(pages)
+
+
 def load_data(vol_size, file_name, dir=TILT_DIR):
     """pytvlib.py:57-79.  Returns (name without the ``_tiltser<ext>`` suffix, tilt series (x, y, angles))."""
     full_name = f"{vol_size}_{file_name}" if vol_size != "" else file_name
     path = os.path.join(dir, full_name)
     for ftype in (".tiff", ".tif"):
         if full_name.endswith(ftype):
-            if _skio is None:
-                raise ImportError("reading TIFF tilt series needs scikit-image (not in this image); convert to .npy")
-            # sk-image loads (z, y, x): swap back to (x, y, z) like the reference
-            ts = np.swapaxes(np.array(_skio.imread(path), dtype=np.float32), 0, 2)
+            # the stack loads as (z, y, x): swap back to (x, y, z) like the reference
+            ts = np.swapaxes(np.array(_read_tiff_stack(path), dtype=np.float32), 0, 2)
             return file_name.replace("_tiltser" + ftype, ""), ts
     if full_name.endswith(".npy"):
         return file_name.replace("_tiltser.npy", ""), np.load(path)
