@@ -55,9 +55,9 @@ int main(int argc, char **argv)
                         bool last = false;
                         for (int j = 0; j < NB; ++j) {
                             const size_t at = b * NB + j;
-                            uint32_t off = t.fs_off[at]; float w = t.fs_w[at];
+                            uint32_t off = Tables::fs_off_of(t.fs_ent[at]); float w = Tables::fs_w_of(t.fs_ent[at]);
                             if (j == 0) last = off >> 31; else REQUIRE((off >> 31) == (uint32_t)last, "flag differs inside batch %zu", b);
-                            if (half && j >= NB / 2) { REQUIRE(off == t.fs_off[at - NB / 2] && w == t.fs_w[at - NB / 2], "half batch %zu is not stored twice", b); continue; }
+                            if (half && j >= NB / 2) { REQUIRE(t.fs_ent[at] == t.fs_ent[at - NB / 2], "half batch %zu is not stored twice", b); continue; }
                             uint32_t lp = (off & 0x7FFFFFFFu) / PIXB;
                             REQUIRE((off & 0x7FFFFFFFu) % PIXB == 0 && lp <= (uint32_t)(W * H), "bad offset");
                             if (lp == (uint32_t)(W * H)) { REQUIRE(w == 0.f, "padding entry with weight"); continue; }

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <chrono>
+#include <cstdio>
 
 namespace tomo {
 
@@ -720,6 +722,10 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
     constexpr int NB = Tables::TILE_BATCH;
     static_assert(GROUPS == WAVES * 4 && KMAX <= 16, "slot layout");
     t.fs_ok = false;
+    const bool timing = std::getenv("TOMO_FS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto lap = [&](const char *what) { if (timing) { double x = now(); std::fprintf(stderr, "build_fp_strips: %-28s %.3f s\n", what, x - t_last); t_last = x; } };
     const int64_t nrows = (int64_t)N * P;
     const int64_t nnz = m.ptr[nrows];
     if (N < 1 || P < 1 || nnz <= 0 || N > 32768) { why = "empty geometry"; return false; }
@@ -828,6 +834,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
                 rs.back().cnt++; rs.back().t1 = (uint32_t)key[k].u / H;
             }
         });
+        lap("rays sorted into strips");
         // ---- 4. bucket the ray segments by (pass, strip)
         const int nstrip_max = ((3 * N + W - 1) / W + 2) * nsegs;     // (strip, segment) keys
         std::vector<uint32_t> iptr((size_t)npass * nstrip_max + 1, 0);
@@ -845,6 +852,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
         std::vector<size_t> bucket;                        // non-empty (pass, strip) buckets = items
         for (size_t k = 0; k + 1 < iptr.size(); ++k) if (iptr[k + 1] > iptr[k]) bucket.push_back(k);
         work.assign(bucket.size(), {});
+        lap("segments bucketed");
         // ---- 5. per item: accumulator slots and batch counts (sizing phase)
         std::vector<uint8_t> over(bucket.size(), 0);
         fs_parallel(bucket.size(), hw, [&](size_t it) {
@@ -929,6 +937,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
                 wk.wave_batches[w] += (h + 1) >> 1; wk.wave_halves[w] += h;
             }
         });
+        lap("slots and counts");
         bool any_over = false;
         for (uint8_t o : over) any_over |= o != 0;
         if (!any_over) break;
@@ -965,11 +974,13 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
     t.fs_nseg = (uint32_t)nseg;
     t.fs_cnt.assign((size_t)ncnt * 16 + 16, 0);
     const uint32_t zero_off = (uint32_t)(W * H) * (uint32_t)pixel_bytes;
-    t.fs_off.assign((size_t)(nbatch + 16) * NB, zero_off);    // + the kernel's prefetch distance past the last stream
-    t.fs_w.assign((size_t)(nbatch + 16) * NB, 0.f);
+    t.fs_ent_n = (size_t)(nbatch + 16) * NB;                  // + the kernel's prefetch distance past the last stream
+    t.fs_ent.reset(new uint64_t[t.fs_ent_n]);                 // uninitialised: every stream slot is written by the emission below
+    for (size_t k = (size_t)nbatch * NB; k < t.fs_ent_n; ++k) t.fs_ent[k] = Tables::fs_pack(zero_off, 0.f);
     t.fs_rseg_ptr.assign(nrows + 1, 0);
     for (int64_t r = 0; r < nrows; ++r) t.fs_rseg_ptr[r + 1] = t.fs_rseg_ptr[r] + (uint32_t)rsegs[r].size();
     t.fs_rseg_idx.assign(nseg ? nseg : 1, 0);
+    lap("layout + allocation");
     // ---- 7. emission (threads over items)
     std::vector<uint64_t> real_of(nitems, 0);
     fs_parallel(nitems, hw, [&](size_t o) {
@@ -1012,8 +1023,8 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
                             const uint32_t e = un < nfull ? un * NB + j : nfull * NB + j % (NB / 2);
                             if (e < c) {
                                 const uint32_t lu = (uint32_t)eu[base + e] % H, lv = elv[base + e];
-                                t.fs_off[oe] = ((lu * W + lv) * (uint32_t)pixel_bytes) | flag; t.fs_w[oe] = ew[base + e];
-                            } else { t.fs_off[oe] = zero_off | flag; t.fs_w[oe] = 0.f; }
+                                t.fs_ent[oe] = Tables::fs_pack(((lu * W + lv) * (uint32_t)pixel_bytes) | flag, ew[base + e]);
+                            } else t.fs_ent[oe] = Tables::fs_pack(zero_off | flag, 0.f);
                         }
                     }
                     real_of[o] += c;
@@ -1022,6 +1033,7 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
             }
         }
     });
+    lap("emission");
     t.fs_npass = npass;
     t.fs_orient.assign(npass, 0);
     for (int ps = 0; ps < npass; ++ps) t.fs_orient[ps] = passes[ps].orient;

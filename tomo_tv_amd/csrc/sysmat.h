@@ -1,6 +1,8 @@
 // sysmat.h -- host-side system matrix + derived tables (see sysmat.cpp).
 #pragma once
 #include <cstdint>
+#include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -110,8 +112,13 @@ struct Tables {
     std::vector<FsItem> fs_item;
     std::vector<uint8_t> fs_cnt;
     std::vector<uint32_t> fs_gstart, fs_gseg0;
-    std::vector<uint32_t> fs_off;
-    std::vector<float> fs_w;
+    // entries as the kernel loads them: low word = LDS byte offset | flush flag << 31, high word = the weight's bits.  Allocated
+    // WITHOUT initialisation and filled by the emission threads (1.6 GB at 1024^2 x 120: a zero fill alone cost seconds)
+    std::unique_ptr<uint64_t[]> fs_ent;
+    size_t fs_ent_n = 0;
+    static uint64_t fs_pack(uint32_t off, float w) { uint32_t b; std::memcpy(&b, &w, 4); return (uint64_t)off | ((uint64_t)b << 32); }
+    static uint32_t fs_off_of(uint64_t e) { return (uint32_t)e; }
+    static float fs_w_of(uint64_t e) { uint32_t b = (uint32_t)(e >> 32); float w; std::memcpy(&w, &b, 4); return w; }
     std::vector<uint32_t> fs_rseg_ptr, fs_rseg_idx;
 };
 

@@ -912,24 +912,24 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             std::string why;
             static_assert(Tables::FS_W == FS_W && Tables::FS_H == FS_H && Tables::FS_WAVES == FS_WAVES && Tables::FS_GROUPS == FS_GROUPS, "strip shape");
             static_assert(sizeof(Tables::FsItem) == sizeof(FsItemD), "strip item layout");
-            // Measured (round 4, MI355X, FP alone, strips against tiles): 1024^3 x 120 12.1 / 14.6 ms, 1024 x 512^2 x 90 2.55 / 2.82,
-            // 512^3 x 90 1.28 / 1.37 -- and 256 x 512^2 0.76 / 0.70, 128 x 1024^2 x 120 1.89 / 1.68, 256^3 x 60 0.18 / 0.12: a strip is one
-            // long sequential march, so the form pays once there are several rounds of workgroups (~0.4 N strips x chunks of 64 slices
-            // over 512 resident workgroups).  TOMO_FP_STRIP = 0 / 1 overrides the rule (tests build the tables at small sizes).
-            bool want = (int64_t)e->n * (e->sxc / 64) >= 4000;
+            // Measured (round 4, MI355X, FP alone, strips against tiles, strips cut into segments for ~6 rounds of workgroups):
+            // 1024 x 512^2 x 90 2.53 / 2.87 ms, 512^3 x 90 1.32 / 1.44, 256 x 512^2 0.70 / 0.73, 128 x 1024^2 x 120 1.71 / 1.83, 1024^3 x 120
+            // 12.1 / 14.6 -- and 64 x 512^2 0.211 / 0.208, 256^3 x 60 0.143 / 0.123: a strip is a sequential march over at least four
+            // tiles, so small images and one-chunk slabs do not fill the chip with them.  TOMO_FP_STRIP = 0 / 1 overrides the rule
+            // (tests build the tables at small sizes).
+            bool want = e->n >= 384 && (int64_t)e->n * (e->sxc / 64) >= 1024;
             if (const char *env = std::getenv("TOMO_FP_STRIP")) want = std::atoi(env) != 0;
             e->fs_ok = want && build_fp_strips(m, e->n, e->np, 256, e->sxc / 64, t, why);
             if (e->fs_ok) {
                 e->fs_nitems = (int)t.fs_item.size(); e->fs_kused = t.fs_kused; e->fs_nseg = t.fs_nseg;
-                std::vector<uint2> sent(t.fs_off.size());
-                for (size_t k = 0; k < sent.size(); ++k) { uint32_t bits; std::memcpy(&bits, &t.fs_w[k], 4); sent[k] = make_uint2(t.fs_off[k], bits); }
+                static_assert(sizeof(uint2) == sizeof(uint64_t), "entry layout");
                 if ((rc = dev_alloc((void **)&e->d_fs_items, t.fs_item.size() * sizeof(FsItemD), false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_orient, t.fs_orient.size() * 4, false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_shift, t.fs_shift.size() * 4, false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_cnt, t.fs_cnt.size(), false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_gstart, t.fs_gstart.size() * 4, false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_gseg0, t.fs_gseg0.size() * 4, false, e->stream))) return rc;
-                if ((rc = dev_alloc((void **)&e->d_fs_ent, sent.size() * sizeof(uint2), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_ent, t.fs_ent_n * sizeof(uint2), false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_rsptr, t.fs_rseg_ptr.size() * 4, false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_rsidx, t.fs_rseg_idx.size() * 4, false, e->stream))) return rc;
                 HIPCHK(hipMemcpy(e->d_fs_items, t.fs_item.data(), t.fs_item.size() * sizeof(FsItemD), hipMemcpyHostToDevice));
@@ -938,11 +938,11 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
                 HIPCHK(hipMemcpy(e->d_fs_cnt, t.fs_cnt.data(), t.fs_cnt.size(), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(e->d_fs_gstart, t.fs_gstart.data(), t.fs_gstart.size() * 4, hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(e->d_fs_gseg0, t.fs_gseg0.data(), t.fs_gseg0.size() * 4, hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(e->d_fs_ent, sent.data(), sent.size() * sizeof(uint2), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fs_ent, t.fs_ent.get(), t.fs_ent_n * sizeof(uint2), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(e->d_fs_rsptr, t.fs_rseg_ptr.data(), t.fs_rseg_ptr.size() * 4, hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(e->d_fs_rsidx, t.fs_rseg_idx.data(), t.fs_rseg_idx.size() * 4, hipMemcpyHostToDevice));
             }
-            release(t.fs_off); release(t.fs_w); release(t.fs_cnt); release(t.fs_rseg_idx); release(t.fs_rseg_ptr); release(t.fs_gstart); release(t.fs_gseg0);
+            t.fs_ent.reset(); t.fs_ent_n = 0; release(t.fs_cnt); release(t.fs_rseg_idx); release(t.fs_rseg_ptr); release(t.fs_gstart); release(t.fs_gseg0);
         }
         build_sart_tiles(m, e->n, e->np, ST_TY, ST_TZ, ST_MAXR, 256, t);
         static_assert(Tables::ST_MAXSEG == ST_MAXSEG, "segment slots per tile");
