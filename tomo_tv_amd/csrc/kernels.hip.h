@@ -469,6 +469,8 @@ struct FsItemD { int pass, v0; uint32_t tile0, ntiles, cnt0, g0, work, pad; };
 // the NEXT batch is read from the ring (ds_read_b64, issued by inline asm: the waitcnt pass would otherwise drain the DMAs in
 // flight before every LDS read it cannot tell apart from their destination -- the ring is an LDS object of its own for the same
 // reason, so the tile reads are not held back) while the current batch's pixel images are read.
+// (Measured and not kept: the weight's lane rotation folded into the multiply-add -- four v_fmac_f32 with a DPP source per entry
+// instead of one DPP move + two packed FMAs -- 1.33 against 1.27 ms per projection at 512^3 x 90.)
 template <int K>
 __global__ __launch_bounds__(FS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, const int *__restrict__ orient,
