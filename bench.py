@@ -286,7 +286,7 @@ def attach_traffic(roofs, shape):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, separate runs, FETCH_SIZE x2), null if the
     profile is absent or was taken at another shape.  Measured outside this run by construction (the counters need the
     profiler); the file names the command."""
-    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         try:
             doc = json.load(open(path))
@@ -417,11 +417,19 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     nnz = nnz_per_pixel_angle * n * n * P
     avg = lambda k: pr[k][1] / max(pr[k][0], 1)  # noqa: E731
     fp_ms = avg("k_fp_tile") + avg("k_fp_tile_reduce")
+    # which form projected: sheared strips (k_fp_strip; large slabs, round 4) or image tiles (k_fp_tile) -- both log under the same slot
+    strip = bool(t.get_option("fp_strip_ready") and t.get_option("fp_strip"))
+    fp_kernel = "k_fp_strip" if strip else "k_fp_tile"
+    # the other form, for the record (same engine, one option)
+    t.set_option("fp_tile", 1) if strip else None
+    ms_tile_form = _time_steps(t, lambda: (t.SIRT(1), t.data_distance()), 5) if strip else None
+    t.set_option("fp_strip", 1) if strip else None
     out["config3_sirt_512cube_x90tilts"] = {
         "ms_per_step": ms, "iters_per_s": 1e3 / ms, "ms_per_step_every_projection_recomputed": ms_noreuse,
-        # all-angle FP = k_fp_tile + k_fp_tile_reduce (4V + 4S algorithmic); one entry = one FMA and one 4-byte LDS read per slice
-        "roofline_fp_all": dict(roof("k_fp_tile+k_fp_tile_reduce", 1, fp_ms, 4 * V + 4 * S, flops=2 * nnz * nx, lds_bytes=4 * nnz * nx),
-                                k_fp_tile_avg_ms=avg("k_fp_tile"), k_fp_tile_reduce_avg_ms=avg("k_fp_tile_reduce")),
+        "forward_projector": fp_kernel, "ms_per_step_with_the_tile_forward_projector": ms_tile_form,
+        # all-angle FP = projection kernel + k_fp_tile_reduce (4V + 4S algorithmic); one entry = one FMA and one 4-byte LDS read per slice
+        "roofline_fp_all": dict(roof(fp_kernel + "+k_fp_tile_reduce", 1, fp_ms, 4 * V + 4 * S, flops=2 * nnz * nx, lds_bytes=4 * nnz * nx),
+                                **{fp_kernel + "_avg_ms": avg("k_fp_tile"), "k_fp_tile_reduce_avg_ms": avg("k_fp_tile_reduce")}),
         # all-angle BP (8V + 4S): two FMAs and two LDS row reads per pixel, angle and slice
         "roofline_bp_all": roof("k_bp_tile", pr["k_bp_tile"][0], pr["k_bp_tile"][1], 8 * V + 4 * S, flops=4.0 * n * n * P * nx,
                                 lds_bytes=8.0 * n * n * P * nx, busy_ms=pr["k_bp_tile"][2])}
