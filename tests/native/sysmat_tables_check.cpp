@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include "sysmat.h"
 using namespace tomo;
@@ -168,6 +169,29 @@ int main(int argc, char **argv)
         for (uint32_t q = 0; q < t.st_max_ids; ++q) REQUIRE(wr[q] != 1, "partial %u of angle %d belongs to no row", q, i);
     }
     REQUIRE(worst_st < 1e-9 && worst_stbp == 0.0, "SART tile mismatch fp %g bp %g", worst_st, worst_stbp);
+    // ---- build_tables: the cell table and the three column sums against the plain row loop (ctvlib.cpp:194-202 order), BIT FOR BIT:
+    // the builder spreads the work over threads (cells per angle, sums per pixel range) and must not change a rounding
+    {
+        std::vector<Cell> cell((size_t)P * npix, Cell{0u, 0.f, 0u, 0.f});
+        std::vector<float> cs(npix, 0.f), a1(npix, 0.f), am(npix, 0.f);
+        for (int64_t r = 0; r < nrows; ++r) {
+            const int i = (int)(r / N);
+            const uint32_t j = (uint32_t)(r % N);
+            for (int64_t k = m.ptr[r]; k < m.ptr[r + 1]; ++k) {
+                const uint32_t p = m.col[k];
+                const float w = m.val[k];
+                cs[p] += w; a1[p] += w * t.rowsum[r]; am[p] += (w * t.rowinner[r]) * t.rowsum[r];
+                if (w == 0.f) continue;
+                Cell &c = cell[(size_t)i * npix + p];
+                if (c.w0 == 0.f) { c.r0 = j; c.w0 = w; } else { c.r1 = j; c.w1 = w; }
+            }
+        }
+        float L = 0.f, Lm = 0.f;
+        for (int64_t p = 0; p < npix; ++p) { L = std::max(L, a1[p]); Lm = std::max(Lm, am[p]); }
+        REQUIRE(std::memcmp(cs.data(), t.colsum_all.data(), npix * sizeof(float)) == 0, "column sums differ from the row loop");
+        REQUIRE(L == t.lipschitz && Lm == t.lipschitz_cimmino, "Lipschitz constants differ from the row loop: %.9g / %.9g vs %.9g / %.9g", t.lipschitz, t.lipschitz_cimmino, L, Lm);
+        REQUIRE(std::memcmp(cell.data(), t.cell.data(), cell.size() * sizeof(Cell)) == 0, "cell table differs from the row loop");
+    }
     std::printf("OK N=%d P=%d nnz=%ld nseg=%u padded=%.3f stream_imbalance=%.3f max_window=%u\n", N, P, (long)nnz, t.tile_nseg,
                 (double)t.tile_off.size() / std::max<int64_t>(1, nnz), imb, maxwin);
     return 0;

@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(256) void k_tv_value(const float *__restrict__ x, H
                                                    float eps, int n, int nx, int sx)
 {
     int lane = threadIdx.x & 63;
-    int nchunk = sx >> 6;
+    int nchunk = (nx + 63) >> 6   /* computed width, not the row pitch: the pitch may carry padding */;
     int64_t items = (int64_t)n * n * nchunk;
     int64_t wstride = (int64_t)gridDim.x * 4;
     double acc = 0.0;
@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_tv_grad(const float *__restrict__ x, Ha
                                                   double *__restrict__ part, float eps, int n, int nx, int sx)
 {
     int lane = threadIdx.x & 63;
-    int nchunk = sx >> 6;
+    int nchunk = (nx + 63) >> 6   /* computed width, not the row pitch: the pitch may carry padding */;
     int64_t items = (int64_t)n * n * nchunk;
     int64_t wstride = (int64_t)gridDim.x * 4;
     double acc = 0.0;
@@ -2210,7 +2210,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x
                                                       int yseg, double *__restrict__ part_tv, TvUpd up = TvUpd{})
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
+    const int nzb = (n + TZ - 1) / TZ, nchunk = (nx + 63) >> 6   /* computed width, not the row pitch: the pitch may carry padding */, nys = (n + yseg - 1) / yseg;
     double acc = 0.0, tvacc = 0.0;
     float nrm_ = 1.f;
     if (MODE == TVM_UPDATE) nrm_ = tv_step_len(up.dPOCS, up.gnorm2);      // the step length dPOCS / ||g||
@@ -2407,7 +2407,7 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
     static_assert(MODE == TVM_NORM || MODE == TVM_UPDATE || MODE == TVM_VALUE, "modes without a stored gradient");
     static_assert(MODE != TVM_VALUE || WITH_TV, "the value mode sums the TV integrand");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nzb = (n + TZ - 1) / TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
+    const int nzb = (n + TZ - 1) / TZ, nchunk = (nx + 63) >> 6   /* computed width, not the row pitch: the pitch may carry padding */, nys = (n + yseg - 1) / yseg;
     double acc = 0.0, tvacc = 0.0;
     float nrm_ = 1.f;
     if (MODE == TVM_UPDATE) nrm_ = tv_step_len(up.dPOCS, up.gnorm2);      // the step length dPOCS / ||g||
@@ -2725,7 +2725,7 @@ __global__ __launch_bounds__(256) void k_fgp_obj(const float *A, float *D,
                                                   int first, float lambda, int n, int nx, int sx)
 {
     int lane = threadIdx.x & 63;
-    int nchunk = sx >> 6;
+    int nchunk = (nx + 63) >> 6   /* computed width, not the row pitch: the pitch may carry padding */;
     int64_t items = (int64_t)n * n * nchunk;
     int64_t wstride = (int64_t)gridDim.x * 4;
     for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += wstride) {
@@ -2751,7 +2751,7 @@ __global__ __launch_bounds__(256) void k_fgp_grad(const float *__restrict__ D, f
                                                    int nx, int sx)
 {
     int lane = threadIdx.x & 63;
-    int nchunk = sx >> 6;
+    int nchunk = (nx + 63) >> 6   /* computed width, not the row pitch: the pitch may carry padding */;
     int64_t items = (int64_t)n * n * nchunk;
     int64_t wstride = (int64_t)gridDim.x * 4;
     for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += wstride) {
@@ -2802,7 +2802,7 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
     __shared__ float al[TVL_TZ + 2][TVL_PITCH];           // A plane being turned into D
     __shared__ float dl[2][TVL_TZ + 1][TVL_PITCH];        // D planes: row zi' = column z0+zi', element si' = slice s0+si'
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nzb = (n + TVL_TZ - 1) / TVL_TZ, nchunk = sx >> 6, nys = (n + yseg - 1) / yseg;
+    const int nzb = (n + TVL_TZ - 1) / TVL_TZ, nchunk = (nx + 63) >> 6   /* computed width, not the row pitch: the pitch may carry padding */, nys = (n + yseg - 1) / yseg;
     // one workgroup per (y segment, z block, chunk); XCD-aware like k_tv_grad_reg: an XCD (workgroups b, b+8, ...) owns a
     // contiguous slab of z blocks and walks it chunk-fastest, so the halo columns / slices two neighbours share are fetched
     // once per L2 (PMC, round 2, blockIdx-ordered z blocks: reads 1.77x compulsory)

@@ -25,6 +25,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <functional>
@@ -838,8 +839,14 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
 {
     Tables t;
     std::string err;
+    const bool timing = std::getenv("TOMO_BUILD_TIMING") != nullptr;      // per-phase wall clock of the table builders to stderr
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto lap = [&](const char *what) { if (timing) { double x = now(); std::fprintf(stderr, "tomo_create: %-32s %.3f s\n", what, x - t_last); t_last = x; } };
     sort_rows(m);
+    lap("sort_rows");
     if (!build_tables(m, e->n, e->np, t, err)) return fail(TOMO_ERR_GEOMETRY, err);
+    lap("build_tables");
     e->nnz = m.ptr[m.nrow];
     if (e->nnz >= (int64_t)0xFFFFFFFFu) return fail(TOMO_ERR_ARG, "matrix too large for 32-bit entry offsets");
     e->lipschitz = t.lipschitz;
@@ -867,6 +874,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
     HIPCHK(hipMemcpy(e->d_rowinner, t.rowinner.data(), t.rowinner.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_colsum_all, t.colsum_all.data(), t.colsum_all.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_rowcross, t.rowcross.data(), t.rowcross.size() * 4, hipMemcpyHostToDevice));
+    lap("csr / cells upload");
     build_walk(m, e->n, e->np, t);
     {
         std::vector<uint2> went(t.walk_pix.size() ? t.walk_pix.size() : 1);
@@ -876,6 +884,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_wptr, t.walk_ptr.data(), t.walk_ptr.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_went, went.data(), t.walk_pix.size() * sizeof(uint2), hipMemcpyHostToDevice));
     }
+    lap("build_walk + upload");
     {
         const int seg_len = 32;   // visits per work item: 16/32/64/128 measured 222/224/233/242 us per fused step at 512^3
         build_segments(e->n, e->np, seg_len, t);
@@ -890,6 +899,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_row_nseg, t.row_nseg.data(), t.row_nseg.size() * 4, hipMemcpyHostToDevice));
         release(t.walk_pix); release(t.walk_w); release(t.walk_ptr); release(t.seg_exec); release(t.row_first); release(t.row_nseg);
     }
+    lap("build_segments + upload");
     {
         build_tiles(m, e->n, e->np, FT_TY, FT_TZ, 256, t);
         static_assert(Tables::TILE_SLOTS == FT_SLOTS && Tables::TILE_BATCH == FT_BATCH, "tile stream shape");
@@ -908,16 +918,19 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         HIPCHK(hipMemcpy(e->d_ft_rsptr, t.rseg_ptr.data(), t.rseg_ptr.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_ft_rsidx, t.rseg_idx.data(), t.rseg_idx.size() * 4, hipMemcpyHostToDevice));
         release(tent); release(t.tile_off); release(t.tile_w); release(t.rseg_idx); release(t.rseg_ptr); release(t.tile_slot_ptr); release(t.tile_slot_seg0);
+        lap("build_tiles + upload");
         {   // sheared-strip tables of the all-angle FP; a geometry they cannot hold (a user matrix whose rays are no lines) keeps the tile form
             std::string why;
             static_assert(Tables::FS_W == FS_W && Tables::FS_H == FS_H && Tables::FS_WAVES == FS_WAVES && Tables::FS_GROUPS == FS_GROUPS, "strip shape");
             static_assert(sizeof(Tables::FsItem) == sizeof(FsItemD), "strip item layout");
-            // Measured (round 4, MI355X, FP alone, strips against tiles, strips cut into segments for ~6 rounds of workgroups):
-            // 1024 x 512^2 x 90 2.53 / 2.87 ms, 512^3 x 90 1.32 / 1.44, 256 x 512^2 0.70 / 0.73, 128 x 1024^2 x 120 1.71 / 1.83, 1024^3 x 120
-            // 12.1 / 14.6 -- and 64 x 512^2 0.211 / 0.208, 256^3 x 60 0.143 / 0.123: a strip is a sequential march over at least four
-            // tiles, so small images and one-chunk slabs do not fill the chip with them.  TOMO_FP_STRIP = 0 / 1 overrides the rule
-            // (tests build the tables at small sizes).
-            bool want = e->n >= 384 && (int64_t)e->n * (e->sxc / 64) >= 1024;
+            // Measured (round 4, MI355X, FP alone, strips against tiles; strips cut into segments of 16 tiles): 1024 x 512^2 x 90 2.53 / 2.87 ms,
+            // 512^3 x 90 1.32 / 1.44, 128 x 1024^2 x 120 1.71 / 1.83, 1024^3 x 120 12.1 / 14.6 -- and 256 x 512^2 0.71 / 0.70, 64 x 512^2 0.235 / 0.196,
+            // 256^3 x 60 0.143 / 0.122: an item is a sequential march of up to 16 tiles, and the form pays once a launch has several rounds
+            // of them over the 512 resident workgroups: passes (~6.5 with the shear's overhang) x strips x segments x chunks >= 3000.
+            // TOMO_FP_STRIP = 0 / 1 overrides the rule (tests build the tables at small sizes).
+            const int fs_tiles = (e->n + FS_H - 1) / FS_H, fs_seglen = std::max(4, std::min(16, fs_tiles / 2));
+            const double fs_wgs = 6.5 * ((double)e->n / FS_W) * ((fs_tiles + fs_seglen - 1) / fs_seglen) * (e->sxc / 64);
+            bool want = e->n >= 384 && fs_wgs >= 3000.0;
             if (const char *env = std::getenv("TOMO_FP_STRIP")) want = std::atoi(env) != 0;
             e->fs_ok = want && build_fp_strips(m, e->n, e->np, 256, e->sxc / 64, t, why);
             if (e->fs_ok) {
@@ -944,6 +957,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             }
             t.fs_ent.reset(); t.fs_ent_n = 0; release(t.fs_cnt); release(t.fs_rseg_idx); release(t.fs_rseg_ptr); release(t.fs_gstart); release(t.fs_gseg0);
         }
+        lap("build_fp_strips + upload");
         build_sart_tiles(m, e->n, e->np, ST_TY, ST_TZ, ST_MAXR, 256, t);
         static_assert(Tables::ST_MAXSEG == ST_MAXSEG, "segment slots per tile");
         e->st_ok = t.st_ok;
@@ -967,6 +981,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             HIPCHK(hipMemcpy(e->d_st_row_nseg, t.st_row_nseg.data(), t.st_row_nseg.size() * 4, hipMemcpyHostToDevice));
         }
         release(t.st_cell); release(t.st_off); release(t.st_w); release(t.st_seg); release(t.st_segid); release(t.st_win);
+        lap("build_sart_tiles + upload");
         build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, 2 * FB_A, t);   // the cell ring prefetches up to angle P + 2*FB_A - 2
         static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
         e->fb_ok = t.bp_tile_ok && e->np <= FB_MAX_PROJ;
@@ -977,6 +992,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             HIPCHK(hipMemcpy(e->d_fb_win, t.bp_win.data(), t.bp_win.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    lap("build_bp_tiles + upload");
     static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
     HIPCHK(hipMemcpy(e->d_cell, t.cell.data(), t.cell.size() * sizeof(CellD), hipMemcpyHostToDevice));
     if ((rc = dev_alloc((void **)&e->d_scal_own, TOMO_S_COUNT * sizeof(double), true, e->stream))) return rc;
@@ -1013,7 +1029,13 @@ static tomo_engine *new_engine(int nslice, int nray, int nproj, int device)
     e->nx = nslice; e->n = nray; e->np = nproj; e->device = device;
     e->sxc = ((nslice + 63) / 64) * 64;
     e->vec = (e->sxc % 256 == 0) ? 4 : (e->sxc % 128 == 0) ? 2 : 1;
-    e->sx = e->sxc;   // row pitch = computed width (padding the pitch against power-of-two strides changed nothing)
+    // Row pitch = computed width.  A pixel's row of slices that is a multiple of 4 KB (1024 slices) makes two sweep chains striding over
+    // alternate halves of the rows alias the memory channels (round 2: 51.3 against 40.6 ms per sweep at 1024 slices), so such a slab
+    // runs ONE chain (chain_count).  Round 4 tried 64 slices of padding on the pitch so that it can run two (TOMO_PITCH_PAD = slices;
+    // no kernel computes on the padding: chunk counts come from the computed width): 1024^3 x 120 ASD-POCS step 208.7 ms with two
+    // chains on the padded pitch against 206.6 ms with one chain on the plain one -- not kept as the default.
+    e->sx = e->sxc;
+    if (const char *env = std::getenv("TOMO_PITCH_PAD")) { int v = std::atoi(env); if (v >= 0 && v % 4 == 0) e->sx = e->sxc + v; }
     e->npix = (int64_t)nray * nray;
     e->nrows = (int64_t)nray * nproj;
     return e;
