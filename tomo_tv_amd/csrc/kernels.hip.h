@@ -459,6 +459,9 @@ struct FsItemD { int pass, v0; uint32_t tile0, ntiles, cnt0, g0, work, pad; };
 #ifndef FS_WHATIF
 #define FS_WHATIF 0
 #endif
+#ifndef FS_DMA_STAGE
+#define FS_DMA_STAGE 1
+#endif
 
 // The entry stream of a lane group (8 entries of 8 bytes per batch) comes from L2 at best, and from HBM for whichever of an
 // item's chunk workgroups touches a line first; the batch loops have run-time trip counts, so a register ring cannot be kept
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(FS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, const int *__restrict__ orient,
                 const int *__restrict__ shift, const uint4 *__restrict__ cnt, const uint32_t *__restrict__ gstart,
                 const uint32_t *__restrict__ gseg0, const uint2 *__restrict__ ent, float *__restrict__ part, int n, int sx,
-                int nitems, int chunk0, int ncp)
+                int nitems, int chunk0, int ncp, const float *__restrict__ zero16)
 {
     typedef VecOf<4>::T V;
     static_assert(K >= 1 && K <= 16, "slots per lane group");
@@ -513,6 +516,24 @@ void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, 
     asm volatile("s_waitcnt vmcnt(%1)\n\tds_read_b64 %0, %2" : "=v"(en) : "n"(FS_RING - 1), "v"(ring_l) : "memory");
     for (uint32_t tt = 0; tt < I.ntiles; ++tt) {
         if (tt) __syncthreads();                        // every group is done with the previous tile
+#if FS_DMA_STAGE
+        {   // the tile by LDS-DMA: a wave-instruction moves the 64-slice images of four neighbouring pixels (one per lane group, 16 bytes
+            // per lane) straight into their 1 KB of the tile -- no vector registers, no ds_write pass; pixels outside the image read zeros
+            const int u0 = (int)(I.tile0 + tt) * FS_H;
+#pragma unroll
+            for (int i = 0; i < FS_PIX / FS_GROUPS; ++i) {
+                const int q = g + FS_GROUPS * i;
+                const int u = u0 + q / FS_W;
+                const int vv = I.v0 + sh[min(u, n - 1)] + q % FS_W;
+                const bool ok = u < n && (unsigned)vv < (unsigned)n;
+                const size_t pix = o ? (size_t)vv * n + u : (size_t)u * n + vv;
+                const float *src = ok ? xc + pix * sx : zero16 + gl * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(fs_tile + (4 * wave + FS_GROUPS * i) * 16), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#else
         {
             const int u0 = (int)(I.tile0 + tt) * FS_H;
             V v[FS_PIX / FS_GROUPS];
@@ -532,6 +553,7 @@ void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, 
 #pragma unroll
             for (int i = 0; i < FS_PIX / FS_GROUPS; ++i) fs_tile[(g + FS_GROUPS * i) * 16 + gl] = v[i];
         }
+#endif
         __syncthreads();
         const uint4 c4 = cp[(size_t)tt * FS_WAVES];
         // One stream unit: the entry of the unit after it is read from the ring while this one's pixel images are read.  FULL: a

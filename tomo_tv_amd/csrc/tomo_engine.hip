@@ -163,6 +163,7 @@ struct tomo_engine {
     uint4 *d_fs_cnt = nullptr;
     uint32_t *d_fs_gstart = nullptr, *d_fs_gseg0 = nullptr, *d_fs_rsptr = nullptr, *d_fs_rsidx = nullptr;
     uint2 *d_fs_ent = nullptr;
+    float *d_fs_zero = nullptr;                   // 256 bytes of zeros: what a strip tile's pixels outside the image are staged from
     float *fs_part = nullptr, *fs_part_aux = nullptr;
     // all-angle FP as a two-stage pipeline over groups of 64-slice chunks ("fp_tile_pipe"): [0] main stream, [1] second stream
     int fp_tile_pipe = 0;   // off: measured (round 3) 1.50 vs 1.52 ms at 512^3 x 90, 1.91 vs 1.83 ms at 128 x 1024^2 x 120, 0.127 vs 0.154 ms at 256^3 x 60
@@ -504,7 +505,7 @@ static int launch_fp_strip(tomo_engine *e, const float *x, const float *b, float
             ProfScope ps(e, TOMO_K_FP_TILE);
             dim3 grid((unsigned)(8 * ((e->fs_nitems + 7) / 8) * ncp)), block(FS_THREADS);
 #define FS_LAUNCH(KK) hipLaunchKernelGGL((k_fp_strip<KK>), grid, block, 0, e->stream, x, e->d_fs_items, e->d_fs_orient, e->d_fs_shift, e->d_fs_cnt, \
-                                         e->d_fs_gstart, e->d_fs_gseg0, e->d_fs_ent, *slot, e->n, e->sx, e->fs_nitems, c0, ncp)
+                                         e->d_fs_gstart, e->d_fs_gseg0, e->d_fs_ent, *slot, e->n, e->sx, e->fs_nitems, c0, ncp, e->d_fs_zero)
             if (e->fs_kused <= 8) FS_LAUNCH(8); else if (e->fs_kused <= 12) FS_LAUNCH(12); else FS_LAUNCH(16);
 #undef FS_LAUNCH
             LAUNCHCHK();
@@ -945,6 +946,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
                 if ((rc = dev_alloc((void **)&e->d_fs_ent, t.fs_ent_n * sizeof(uint2), false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_rsptr, t.fs_rseg_ptr.size() * 4, false, e->stream))) return rc;
                 if ((rc = dev_alloc((void **)&e->d_fs_rsidx, t.fs_rseg_idx.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fs_zero, 256, true, e->stream))) return rc;
                 HIPCHK(hipMemcpy(e->d_fs_items, t.fs_item.data(), t.fs_item.size() * sizeof(FsItemD), hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(e->d_fs_orient, t.fs_orient.data(), t.fs_orient.size() * 4, hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(e->d_fs_shift, t.fs_shift.data(), t.fs_shift.size() * 4, hipMemcpyHostToDevice));
@@ -1174,7 +1176,7 @@ static void free_geometry(tomo_engine *e)
                      (void **)&e->d_rptr, (void **)&e->d_rent, (void **)&e->d_rowsum, (void **)&e->d_rowinner, (void **)&e->d_colsum_all,
                      (void **)&e->d_rowcross, (void **)&e->d_cell,
                      (void **)&e->d_fs_items, (void **)&e->d_fs_orient, (void **)&e->d_fs_shift, (void **)&e->d_fs_cnt, (void **)&e->d_fs_gstart,
-                     (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux};
+                     (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_zero, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
     if (e->g_prev) { (void)hipFree(e->g_prev); e->g_prev = nullptr; }
