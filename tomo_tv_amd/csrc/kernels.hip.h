@@ -908,6 +908,17 @@ __global__ __launch_bounds__(256) void k_resid_finish(const float *__restrict__ 
 // ---- voxel-driven back-projector, all angles (SIRT / Landweber / plain A^T / Poisson) ----------------
 // acc[p][s] = sum_i (w0 r[i*N+j0][s] + w1 r[i*N+j1][s])      rows in ascending order, like Eigen's A^T*v
 // epilogue:  v = alpha*x + beta * (colsum ? acc/colsum[p] : acc);  x = clamp ? max(0, v) : v
+// alpha * x + beta * a of the all-angle back-projectors' epilogues, in ONE arithmetic for every form and vector width: the product
+// beta * a rounded, then one FMA (left to the contraction pass, the scalar and the vector forms of "alpha * x + beta * a" came out
+// as different FMAs: 1-ulp differences between k_bp_all<1> and the others).
+template <typename V>
+__device__ __forceinline__ V bp_axpby(float alpha, V x, float beta, V a)
+{
+#pragma clang fp contract(off)
+    V t = beta * a;
+    return __builtin_elementwise_fma((V)alpha, x, t);
+}
+
 template <int VEC, int PPW>
 __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const CellD *__restrict__ cell,
                                                  const float *__restrict__ r, const float *__restrict__ colsum,
@@ -950,7 +961,7 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
             }
             float *xp = x + (size_t)p * sx + off;
             V nv = beta * a;
-            if (alpha != 0.f) nv = alpha * (*reinterpret_cast<const V *>(xp)) + nv;
+            if (alpha != 0.f) nv = bp_axpby(alpha, *reinterpret_cast<const V *>(xp), beta, a);
             if (clamp) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) vset<VEC>(nv, i, fmaxf(velem<VEC>(nv, i), 0.f));
@@ -1395,12 +1406,220 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
             if (colsum) { float cs = colsum[p]; a = cs > 0.f ? a / cs : vzero<4>(); }
             float *xp = x + p * sx + off;
             V nv = beta * a;
-            if (alpha != 0.f) nv = alpha * nt_ld<64>(reinterpret_cast<const V *>(xp)) + nv;
+            if (alpha != 0.f) nv = bp_axpby(alpha, nt_ld<64>(reinterpret_cast<const V *>(xp)), beta, a);
             if (clamp) { nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f); }
             nt_st<64>(nv, reinterpret_cast<V *>(xp));
         }
     }
 }
+
+// ---- back-projector, all angles, tile-stationary form with WAVE-UNIFORM entry lists (round 4) -----------------------------------
+// k_bp_tile shares a cell {row offset, weight} x 2 among the 16 lanes of a group by DPP rotation: 28 lane moves and 16 address adds
+// for every 8 pixels and angle, next to the 32 packed FMAs that do the work, and BOTH row reads of every pixel -- although a pixel has
+// a second ray of an angle in one case of four (the second read then fetches the zero row: 39 % of the LDS reads and of the FMAs).
+// Here a wave covers 128 slices (64 lanes x float2) and owns 32 pixels of the 32 x 16 tile (2 registers each: v[64:127]); what it
+// has to do in a stage of FB_A angles is a LIST of entries {window byte offset | accumulator register, weight}, one per NONZERO
+// weight (sysmat.cpp: build_bp_lists), fetched 16 at a time by scalar loads.  An entry costs one v_and_or_b32 (the address), one
+// ds_read_b64 and one v_pk_fma_f32 whose accumulator is picked by the VGPR index mode (s_set_gpr_idx_on: M0[7:0] is added to the
+// register number of src2 and dst), the weight being the scalar operand: no lane moves, no branches, no reads of zeros.  The loop is
+// one asm block on fixed registers (the index mode cannot be expressed otherwise): entries s[36:67] / s[68:99] (two sets: the next
+// batch is requested while the second half of this one is worked on; scalar loads return out of order with LDS reads, so they go out
+// only after the batch's last read has landed), rows v[32:63], list pointer in vcc.  The residual rows of a stage (<= 40 per angle,
+// 512 bytes each) are staged by LDS-DMA, the next stage into the other half of the LDS while this one is worked on (2 x 80 KB: all
+// of a CU's LDS; no registers, which the fixed blocks leave no room for).  A pixel's FMAs keep the order of k_bp_all (angles
+// ascending, first ray before second); a skipped zero weight would have added +-0 to a sum that is never -0: bit-identical.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v32f __attribute__((ext_vector_type(32)));
+constexpr int FB2_ROWB = 512, FB2_ROWS = FB_A * FB_MAXR, FB2_BUF = FB2_ROWS * FB2_ROWB, FB2_LDS_BYTES = 2 * FB2_BUF;
+constexpr int FB2_PIECES = FB2_ROWS * (FB2_ROWB / 16), FB2_Q = (FB2_PIECES + FT_THREADS - 1) / FT_THREADS;   // float4 pieces of a stage per thread
+constexpr int FB2_WAVES = FT_THREADS / 64, FB2_PPW = FT_PIX / FB2_WAVES;      // 16 waves, 32 pixels each
+constexpr int BL_BATCH = 16;                            // entries per batch (two s_load_dwordx16)
+#ifndef BL_WHATIF
+#define BL_WHATIF 0                                     // timing experiments: 1 = the list pointer never advances, 2 = only stage 0 is staged, 4 = no LDS reads
+#endif
+
+#if BL_WHATIF & 4
+#define BL_DSREAD(K) ""
+#else
+#define BL_DSREAD(K) "ds_read_b64 v[32+2*" #K ":33+2*" #K "], v[32+2*" #K "]\n"
+#endif
+// entry K of the set that starts at SGPR SB: s[SB+2K] = row offset | register (rows are 512 bytes apart: the low 9 bits of the offset
+// are free; M0 takes the register from bits 7:0, the address is (entry & ~511) | 8 * lane), s[SB+2K+1] = weight; the row lands in
+// v[32+2K:33+2K]
+#define BL_RD(SB, K)                                                                                      \
+    "v_and_or_b32 v[32+2*" #K "], s[" #SB "+2*" #K "], %[mask], %[base]\n"                                \
+    BL_DSREAD(K)
+#define BL_FMA(SB, K)                                                                                     \
+    "s_set_gpr_idx_on s[" #SB "+2*" #K "], gpr_idx(SRC2,DST)\n"                                           \
+    "v_pk_fma_f32 v[64:65], s[" #SB "+2*" #K ":" #SB "+2*" #K "+1], v[32+2*" #K ":33+2*" #K "], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
+#define BL_WFMA(SB, K, W) "s_waitcnt lgkmcnt(" #W ")\n" BL_FMA(SB, K)
+#define BL_READS(SB)                                                                                      \
+    BL_RD(SB, 0) BL_RD(SB, 1) BL_RD(SB, 2) BL_RD(SB, 3) BL_RD(SB, 4) BL_RD(SB, 5) BL_RD(SB, 6) BL_RD(SB, 7)             \
+    BL_RD(SB, 8) BL_RD(SB, 9) BL_RD(SB, 10) BL_RD(SB, 11) BL_RD(SB, 12) BL_RD(SB, 13) BL_RD(SB, 14) BL_RD(SB, 15)
+#define BL_FMAS(SB)                                                                                       \
+    BL_FMA(SB, 0) BL_FMA(SB, 1) BL_FMA(SB, 2) BL_FMA(SB, 3) BL_FMA(SB, 4) BL_FMA(SB, 5) BL_FMA(SB, 6) BL_FMA(SB, 7)     \
+    BL_FMA(SB, 8) BL_FMA(SB, 9) BL_FMA(SB, 10) BL_FMA(SB, 11) BL_FMA(SB, 12) BL_FMA(SB, 13) BL_FMA(SB, 14) BL_FMA(SB, 15) "s_set_gpr_idx_off\n"
+#define BL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
+#define BL_CLOBBERS                                                                                       \
+    BL_CLOB4(s, 36, 37, 38, 39), BL_CLOB4(s, 40, 41, 42, 43), BL_CLOB4(s, 44, 45, 46, 47), BL_CLOB4(s, 48, 49, 50, 51),      \
+    BL_CLOB4(s, 52, 53, 54, 55), BL_CLOB4(s, 56, 57, 58, 59), BL_CLOB4(s, 60, 61, 62, 63), BL_CLOB4(s, 64, 65, 66, 67),      \
+    BL_CLOB4(s, 68, 69, 70, 71), BL_CLOB4(s, 72, 73, 74, 75), BL_CLOB4(s, 76, 77, 78, 79), BL_CLOB4(s, 80, 81, 82, 83),      \
+    BL_CLOB4(s, 84, 85, 86, 87), BL_CLOB4(s, 88, 89, 90, 91), BL_CLOB4(s, 92, 93, 94, 95), BL_CLOB4(s, 96, 97, 98, 99),      \
+    "s33",                                                                                                \
+    BL_CLOB4(v, 32, 33, 34, 35), BL_CLOB4(v, 36, 37, 38, 39), BL_CLOB4(v, 40, 41, 42, 43), BL_CLOB4(v, 44, 45, 46, 47),      \
+    BL_CLOB4(v, 48, 49, 50, 51), BL_CLOB4(v, 52, 53, 54, 55), BL_CLOB4(v, 56, 57, 58, 59), BL_CLOB4(v, 60, 61, 62, 63),      \
+    "vcc", "scc", "memory"
+
+__global__ __launch_bounds__(FT_THREADS) void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent,
+                                                         const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ win,
+                                                         const float *__restrict__ r, const float *__restrict__ colsum,
+                                                         float alpha, float beta, int clamp,
+                                                         int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2)
+{
+    typedef VecOf<4>::T V;
+    extern __shared__ V fb2_lds[];                      // [2][FB2_ROWS][32]: stage parity, slot (angle % 4), row of its window
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int tile = (l / nchunk2) * 8 + xcd, c2 = l % nchunk2;
+    if (tile >= ntiles) return;
+    const int ty = tile / tiles_z, tz = tile - ty * tiles_z;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t *wn = win + (size_t)tile * nproj;
+    const int nstage = (nproj + FB_A - 1) / FB_A;
+    // One DMA instruction moves 64 x 16 bytes = a PAIR of consecutive rows of a window (lanes 0-31 the even row, 32-63 the odd one).
+    // A stage has FB_A x FB_MAXR / 2 = 80 pairs: wave w moves pair w of each of the 4 angles, and pair 16 + (w & 3) of angle w >> 2.
+    // The window words {first ray | rays << 16} of all angles sit in 4 registers, stage s in lane s (nstage <= 64), so that a
+    // stage's staging depends on no scalar load; everything but the odd row's lane offset is scalar arithmetic.
+    static_assert(FB_A == 4 && FB_MAXR == 40 && FB2_WAVES == 16, "pair assignment of the staging");
+    const int jl = lane >> 5;
+    const float *rc = r + (size_t)c2 * 128 + (lane & 31) * 4 + (size_t)jl * sx;
+    uint32_t wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0;
+    if (lane < nstage) {
+        const int i0 = lane * FB_A;
+        wv0 = wn[i0];
+        if (i0 + 1 < nproj) wv1 = wn[i0 + 1];
+        if (i0 + 2 < nproj) wv2 = wn[i0 + 2];
+        if (i0 + 3 < nproj) wv3 = wn[i0 + 3];
+    }
+#define BL_DMA1(S, A, WW, PAIR)                                                                           \
+    if ((uint32_t)(2 * (PAIR)) < ((WW) >> 16)) {                                                          \
+        if ((uint32_t)(2 * (PAIR) + jl) < ((WW) >> 16))                                                   \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rc + ((size_t)((S) * FB_A + (A)) * n + ((WW) & 0xFFFFu) + 2 * (PAIR)) * sx), \
+                                             (__attribute__((address_space(3))) void *)(fb2_lds + ((S) & 1) * (FB2_BUF / 16) + ((A) * FB_MAXR + 2 * (PAIR)) * (FB2_ROWB / 16)), 16, 0, 0); \
+    }
+#define BL_STAGE_DMA(S)                                                                                   \
+    {                                                                                                     \
+        const uint32_t w0 = __builtin_amdgcn_readlane(wv0, (S)), w1 = __builtin_amdgcn_readlane(wv1, (S)); \
+        const uint32_t w2 = __builtin_amdgcn_readlane(wv2, (S)), w3 = __builtin_amdgcn_readlane(wv3, (S)); \
+        BL_DMA1(S, 0, w0, wave) BL_DMA1(S, 1, w1, wave) BL_DMA1(S, 2, w2, wave) BL_DMA1(S, 3, w3, wave)   \
+        const int a5 = wave >> 2;                                                                         \
+        const uint32_t w5 = a5 == 0 ? w0 : a5 == 1 ? w1 : a5 == 2 ? w2 : w3;                              \
+        BL_DMA1(S, a5, w5, 16 + (wave & 3))                                                               \
+    }
+    BL_STAGE_DMA(0)
+    // The lists stream from HBM once and a scalar load has nobody to hide a miss behind: every wave touches the lines of its NEXT
+    // list with one vector load a stage ahead (lane k: batch k of the list), so that the scalar loads hit the L2.
+    // (the list bounds of all stages, one stage per lane, so that no stage starts behind a scalar miss: nstage <= 64)
+    const uint32_t *lp = lptr + (size_t)tile * nstage * FB2_WAVES + wave;
+    uint32_t pv0 = 0, pv1 = 0;
+    if (lane < nstage) { pv0 = lp[(size_t)lane * FB2_WAVES]; pv1 = lp[(size_t)lane * FB2_WAVES + 1]; }
+#define BL_TOUCH(S)                                                                                       \
+    {                                                                                                     \
+        const uint32_t t0 = __builtin_amdgcn_readlane(pv0, (S)), t1 = __builtin_amdgcn_readlane(pv1, (S)); \
+        if (t0 + lane < t1) touched = *reinterpret_cast<const uint32_t *>(lent + (size_t)(t0 + lane) * BL_BATCH);   /* a list has <= 16 batches */ \
+    }
+    uint32_t touched = 0;
+    BL_TOUCH(0)
+    v32f acc_lo, acc_hi;                                // pixel q of the wave: registers 2q, 2q+1 of v[64:127]
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { acc_lo[q] = 0.f; acc_hi[q] = 0.f; }
+    // (the dynamic LDS block is the kernel's only one, so it starts at LDS address 0 and a row offset IS its address)
+    const uint32_t base = (uint32_t)lane * 8u, mask = ~(uint32_t)(FB2_ROWB - 1);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+#if (BL_WHATIF & 10) == 10
+#elif BL_WHATIF & 2
+        if (s + 1 < nstage) { BL_TOUCH(s + 1) }
+#else
+        if (s + 1 < nstage) { BL_STAGE_DMA(s + 1) BL_TOUCH(s + 1) }
+#endif
+        const uint32_t b0 = __builtin_amdgcn_readlane(pv0, s);
+        uint32_t nb = __builtin_amdgcn_readlane(pv1, s) - b0;
+#if BL_WHATIF & 32
+        nb = 0;
+#endif
+        if (nb != 0u) {
+            const uint2 *ep = lent + (size_t)b0 * BL_BATCH;
+            asm volatile("s_mov_b32 s33, m0\n"
+                         "s_mov_b64 vcc, %[ep]\n"
+                         "s_load_dwordx16 s[36:51], vcc, 0x0\n"
+                         "s_load_dwordx16 s[52:67], vcc, 0x40\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "1:\n"
+                         "s_load_dwordx16 s[68:83], vcc, 0x80\n"
+                         "s_load_dwordx16 s[84:99], vcc, 0xc0\n"
+                         BL_READS(36)
+                         "s_waitcnt lgkmcnt(0)\n"
+                         BL_FMAS(36)
+                         "s_sub_u32 %[nb], %[nb], 1\n"
+                         "s_cmp_eq_u32 %[nb], 0\n"
+                         "s_cbranch_scc1 2f\n"
+#if BL_WHATIF & 1
+                         "s_add_u32 vcc_lo, vcc_lo, 0\n"
+#else
+                         "s_add_u32 vcc_lo, vcc_lo, 0x100\n"
+#endif
+                         "s_addc_u32 vcc_hi, vcc_hi, 0\n"
+                         "s_load_dwordx16 s[36:51], vcc, 0x0\n"
+                         "s_load_dwordx16 s[52:67], vcc, 0x40\n"
+                         BL_READS(68)
+                         "s_waitcnt lgkmcnt(0)\n"
+                         BL_FMAS(68)
+                         "s_sub_u32 %[nb], %[nb], 1\n"
+                         "s_cmp_lg_u32 %[nb], 0\n"
+                         "s_cbranch_scc1 1b\n"
+                         "2:\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "s_mov_b32 m0, s33\n"
+                         : "+{v[64:95]}"(acc_lo), "+{v[96:127]}"(acc_hi), [nb] "+s"(nb)
+                         : [ep] "s"(ep), [base] "v"(base), [mask] "v"(mask)
+                         : BL_CLOBBERS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");     // this wave's pieces of the next stage have landed
+#if !(BL_WHATIF & 16)
+        __syncthreads();
+#endif
+        //                                       // ... everybody's have, and every wave is done with this stage's rows
+    }
+#undef BL_STAGE_DMA
+#undef BL_DMA1
+#undef BL_TOUCH
+    const int off = c2 * 128 + lane * 2;
+#pragma unroll
+    for (int q = 0; q < FB2_PPW; ++q) {
+        const int lpx = wave * FB2_PPW + q;
+        const int y = ty * FT_TY + lpx / FT_TZ, z = tz * FT_TZ + lpx % FT_TZ;
+        if (y < n && z < n) {
+            const size_t p = (size_t)y * n + z;
+            v2f a = q < 16 ? v2f{acc_lo[2 * q], acc_lo[2 * q + 1]} : v2f{acc_hi[2 * (q & 15)], acc_hi[2 * (q & 15) + 1]};
+            if (colsum) { const float cs = colsum[p]; a = cs > 0.f ? a / cs : v2f{0.f, 0.f}; }
+            float *xp = x + p * sx + off;
+            v2f nv = beta * a;
+            if (alpha != 0.f) nv = bp_axpby(alpha, nt_ld<64>(reinterpret_cast<const v2f *>(xp)), beta, a);
+            if (clamp) { nv.x = fmaxf(nv.x, 0.f); nv.y = fmaxf(nv.y, 0.f); }
+            nt_st<64>(nv, reinterpret_cast<v2f *>(xp));
+        }
+    }
+}
+#undef BL_CLOBBERS
+#undef BL_CLOB4
+#undef BL_FMAS
+#undef BL_READS
+#undef BL_WFMA
+#undef BL_FMA
+#undef BL_RD
+#undef BL_DSREAD
 
 // ---- ART (Kaczmarz), row-sequential by definition (ctvlib.cpp:137-155) -------------------------------
 // a = (b_j - A_j x)/|A_j|^2 ; x += A_j^T a beta, one row after the other: row j+1 shares pixels with row j, so

@@ -617,6 +617,72 @@ void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows
     for (uint32_t k = 0; k < ntiles; ++k) if (bad[k]) t.bp_tile_ok = false;
 }
 
+// Entry lists of k_bp_list (see sysmat.h).
+void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int waves, int batch, int regs_per_pixel, Tables &t)
+{
+    const int64_t npix = (int64_t)N * N;
+    const int tiles_y = (N + TY - 1) / TY, tiles_z = (N + TZ - 1) / TZ;
+    const uint32_t ntiles = (uint32_t)tiles_y * tiles_z;
+    const int TP = TY * TZ, ppw = TP / waves, nstage = (P + stage_angles - 1) / stage_angles;
+    const uint32_t buf_bytes = (uint32_t)(stage_angles * max_rows) * (uint32_t)row_bytes;       // stage s sits in LDS buffer s & 1
+    const size_t nlist = (size_t)ntiles * nstage * waves;
+    unsigned hw = builder_threads();
+    int nth = (int)std::min<uint32_t>(std::max(1u, std::min(hw, 32u)), std::max(1u, ntiles / 8));
+    std::vector<uint32_t> nb(nlist, 0);
+    // pass 0 counts the batches of every list, pass 1 (after the prefix sum) writes them
+    auto work = [&](int th, int pass) {
+        for (uint32_t k = ntiles * (uint64_t)th / nth; k < ntiles * (uint64_t)(th + 1) / nth; ++k) {
+            const int y0 = (int)(k / tiles_z) * TY, z0 = (int)(k % tiles_z) * TZ;
+            for (int s = 0; s < nstage; ++s)
+                for (int w = 0; w < waves; ++w) {
+                    const size_t li = ((size_t)k * nstage + s) * waves + w;
+                    uint64_t *out = pass ? t.bl_ent.get() + (size_t)t.bl_ptr[li] * batch : nullptr;
+                    uint32_t cnt = 0;
+                    for (int i = s * stage_angles; i < std::min(P, (s + 1) * stage_angles); ++i) {
+                        const Cell *ci = t.cell.data() + (size_t)i * npix;
+                        const uint32_t lo = t.bp_win[(size_t)k * P + i] & 0xFFFFu;
+                        const uint32_t slot_base = (uint32_t)(s & 1) * buf_bytes + (uint32_t)(i % stage_angles) * (uint32_t)max_rows * (uint32_t)row_bytes;
+                        for (int second = 0; second < 2; ++second)
+                            for (int q = 0; q < ppw; ++q) {
+                                const int lp = w * ppw + q, ly = lp / TZ, lz = lp % TZ;
+                                if (y0 + ly >= N || z0 + lz >= N) continue;
+                                const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
+                                const float wt = second ? c.w1 : c.w0;
+                                if (wt == 0.f) continue;
+                                if (pass) {
+                                    const uint32_t off = slot_base + ((second ? c.r1 : c.r0) - lo) * (uint32_t)row_bytes;
+                                    uint32_t wb;
+                                    std::memcpy(&wb, &wt, 4);
+                                    out[cnt] = ((uint64_t)wb << 32) | (uint64_t)(off | (uint32_t)(q * regs_per_pixel));
+                                }
+                                ++cnt;
+                            }
+                    }
+                    const uint32_t batches = (cnt + batch - 1) / batch;
+                    // padding: weight 0 on the row of the list's last entry (staged, so finite), into accumulator 0
+                    if (pass) for (uint32_t j = cnt; j < batches * (uint32_t)batch; ++j) out[j] = out[cnt - 1] & (uint64_t)~(uint32_t)(row_bytes - 1);
+                    else nb[li] = batches;
+                }
+        }
+    };
+    auto run = [&](int pass) {
+        std::vector<std::thread> thr;
+        for (int th = 1; th < nth; ++th) thr.emplace_back(work, th, pass);
+        work(0, pass);
+        for (auto &x : thr) x.join();
+    };
+    run(0);
+    t.bl_ptr.assign(nlist + 1, 0);
+    uint64_t tot = 0;
+    for (size_t i = 0; i < nlist; ++i) { t.bl_ptr[i] = (uint32_t)tot; tot += nb[i]; }
+    t.bl_ptr[nlist] = (uint32_t)tot;
+    t.bl_nbatch = tot;
+    if (tot >= 0xFFFFFFFFull) { t.bl_nbatch = 0; t.bl_ptr.clear(); return; }        // (the kernel then stays with the cell form)
+    t.bl_ent.reset(new uint64_t[(size_t)(tot + 1) * batch]);
+    for (int j = 0; j < batch; ++j) t.bl_ent[(size_t)tot * batch + j] = 0;          // (prefetched behind the last list, never worked on)
+    run(1);
+}
+
 // Per-angle tile tables of the fused SART step (see sysmat.h); needs t.cell (build_tables).
 void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, int pixel_bytes, Tables &t)
 {

@@ -205,6 +205,10 @@ struct tomo_engine {
     int sart_skip_same = 1;                        // k_sart_tile stores only the 256-byte pieces whose bits changed (in place)
     int sart_nt = -1;                              // tile accesses: -1 streaming form by slab size (slab_streams), 0 plain, 1 streaming
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
+    int bp_list = 1;                              // ... in its entry-list form (k_bp_list) when the slab is whole pairs of 64-slice chunks
+    bool attr_bp2 = false, bl_ok = false;
+    uint2 *d_bl_ent = nullptr;                    // k_bp_list: entry batches and the first batch of every (tile, stage, wave) list
+    uint32_t *d_bl_ptr = nullptr;
     bool fb_ok = false;
     uint4 *d_fb_cell = nullptr;
     uint32_t *d_fb_win = nullptr;
@@ -805,6 +809,19 @@ static int launch_sart_coop(tomo_engine *e, const Sub &sb, float *x, int prev, i
 
 static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
 {
+    if (e->bp_tile && e->fb_ok && e->bl_ok && e->bp_list && e->sxc % 128 == 0) {     // entry lists: whole pairs of 64-slice chunks
+        if (!e->attr_bp2) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_bp_list, hipFuncAttributeMaxDynamicSharedMemorySize, FB2_LDS_BYTES));
+            e->attr_bp2 = true;
+        }
+        const int nchunk2 = e->sxc / 128;
+        ProfScope ps(e, TOMO_K_BP_TILE);
+        dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * nchunk2)), block(FT_THREADS);
+        hipLaunchKernelGGL(k_bp_list, grid, block, FB2_LDS_BYTES, e->stream, x, e->d_bl_ent, e->d_bl_ptr, e->d_fb_win, r, colsum, alpha, beta, clamp,
+                           e->np, e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, nchunk2);
+        LAUNCHCHK();
+        return TOMO_OK;
+    }
     if (e->bp_tile && e->fb_ok) {
         if (!e->attr_bp) {
             HIPCHK(hipFuncSetAttribute((const void *)k_bp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES + FB_MAX_PROJ * 4));
@@ -987,14 +1004,27 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, 2 * FB_A, t);   // the cell ring prefetches up to angle P + 2*FB_A - 2
         static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
         e->fb_ok = t.bp_tile_ok && e->np <= FB_MAX_PROJ;
+        e->bl_ok = false;
         if (e->fb_ok) {
             if ((rc = dev_alloc((void **)&e->d_fb_cell, t.bp_cell.size() * sizeof(uint4), false, e->stream))) return rc;
             if ((rc = dev_alloc((void **)&e->d_fb_win, t.bp_win.size() * 4, false, e->stream))) return rc;
             HIPCHK(hipMemcpy(e->d_fb_cell, t.bp_cell.data(), t.bp_cell.size() * sizeof(uint4), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_fb_win, t.bp_win.data(), t.bp_win.size() * 4, hipMemcpyHostToDevice));
+            release(t.bp_cell);
+            lap("build_bp_tiles + upload");
+            build_bp_lists(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, FB2_ROWB, FB2_WAVES, BL_BATCH, 2, t);
+            e->bl_ok = t.bl_nbatch != 0 && (e->np + FB_A - 1) / FB_A <= 64;     // (k_bp_list keeps a stage's list bounds per lane)
+            if (e->bl_ok) {
+                const size_t nent = (size_t)(t.bl_nbatch + 1) * BL_BATCH;
+                if ((rc = dev_alloc((void **)&e->d_bl_ent, nent * sizeof(uint2), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_bl_ptr, t.bl_ptr.size() * 4, false, e->stream))) return rc;
+                HIPCHK(hipMemcpy(e->d_bl_ent, t.bl_ent.get(), nent * sizeof(uint2), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_bl_ptr, t.bl_ptr.data(), t.bl_ptr.size() * 4, hipMemcpyHostToDevice));
+                t.bl_ent.reset();
+            }
         }
     }
-    lap("build_bp_tiles + upload");
+    lap("build_bp_lists + upload");
     static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
     HIPCHK(hipMemcpy(e->d_cell, t.cell.data(), t.cell.size() * sizeof(CellD), hipMemcpyHostToDevice));
     if ((rc = dev_alloc((void **)&e->d_scal_own, TOMO_S_COUNT * sizeof(double), true, e->stream))) return rc;
@@ -1169,7 +1199,7 @@ int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const 
 static void free_geometry(tomo_engine *e)
 {
     void **ptrs[] = {(void **)&e->d_st_cell, (void **)&e->d_st_win, (void **)&e->d_st_segid, (void **)&e->d_st_seg, (void **)&e->d_st_ent,
-                     (void **)&e->d_st_row_first, (void **)&e->d_st_row_nseg, (void **)&e->st_partial, (void **)&e->st_partial2, (void **)&e->st_flags, (void **)&e->d_fb_cell, (void **)&e->d_fb_win,
+                     (void **)&e->d_st_row_first, (void **)&e->d_st_row_nseg, (void **)&e->st_partial, (void **)&e->st_partial2, (void **)&e->st_flags, (void **)&e->d_fb_cell, (void **)&e->d_fb_win, (void **)&e->d_bl_ent, (void **)&e->d_bl_ptr,
                      (void **)&e->d_ft_slot_ptr, (void **)&e->d_ft_slot_seg0, (void **)&e->d_ft_tent, (void **)&e->d_ft_rsptr, (void **)&e->d_ft_rsidx,
                      (void **)&e->ft_part, (void **)&e->ft_part_aux, (void **)&e->cg_w, (void **)&e->fbp_h, (void **)&e->d_seg_exec,
                      (void **)&e->d_row_first, (void **)&e->d_row_nseg, (void **)&e->seg_partial, (void **)&e->d_wptr, (void **)&e->d_went,
@@ -2874,6 +2904,8 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "fp_strip_slots") == 0) { *value = e->fs_ok ? e->fs_kused : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { *value = e->fp_tile; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { *value = e->bp_tile; return TOMO_OK; }
+    if (std::strcmp(name, "bp_list") == 0) { *value = e->bp_list; return TOMO_OK; }
+    if (std::strcmp(name, "bp_list_ready") == 0) { *value = e->bl_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_reuse") == 0) { *value = e->fp_reuse; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { *value = e->sart_tile; return TOMO_OK; }
     if (std::strcmp(name, "comm_rounds") == 0) { *value = (int)std::min<int64_t>(e->comm_rounds, 0x7FFFFFFF); return TOMO_OK; }
@@ -2900,6 +2932,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_coop") == 0) { e->sart_coop = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "bp_list") == 0) { e->bp_list = value ? 1 : 0; return TOMO_OK; }
     // all-angle FP form: "fp_strip" = 1 (default) sheared strips; asking for "fp_tile" = 1 / 0 explicitly selects the tile-stationary /
     // the ray-driven form (and takes the strips out of the way until "fp_strip" = 1 is set again)
     if (std::strcmp(name, "fp_strip") == 0) { e->fp_strip = value ? 1 : 0; return TOMO_OK; }
