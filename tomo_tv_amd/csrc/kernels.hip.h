@@ -1430,9 +1430,11 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
 // ascending, first ray before second); a skipped zero weight would have added +-0 to a sum that is never -0: bit-identical.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v32f __attribute__((ext_vector_type(32)));
-constexpr int FB2_ROWB = 512, FB2_ROWS = FB_A * FB_MAXR, FB2_BUF = FB2_ROWS * FB2_ROWB, FB2_LDS_BYTES = 2 * FB2_BUF;
-constexpr int FB2_PIECES = FB2_ROWS * (FB2_ROWB / 16), FB2_Q = (FB2_PIECES + FT_THREADS - 1) / FT_THREADS;   // float4 pieces of a stage per thread
-constexpr int FB2_WAVES = FT_THREADS / 64, FB2_PPW = FT_PIX / FB2_WAVES;      // 16 waves, 32 pixels each
+constexpr int BL_TY = 16, BL_TZ = 16, BL_PIX = BL_TY * BL_TZ, BL_THREADS = 512, BL_WAVES = BL_THREADS / 64, BL_PPW = BL_PIX / BL_WAVES;
+constexpr int BL_A = 3, BL_MAXR = 26, BL_ROWB = 512;   // angles per stage, rows of a 16 x 16 tile's window (<= 16 sqrt 2 + 2), bytes of a row
+constexpr int BL_BUF = BL_A * BL_MAXR * BL_ROWB, BL_LDS_BYTES = 2 * BL_BUF;         // 79,872 bytes: two workgroups per CU
+constexpr int BL_PAIRS = BL_MAXR / 2, BL_STAGE_PAIRS = BL_A * BL_PAIRS;              // DMA pieces (row pairs) of an angle / a stage
+static_assert(BL_PPW == 32 && BL_MAXR % 2 == 0 && 2 * BL_LDS_BYTES <= 160 * 1024, "k_bp_list geometry");
 constexpr int BL_BATCH = 16;                            // entries per batch (two s_load_dwordx16)
 #ifndef BL_WHATIF
 #define BL_WHATIF 0                                     // timing experiments: 1 = the list pointer never advances, 2 = only stage 0 is staged, 4 = no LDS reads
@@ -1456,9 +1458,12 @@ constexpr int BL_BATCH = 16;                            // entries per batch (tw
 #define BL_READS(SB)                                                                                      \
     BL_RD(SB, 0) BL_RD(SB, 1) BL_RD(SB, 2) BL_RD(SB, 3) BL_RD(SB, 4) BL_RD(SB, 5) BL_RD(SB, 6) BL_RD(SB, 7)             \
     BL_RD(SB, 8) BL_RD(SB, 9) BL_RD(SB, 10) BL_RD(SB, 11) BL_RD(SB, 12) BL_RD(SB, 13) BL_RD(SB, 14) BL_RD(SB, 15)
+// (a counted wait stays valid with the scalar loads of the next batch in flight: lgkmcnt(15 - K) leaves at most 15 - K of the
+// 16 + 2 operations outstanding, so at least K + 1 LDS reads -- which return in order -- have landed whatever the scalar loads do)
 #define BL_FMAS(SB)                                                                                       \
-    BL_FMA(SB, 0) BL_FMA(SB, 1) BL_FMA(SB, 2) BL_FMA(SB, 3) BL_FMA(SB, 4) BL_FMA(SB, 5) BL_FMA(SB, 6) BL_FMA(SB, 7)     \
-    BL_FMA(SB, 8) BL_FMA(SB, 9) BL_FMA(SB, 10) BL_FMA(SB, 11) BL_FMA(SB, 12) BL_FMA(SB, 13) BL_FMA(SB, 14) BL_FMA(SB, 15) "s_set_gpr_idx_off\n"
+    BL_WFMA(SB, 0, 15) BL_WFMA(SB, 1, 14) BL_WFMA(SB, 2, 13) BL_WFMA(SB, 3, 12) BL_WFMA(SB, 4, 11) BL_WFMA(SB, 5, 10) BL_WFMA(SB, 6, 9) BL_WFMA(SB, 7, 8) \
+    BL_WFMA(SB, 8, 7) BL_WFMA(SB, 9, 6) BL_WFMA(SB, 10, 5) BL_WFMA(SB, 11, 4) BL_WFMA(SB, 12, 3) BL_WFMA(SB, 13, 2) BL_WFMA(SB, 14, 1) BL_WFMA(SB, 15, 0) \
+    "s_set_gpr_idx_off\n"
 #define BL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define BL_CLOBBERS                                                                                       \
     BL_CLOB4(s, 36, 37, 38, 39), BL_CLOB4(s, 40, 41, 42, 43), BL_CLOB4(s, 44, 45, 46, 47), BL_CLOB4(s, 48, 49, 50, 51),      \
@@ -1470,14 +1475,18 @@ constexpr int BL_BATCH = 16;                            // entries per batch (tw
     BL_CLOB4(v, 48, 49, 50, 51), BL_CLOB4(v, 52, 53, 54, 55), BL_CLOB4(v, 56, 57, 58, 59), BL_CLOB4(v, 60, 61, 62, 63),      \
     "vcc", "scc", "memory"
 
-__global__ __launch_bounds__(FT_THREADS) void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent,
-                                                         const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ win,
-                                                         const float *__restrict__ r, const float *__restrict__ colsum,
-                                                         float alpha, float beta, int clamp,
-                                                         int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2)
+__global__ __launch_bounds__(BL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ win,
+               const float *__restrict__ r, const float *__restrict__ colsum, float alpha, float beta, int clamp,
+               int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2, int skew)
 {
     typedef VecOf<4>::T V;
-    extern __shared__ V fb2_lds[];                      // [2][FB2_ROWS][32]: stage parity, slot (angle % 4), row of its window
+    extern __shared__ V bl_lds[];
+    // Every workgroup does the same amount of work, so the ones that start together reach their epilogues (the only HBM traffic
+    // of the kernel: the tile of x, read and written) together: bursts the HBM serves while the CUs wait.  The workgroups of the
+    // first round start `skew` x (l mod 4) sleeps apart so that a CU's two workgroups stay out of phase.
+    if (skew > 0 && blockIdx.x < 4096u)
+        for (int k = ((blockIdx.x >> 3) & 3) * skew; k > 0; --k) __builtin_amdgcn_s_sleep(127);                       // [2][BL_A][BL_MAXR][32]: stage parity, slot (angle % 3), row of its window
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
     const int tile = (l / nchunk2) * 8 + xcd, c2 = l % nchunk2;
     if (tile >= ntiles) return;
@@ -1485,44 +1494,43 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_list(float *__restrict__ x, c
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t *wn = win + (size_t)tile * nproj;
-    const int nstage = (nproj + FB_A - 1) / FB_A;
+    const int nstage = (nproj + BL_A - 1) / BL_A;
     // One DMA instruction moves 64 x 16 bytes = a PAIR of consecutive rows of a window (lanes 0-31 the even row, 32-63 the odd one).
-    // A stage has FB_A x FB_MAXR / 2 = 80 pairs: wave w moves pair w of each of the 4 angles, and pair 16 + (w & 3) of angle w >> 2.
-    // The window words {first ray | rays << 16} of all angles sit in 4 registers, stage s in lane s (nstage <= 64), so that a
+    // A stage has BL_A x BL_MAXR / 2 = 39 pairs: wave w moves pairs w, w + 8, ... (pair k = row pair k % 13 of angle k / 13).
+    // The window words {first ray | rays << 16} of all angles sit in 3 registers, stage s in lane s (nstage <= 64), so that a
     // stage's staging depends on no scalar load; everything but the odd row's lane offset is scalar arithmetic.
-    static_assert(FB_A == 4 && FB_MAXR == 40 && FB2_WAVES == 16, "pair assignment of the staging");
+    static_assert(BL_A == 3, "window words of a stage");
     const int jl = lane >> 5;
     const float *rc = r + (size_t)c2 * 128 + (lane & 31) * 4 + (size_t)jl * sx;
-    uint32_t wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0;
+    uint32_t wv0 = 0, wv1 = 0, wv2 = 0;
     if (lane < nstage) {
-        const int i0 = lane * FB_A;
+        const int i0 = lane * BL_A;
         wv0 = wn[i0];
         if (i0 + 1 < nproj) wv1 = wn[i0 + 1];
         if (i0 + 2 < nproj) wv2 = wn[i0 + 2];
-        if (i0 + 3 < nproj) wv3 = wn[i0 + 3];
     }
-#define BL_DMA1(S, A, WW, PAIR)                                                                           \
-    if ((uint32_t)(2 * (PAIR)) < ((WW) >> 16)) {                                                          \
-        if ((uint32_t)(2 * (PAIR) + jl) < ((WW) >> 16))                                                   \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rc + ((size_t)((S) * FB_A + (A)) * n + ((WW) & 0xFFFFu) + 2 * (PAIR)) * sx), \
-                                             (__attribute__((address_space(3))) void *)(fb2_lds + ((S) & 1) * (FB2_BUF / 16) + ((A) * FB_MAXR + 2 * (PAIR)) * (FB2_ROWB / 16)), 16, 0, 0); \
+#define BL_DMA1(S, K)                                                                                     \
+    if ((K) < BL_STAGE_PAIRS) {                                                                           \
+        const int a = (K) / BL_PAIRS, pr = (K) - a * BL_PAIRS;                                            \
+        const uint32_t ww = a == 0 ? w0 : a == 1 ? w1 : w2;                                               \
+        if ((uint32_t)(2 * pr) < (ww >> 16)) {                                                            \
+            if ((uint32_t)(2 * pr + jl) < (ww >> 16))                                                     \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rc + ((size_t)((S) * BL_A + a) * n + (ww & 0xFFFFu) + 2 * pr) * sx), \
+                                                 (__attribute__((address_space(3))) void *)(bl_lds + ((S) & 1) * (BL_BUF / 16) + (a * BL_MAXR + 2 * pr) * (BL_ROWB / 16)), 16, 0, 0); \
+        }                                                                                                 \
     }
 #define BL_STAGE_DMA(S)                                                                                   \
     {                                                                                                     \
-        const uint32_t w0 = __builtin_amdgcn_readlane(wv0, (S)), w1 = __builtin_amdgcn_readlane(wv1, (S)); \
-        const uint32_t w2 = __builtin_amdgcn_readlane(wv2, (S)), w3 = __builtin_amdgcn_readlane(wv3, (S)); \
-        BL_DMA1(S, 0, w0, wave) BL_DMA1(S, 1, w1, wave) BL_DMA1(S, 2, w2, wave) BL_DMA1(S, 3, w3, wave)   \
-        const int a5 = wave >> 2;                                                                         \
-        const uint32_t w5 = a5 == 0 ? w0 : a5 == 1 ? w1 : a5 == 2 ? w2 : w3;                              \
-        BL_DMA1(S, a5, w5, 16 + (wave & 3))                                                               \
+        const uint32_t w0 = __builtin_amdgcn_readlane(wv0, (S)), w1 = __builtin_amdgcn_readlane(wv1, (S)), w2 = __builtin_amdgcn_readlane(wv2, (S)); \
+        _Pragma("unroll") for (int q = 0; q < (BL_STAGE_PAIRS + BL_WAVES - 1) / BL_WAVES; ++q) { BL_DMA1(S, wave + BL_WAVES * q) } \
     }
     BL_STAGE_DMA(0)
     // The lists stream from HBM once and a scalar load has nobody to hide a miss behind: every wave touches the lines of its NEXT
     // list with one vector load a stage ahead (lane k: batch k of the list), so that the scalar loads hit the L2.
     // (the list bounds of all stages, one stage per lane, so that no stage starts behind a scalar miss: nstage <= 64)
-    const uint32_t *lp = lptr + (size_t)tile * nstage * FB2_WAVES + wave;
+    const uint32_t *lp = lptr + (size_t)tile * nstage * BL_WAVES + wave;
     uint32_t pv0 = 0, pv1 = 0;
-    if (lane < nstage) { pv0 = lp[(size_t)lane * FB2_WAVES]; pv1 = lp[(size_t)lane * FB2_WAVES + 1]; }
+    if (lane < nstage) { pv0 = lp[(size_t)lane * BL_WAVES]; pv1 = lp[(size_t)lane * BL_WAVES + 1]; }
 #define BL_TOUCH(S)                                                                                       \
     {                                                                                                     \
         const uint32_t t0 = __builtin_amdgcn_readlane(pv0, (S)), t1 = __builtin_amdgcn_readlane(pv1, (S)); \
@@ -1530,11 +1538,17 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_list(float *__restrict__ x, c
     }
     uint32_t touched = 0;
     BL_TOUCH(0)
+    // the column sums of the wave's pixels, pixel q in lane q (as scalar loads in the epilogue they were 32 misses in a row)
+    float csv = 0.f;
+    if (colsum && lane < BL_PPW) {
+        const int lpx = wave * BL_PPW + lane, y = ty * BL_TY + lpx / BL_TZ, z = tz * BL_TZ + lpx % BL_TZ;
+        if (y < n && z < n) csv = colsum[(size_t)y * n + z];
+    }
     v32f acc_lo, acc_hi;                                // pixel q of the wave: registers 2q, 2q+1 of v[64:127]
 #pragma unroll
     for (int q = 0; q < 32; ++q) { acc_lo[q] = 0.f; acc_hi[q] = 0.f; }
     // (the dynamic LDS block is the kernel's only one, so it starts at LDS address 0 and a row offset IS its address)
-    const uint32_t base = (uint32_t)lane * 8u, mask = ~(uint32_t)(FB2_ROWB - 1);
+    const uint32_t base = (uint32_t)lane * 8u, mask = ~(uint32_t)(BL_ROWB - 1);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
@@ -1560,7 +1574,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_list(float *__restrict__ x, c
                          "s_load_dwordx16 s[68:83], vcc, 0x80\n"
                          "s_load_dwordx16 s[84:99], vcc, 0xc0\n"
                          BL_READS(36)
-                         "s_waitcnt lgkmcnt(0)\n"
                          BL_FMAS(36)
                          "s_sub_u32 %[nb], %[nb], 1\n"
                          "s_cmp_eq_u32 %[nb], 0\n"
@@ -1574,7 +1587,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_list(float *__restrict__ x, c
                          "s_load_dwordx16 s[36:51], vcc, 0x0\n"
                          "s_load_dwordx16 s[52:67], vcc, 0x40\n"
                          BL_READS(68)
-                         "s_waitcnt lgkmcnt(0)\n"
                          BL_FMAS(68)
                          "s_sub_u32 %[nb], %[nb], 1\n"
                          "s_cmp_lg_u32 %[nb], 0\n"
@@ -1595,20 +1607,32 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_list(float *__restrict__ x, c
 #undef BL_STAGE_DMA
 #undef BL_DMA1
 #undef BL_TOUCH
+    // epilogue in two halves of 16 pixels: the 16 reads of x go out together (clamped addresses for pixels outside the image, so
+    // that no branch separates them), then pixel by pixel the update and the store
     const int off = c2 * 128 + lane * 2;
 #pragma unroll
-    for (int q = 0; q < FB2_PPW; ++q) {
-        const int lpx = wave * FB2_PPW + q;
-        const int y = ty * FT_TY + lpx / FT_TZ, z = tz * FT_TZ + lpx % FT_TZ;
-        if (y < n && z < n) {
-            const size_t p = (size_t)y * n + z;
-            v2f a = q < 16 ? v2f{acc_lo[2 * q], acc_lo[2 * q + 1]} : v2f{acc_hi[2 * (q & 15)], acc_hi[2 * (q & 15) + 1]};
-            if (colsum) { const float cs = colsum[p]; a = cs > 0.f ? a / cs : v2f{0.f, 0.f}; }
-            float *xp = x + p * sx + off;
-            v2f nv = beta * a;
-            if (alpha != 0.f) nv = bp_axpby(alpha, nt_ld<64>(reinterpret_cast<const v2f *>(xp)), beta, a);
-            if (clamp) { nv.x = fmaxf(nv.x, 0.f); nv.y = fmaxf(nv.y, 0.f); }
-            nt_st<64>(nv, reinterpret_cast<v2f *>(xp));
+    for (int h = 0; h < 2; ++h) {
+        v2f xv[16];
+        if (alpha != 0.f) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int lpx = wave * BL_PPW + h * 16 + k;
+                const int y = min(ty * BL_TY + lpx / BL_TZ, n - 1), z = min(tz * BL_TZ + lpx % BL_TZ, n - 1);
+                xv[k] = nt_ld<64>(reinterpret_cast<const v2f *>(x + ((size_t)y * n + z) * sx + off));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int q = h * 16 + k, lpx = wave * BL_PPW + q;
+            const int y = ty * BL_TY + lpx / BL_TZ, z = tz * BL_TZ + lpx % BL_TZ;
+            if (y < n && z < n) {
+                v2f a = h == 0 ? v2f{acc_lo[2 * k], acc_lo[2 * k + 1]} : v2f{acc_hi[2 * k], acc_hi[2 * k + 1]};
+                if (colsum) { const float cs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(csv), q)); a = cs > 0.f ? a / cs : v2f{0.f, 0.f}; }
+                v2f nv = beta * a;
+                if (alpha != 0.f) nv = bp_axpby(alpha, xv[k], beta, a);
+                if (clamp) { nv.x = fmaxf(nv.x, 0.f); nv.y = fmaxf(nv.y, 0.f); }
+                nt_st<64>(nv, reinterpret_cast<v2f *>(x + ((size_t)y * n + z) * sx + off));
+            }
         }
     }
 }

@@ -626,13 +626,34 @@ void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows
     const int TP = TY * TZ, ppw = TP / waves, nstage = (P + stage_angles - 1) / stage_angles;
     const uint32_t buf_bytes = (uint32_t)(stage_angles * max_rows) * (uint32_t)row_bytes;       // stage s sits in LDS buffer s & 1
     const size_t nlist = (size_t)ntiles * nstage * waves;
+    t.bl_ok = false;
+    t.bl_nbatch = 0;
+    t.bl_ptr.clear();
+    t.bl_win.assign((size_t)ntiles * P, 0);
     unsigned hw = builder_threads();
     int nth = (int)std::min<uint32_t>(std::max(1u, std::min(hw, 32u)), std::max(1u, ntiles / 8));
     std::vector<uint32_t> nb(nlist, 0);
-    // pass 0 counts the batches of every list, pass 1 (after the prefix sum) writes them
+    std::vector<uint8_t> bad(nth, 0);
+    // pass 0: the window {first ray | rays << 16} of every (tile, angle) and the batches of every list; pass 1 (after the prefix
+    // sum) writes the lists
     auto work = [&](int th, int pass) {
         for (uint32_t k = ntiles * (uint64_t)th / nth; k < ntiles * (uint64_t)(th + 1) / nth; ++k) {
             const int y0 = (int)(k / tiles_z) * TY, z0 = (int)(k % tiles_z) * TZ;
+            if (!pass)
+                for (int i = 0; i < P; ++i) {
+                    const Cell *ci = t.cell.data() + (size_t)i * npix;
+                    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                    for (int ly = 0; ly < TY && y0 + ly < N; ++ly)
+                        for (int lz = 0; lz < TZ && z0 + lz < N; ++lz) {
+                            const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
+                            if (c.w0 != 0.f) { lo = std::min(lo, c.r0); hi = std::max(hi, c.r0); }
+                            if (c.w1 != 0.f) { lo = std::min(lo, c.r1); hi = std::max(hi, c.r1); }
+                        }
+                    uint32_t nr = (lo == 0xFFFFFFFFu) ? 0u : hi - lo + 1;
+                    if (nr == 0) lo = 0;
+                    if (nr > (uint32_t)max_rows || lo > 0xFFFFu) { bad[th] = 1; nr = 0; }
+                    t.bl_win[(size_t)k * P + i] = lo | (nr << 16);
+                }
             for (int s = 0; s < nstage; ++s)
                 for (int w = 0; w < waves; ++w) {
                     const size_t li = ((size_t)k * nstage + s) * waves + w;
@@ -640,7 +661,7 @@ void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows
                     uint32_t cnt = 0;
                     for (int i = s * stage_angles; i < std::min(P, (s + 1) * stage_angles); ++i) {
                         const Cell *ci = t.cell.data() + (size_t)i * npix;
-                        const uint32_t lo = t.bp_win[(size_t)k * P + i] & 0xFFFFu;
+                        const uint32_t lo = t.bl_win[(size_t)k * P + i] & 0xFFFFu;
                         const uint32_t slot_base = (uint32_t)(s & 1) * buf_bytes + (uint32_t)(i % stage_angles) * (uint32_t)max_rows * (uint32_t)row_bytes;
                         for (int second = 0; second < 2; ++second)
                             for (int q = 0; q < ppw; ++q) {
@@ -672,15 +693,17 @@ void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows
         for (auto &x : thr) x.join();
     };
     run(0);
+    for (int th = 0; th < nth; ++th) if (bad[th]) return;              // a window the kernel's LDS cannot hold: the cell form stays
     t.bl_ptr.assign(nlist + 1, 0);
     uint64_t tot = 0;
     for (size_t i = 0; i < nlist; ++i) { t.bl_ptr[i] = (uint32_t)tot; tot += nb[i]; }
     t.bl_ptr[nlist] = (uint32_t)tot;
+    if (tot >= 0xFFFFFFFFull) { t.bl_ptr.clear(); return; }
     t.bl_nbatch = tot;
-    if (tot >= 0xFFFFFFFFull) { t.bl_nbatch = 0; t.bl_ptr.clear(); return; }        // (the kernel then stays with the cell form)
     t.bl_ent.reset(new uint64_t[(size_t)(tot + 1) * batch]);
     for (int j = 0; j < batch; ++j) t.bl_ent[(size_t)tot * batch + j] = 0;          // (prefetched behind the last list, never worked on)
     run(1);
+    t.bl_ok = true;
 }
 
 // Per-angle tile tables of the fused SART step (see sysmat.h); needs t.cell (build_tables).

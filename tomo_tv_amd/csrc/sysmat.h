@@ -71,6 +71,8 @@ struct Tables {
     // {byte offset in the staged windows (a multiple of row_bytes >= 256) | register index of q, weight} of every nonzero weight, angles ascending, within an
     // angle the first rays of the wave's pixels and then the second rays (so that a pixel's sum keeps the order of k_bp_all), padded
     // to whole batches with zero-weight entries into accumulator 0.  Stage s is staged in LDS buffer s & 1.
+    bool bl_ok = false;                          // false: some window exceeds max_rows, or too many batches (the cell form stays)
+    std::vector<uint32_t> bl_win;                // [ntiles * P]  first ray | rays << 16 (tiles of the LIST form's own size)
     std::unique_ptr<uint64_t[]> bl_ent;          // [bl_nbatch * batch + batch] (one batch of padding behind the last: the kernel prefetches)
     uint64_t bl_nbatch = 0;
     std::vector<uint32_t> bl_ptr;                // [ntiles * nstage * waves + 1] first batch of a list
@@ -140,7 +142,7 @@ void build_segments(int N, int P, int seg_len, Tables &t);
 void build_tiles(const Coo &m, int N, int P, int TY, int TZ, int pixel_bytes, Tables &t);
 void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, int pixel_bytes, Tables &t);
 void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t);
-// needs t.cell and t.bp_win (build_bp_tiles, bp_tile_ok); regs_per_pixel: accumulator registers of one pixel (index step)
+// needs t.cell (build_tables); regs_per_pixel: accumulator registers of one pixel (index step)
 void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int waves, int batch, int regs_per_pixel, Tables &t);
 bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Tables &t, std::string &why);   // nchunk: 64-slice chunks of the slab
 

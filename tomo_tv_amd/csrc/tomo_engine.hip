@@ -208,7 +208,8 @@ struct tomo_engine {
     int bp_list = 1;                              // ... in its entry-list form (k_bp_list) when the slab is whole pairs of 64-slice chunks
     bool attr_bp2 = false, bl_ok = false;
     uint2 *d_bl_ent = nullptr;                    // k_bp_list: entry batches and the first batch of every (tile, stage, wave) list
-    uint32_t *d_bl_ptr = nullptr;
+    uint32_t *d_bl_ptr = nullptr, *d_bl_win = nullptr;
+    int bl_tiles_z = 0, bl_ntiles = 0, bl_skew = 0;
     bool fb_ok = false;
     uint4 *d_fb_cell = nullptr;
     uint32_t *d_fb_win = nullptr;
@@ -809,16 +810,16 @@ static int launch_sart_coop(tomo_engine *e, const Sub &sb, float *x, int prev, i
 
 static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
 {
-    if (e->bp_tile && e->fb_ok && e->bl_ok && e->bp_list && e->sxc % 128 == 0) {     // entry lists: whole pairs of 64-slice chunks
+    if (e->bp_tile && e->bl_ok && e->bp_list && e->sxc % 128 == 0) {     // entry lists: whole pairs of 64-slice chunks
         if (!e->attr_bp2) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_bp_list, hipFuncAttributeMaxDynamicSharedMemorySize, FB2_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute((const void *)k_bp_list, hipFuncAttributeMaxDynamicSharedMemorySize, BL_LDS_BYTES));
             e->attr_bp2 = true;
         }
         const int nchunk2 = e->sxc / 128;
         ProfScope ps(e, TOMO_K_BP_TILE);
-        dim3 grid((unsigned)(8 * ((e->ft_ntiles + 7) / 8) * nchunk2)), block(FT_THREADS);
-        hipLaunchKernelGGL(k_bp_list, grid, block, FB2_LDS_BYTES, e->stream, x, e->d_bl_ent, e->d_bl_ptr, e->d_fb_win, r, colsum, alpha, beta, clamp,
-                           e->np, e->n, e->sx, e->ft_tiles_z, e->ft_ntiles, nchunk2);
+        dim3 grid((unsigned)(8 * ((e->bl_ntiles + 7) / 8) * nchunk2)), block(BL_THREADS);
+        hipLaunchKernelGGL(k_bp_list, grid, block, BL_LDS_BYTES, e->stream, x, e->d_bl_ent, e->d_bl_ptr, e->d_bl_win, r, colsum, alpha, beta, clamp,
+                           e->np, e->n, e->sx, e->bl_tiles_z, e->bl_ntiles, nchunk2, e->bl_skew);
         LAUNCHCHK();
         return TOMO_OK;
     }
@@ -1011,18 +1012,24 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             HIPCHK(hipMemcpy(e->d_fb_cell, t.bp_cell.data(), t.bp_cell.size() * sizeof(uint4), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_fb_win, t.bp_win.data(), t.bp_win.size() * 4, hipMemcpyHostToDevice));
             release(t.bp_cell);
-            lap("build_bp_tiles + upload");
-            build_bp_lists(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, FB2_ROWB, FB2_WAVES, BL_BATCH, 2, t);
-            e->bl_ok = t.bl_nbatch != 0 && (e->np + FB_A - 1) / FB_A <= 64;     // (k_bp_list keeps a stage's list bounds per lane)
-            if (e->bl_ok) {
-                const size_t nent = (size_t)(t.bl_nbatch + 1) * BL_BATCH;
-                if ((rc = dev_alloc((void **)&e->d_bl_ent, nent * sizeof(uint2), false, e->stream))) return rc;
-                if ((rc = dev_alloc((void **)&e->d_bl_ptr, t.bl_ptr.size() * 4, false, e->stream))) return rc;
-                HIPCHK(hipMemcpy(e->d_bl_ent, t.bl_ent.get(), nent * sizeof(uint2), hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(e->d_bl_ptr, t.bl_ptr.data(), t.bl_ptr.size() * 4, hipMemcpyHostToDevice));
-                t.bl_ent.reset();
-            }
         }
+        lap("build_bp_tiles + upload");
+        build_bp_lists(e->n, e->np, BL_TY, BL_TZ, BL_A, BL_MAXR, BL_ROWB, BL_WAVES, BL_BATCH, 2, t);
+        // (k_bp_list keeps a stage's list bounds and window words per lane; its staging offsets are 32-bit)
+        e->bl_ok = t.bl_ok && (e->np + BL_A - 1) / BL_A <= 64;
+        if (e->bl_ok) {
+            const size_t nent = (size_t)(t.bl_nbatch + 1) * BL_BATCH;
+            e->bl_tiles_z = (e->n + BL_TZ - 1) / BL_TZ;
+            e->bl_ntiles = ((e->n + BL_TY - 1) / BL_TY) * e->bl_tiles_z;
+            if ((rc = dev_alloc((void **)&e->d_bl_ent, nent * sizeof(uint2), false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_bl_ptr, t.bl_ptr.size() * 4, false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_bl_win, t.bl_win.size() * 4, false, e->stream))) return rc;
+            HIPCHK(hipMemcpy(e->d_bl_ent, t.bl_ent.get(), nent * sizeof(uint2), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_bl_ptr, t.bl_ptr.data(), t.bl_ptr.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_bl_win, t.bl_win.data(), t.bl_win.size() * 4, hipMemcpyHostToDevice));
+            t.bl_ent.reset();
+        }
+        release(t.bl_win); release(t.bl_ptr);
     }
     lap("build_bp_lists + upload");
     static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
@@ -1199,7 +1206,7 @@ int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const 
 static void free_geometry(tomo_engine *e)
 {
     void **ptrs[] = {(void **)&e->d_st_cell, (void **)&e->d_st_win, (void **)&e->d_st_segid, (void **)&e->d_st_seg, (void **)&e->d_st_ent,
-                     (void **)&e->d_st_row_first, (void **)&e->d_st_row_nseg, (void **)&e->st_partial, (void **)&e->st_partial2, (void **)&e->st_flags, (void **)&e->d_fb_cell, (void **)&e->d_fb_win, (void **)&e->d_bl_ent, (void **)&e->d_bl_ptr,
+                     (void **)&e->d_st_row_first, (void **)&e->d_st_row_nseg, (void **)&e->st_partial, (void **)&e->st_partial2, (void **)&e->st_flags, (void **)&e->d_fb_cell, (void **)&e->d_fb_win, (void **)&e->d_bl_ent, (void **)&e->d_bl_ptr, (void **)&e->d_bl_win,
                      (void **)&e->d_ft_slot_ptr, (void **)&e->d_ft_slot_seg0, (void **)&e->d_ft_tent, (void **)&e->d_ft_rsptr, (void **)&e->d_ft_rsidx,
                      (void **)&e->ft_part, (void **)&e->ft_part_aux, (void **)&e->cg_w, (void **)&e->fbp_h, (void **)&e->d_seg_exec,
                      (void **)&e->d_row_first, (void **)&e->d_row_nseg, (void **)&e->seg_partial, (void **)&e->d_wptr, (void **)&e->d_went,
@@ -2933,6 +2940,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_list") == 0) { e->bp_list = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "bp_list_skew") == 0) { e->bl_skew = value < 0 ? 0 : value; return TOMO_OK; }
     // all-angle FP form: "fp_strip" = 1 (default) sheared strips; asking for "fp_tile" = 1 / 0 explicitly selects the tile-stationary /
     // the ray-driven form (and takes the strips out of the way until "fp_strip" = 1 is set again)
     if (std::strcmp(name, "fp_strip") == 0) { e->fp_strip = value ? 1 : 0; return TOMO_OK; }

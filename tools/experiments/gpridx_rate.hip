@@ -17,7 +17,7 @@ __global__ __launch_bounds__(1024) void rate(float *out, int loops, uint32_t i0,
     __syncthreads();
     uint64_t e0 = ((uint64_t)__float_as_uint(w) << 32) | i0, e1 = ((uint64_t)__float_as_uint(w) << 32) | i1;
     uint32_t base = (threadIdx.x & 63) * 8;
-    for (int k = 0; k < loops; ++k) {
+    for (int k = 0; k < (VAR >= 4 ? 0 : loops); ++k) {
         if (VAR == 0)
             asm volatile(R16("v_pk_fma_f32 v[64:65], %1, v[32:33], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
                              "v_pk_fma_f32 v[70:71], %2, v[32:33], v[70:71] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n")
@@ -49,6 +49,34 @@ __global__ __launch_bounds__(1024) void rate(float *out, int loops, uint32_t i0,
                              "s_set_gpr_idx_off\n")
                          : "+{v[64:95]}"(acc) : "s"(e0), "s"(e1), "s"(i0), "s"(i1), "v"(base) : "v32", "v33", "v34", "v35", "s34", "s35", "memory");
     }
+    if (VAR >= 4) {
+        uint32_t mask = ~511u;
+#define RD(K, E) "v_and_or_b32 v[32+2*" #K "], " E ", %6, %5\n" DSR(K)
+#define FM(K, E, I, W) "s_waitcnt lgkmcnt(" #W ")\n s_set_gpr_idx_on " I ", gpr_idx(SRC2,DST)\n v_pk_fma_f32 v[64:65], " E ", v[32+2*" #K ":33+2*" #K "], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
+        for (int k = 0; k < loops; ++k) {
+            if (VAR == 4) {
+#define DSR(K) "ds_read_b64 v[32+2*" #K ":33+2*" #K "], v[32+2*" #K "]\n"
+            asm volatile(RD(0, "%3") RD(1, "%4") RD(2, "%3") RD(3, "%4") RD(4, "%3") RD(5, "%4") RD(6, "%3") RD(7, "%4")
+                         RD(8, "%3") RD(9, "%4") RD(10, "%3") RD(11, "%4") RD(12, "%3") RD(13, "%4") RD(14, "%3") RD(15, "%4")
+                         FM(0, "%1", "%3", 15) FM(1, "%2", "%4", 14) FM(2, "%1", "%3", 13) FM(3, "%2", "%4", 12) FM(4, "%1", "%3", 11) FM(5, "%2", "%4", 10) FM(6, "%1", "%3", 9) FM(7, "%2", "%4", 8)
+                         FM(8, "%1", "%3", 7) FM(9, "%2", "%4", 6) FM(10, "%1", "%3", 5) FM(11, "%2", "%4", 4) FM(12, "%1", "%3", 3) FM(13, "%2", "%4", 2) FM(14, "%1", "%3", 1) FM(15, "%2", "%4", 0)
+                         "s_set_gpr_idx_off\n"
+                         : "+{v[64:95]}"(acc) : "s"(e0), "s"(e1), "s"(i0), "s"(i1), "v"(base), "v"(mask)
+                         : "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","memory");
+#undef DSR
+            } else {
+#define DSR(K) ""
+            asm volatile(RD(0, "%3") RD(1, "%4") RD(2, "%3") RD(3, "%4") RD(4, "%3") RD(5, "%4") RD(6, "%3") RD(7, "%4")
+                         RD(8, "%3") RD(9, "%4") RD(10, "%3") RD(11, "%4") RD(12, "%3") RD(13, "%4") RD(14, "%3") RD(15, "%4")
+                         FM(0, "%1", "%3", 15) FM(1, "%2", "%4", 14) FM(2, "%1", "%3", 13) FM(3, "%2", "%4", 12) FM(4, "%1", "%3", 11) FM(5, "%2", "%4", 10) FM(6, "%1", "%3", 9) FM(7, "%2", "%4", 8)
+                         FM(8, "%1", "%3", 7) FM(9, "%2", "%4", 6) FM(10, "%1", "%3", 5) FM(11, "%2", "%4", 4) FM(12, "%1", "%3", 3) FM(13, "%2", "%4", 2) FM(14, "%1", "%3", 1) FM(15, "%2", "%4", 0)
+                         "s_set_gpr_idx_off\n"
+                         : "+{v[64:95]}"(acc) : "s"(e0), "s"(e1), "s"(i0), "s"(i1), "v"(base), "v"(mask)
+                         : "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","memory");
+#undef DSR
+            }
+        }
+    }
     float sum = 0.f;
     for (int i = 0; i < 32; ++i) sum += acc[i];
     out[blockIdx.x * 1024 + threadIdx.x] = sum;
@@ -57,7 +85,7 @@ int main()
 {
     float *out; hipMalloc(&out, 2048 * 1024 * 4);
     const int loops = 2000;
-    for (int var = 0; var < 4; ++var) {
+    for (int var = 0; var < 6; ++var) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(a);
@@ -65,6 +93,8 @@ int main()
             if (var == 1) hipLaunchKernelGGL(rate<1>, 2048, 1024, 0, 0, out, loops, 0u, 6u, 0.5f);
             if (var == 2) hipLaunchKernelGGL(rate<2>, 2048, 1024, 0, 0, out, loops, 0u, 6u, 0.5f);
             if (var == 3) hipLaunchKernelGGL(rate<3>, 2048, 1024, 0, 0, out, loops, 0u, 6u, 0.5f);
+            if (var == 4) hipLaunchKernelGGL(rate<4>, 2048, 1024, 0, 0, out, loops, 512u * 3, 512u * 7 + 6u, 0.5f);
+            if (var == 5) hipLaunchKernelGGL(rate<5>, 2048, 1024, 0, 0, out, loops, 512u * 3, 512u * 7 + 6u, 0.5f);
             hipEventRecord(b); hipEventSynchronize(b);
         }
         float ms; hipEventElapsedTime(&ms, a, b);
