@@ -420,6 +420,8 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     # which form projected: sheared strips (k_fp_strip; large slabs, round 4) or image tiles (k_fp_tile) -- both log under the same slot
     strip = bool(t.get_option("fp_strip_ready") and t.get_option("fp_strip"))
     fp_kernel = "k_fp_strip" if strip else "k_fp_tile"
+    bp_list = bool(t.get_option("bp_list_ready") and t.get_option("bp_list") and nx % 128 == 0)
+    bp_kernel = "k_bp_list" if bp_list else "k_bp_tile"
     # the other form, for the record (same engine, one option)
     t.set_option("fp_tile", 1) if strip else None
     ms_tile_form = _time_steps(t, lambda: (t.SIRT(1), t.data_distance()), 5) if strip else None
@@ -430,9 +432,12 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
         # all-angle FP = projection kernel + k_fp_tile_reduce (4V + 4S algorithmic); one entry = one FMA and one 4-byte LDS read per slice
         "roofline_fp_all": dict(roof(fp_kernel + "+k_fp_tile_reduce", 1, fp_ms, 4 * V + 4 * S, flops=2 * nnz * nx, lds_bytes=4 * nnz * nx),
                                 **{fp_kernel + "_avg_ms": avg("k_fp_tile"), "k_fp_tile_reduce_avg_ms": avg("k_fp_tile_reduce")}),
-        # all-angle BP (8V + 4S): two FMAs and two LDS row reads per pixel, angle and slice
-        "roofline_bp_all": roof("k_bp_tile", pr["k_bp_tile"][0], pr["k_bp_tile"][1], 8 * V + 4 * S, flops=4.0 * n * n * P * nx,
-                                lds_bytes=8.0 * n * n * P * nx, busy_ms=pr["k_bp_tile"][2])}
+        # all-angle BP (8V + 4S).  k_bp_list (round 4; logs under the k_bp_tile slot): one FMA and one LDS row read per NONZERO
+        # weight and slice; k_bp_tile: two FMAs and two row reads per pixel, angle and slice
+        "roofline_bp_all": roof(bp_kernel, pr["k_bp_tile"][0], pr["k_bp_tile"][1], 8 * V + 4 * S,
+                                flops=(2 * nnz if bp_list else 4.0 * n * n * P) * nx,
+                                lds_bytes=(4 * nnz if bp_list else 8.0 * n * n * P) * nx, busy_ms=pr["k_bp_tile"][2]),
+        "back_projector": bp_kernel}
     del t
     # ---- ASD-POCS in the CPU reference's form (cpu/sim_ASD.py:64-96: ART sweep + tv + 10 TV-GD steps + 3 norms) at 512^3 x 90
     from tomo_tv_amd.engine import ctvlib

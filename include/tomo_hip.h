@@ -281,6 +281,9 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "fp_tile_chunks_per_pass" (0): that number of 64-slice chunks per pass instead (0 = derived from the cap)
  *   "bp_tile" (1):    all-angle back-projection from LDS-staged residual-row windows (k_bp_tile; bit-identical to the
  *                     pixel-driven k_bp_all it replaces; used when every tile's ray window fits, else k_bp_all)
+ *   "bp_list" (1):    ... in its entry-list form (k_bp_list: one scalar-loaded entry per nonzero weight, accumulators picked by
+ *                     the VGPR index mode; same bits) when the engine built the lists ("bp_list_ready" of tomo_get_option) and
+ *                     the slab is a whole number of 128-slice pieces; 0 = k_bp_tile
  *   "fp_all_lpr" (16): ray-driven all-angle forward projection with 16 lanes x float4 per ray and 64-slice chunks
  *                     (0 = wide form)
  *   "fp_reuse" (1):   a tomo_sirt / tomo_sirt_data / tomo_cgls call whose volume is exactly what the model sinogram was last
@@ -293,7 +296,8 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "fp_tile_pipe" (0): experimental, P >= 2: the tile projector runs as P groups of 64-slice chunks, the reduce pass of one
  *                     group on a second stream beside the tile pass of the next (no gain measured) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
-/* read back a switch, or a fact about the engine: "fp_strip", "fp_tile", "bp_tile", "fp_reuse", "sart_tile", and
+/* read back a switch, or a fact about the engine: "fp_strip", "fp_tile", "bp_tile", "bp_list", "fp_reuse", "sart_tile", and
+ * "bp_list_ready" (1: the entry lists of k_bp_list were built: every tile's ray windows fit and there are at most 192 angles),
  * "fp_strip_ready" (1: the sheared-strip tables were built at creation -- by the slab-size rule or TOMO_FP_STRIP=1 -- so
  * "fp_strip" = 1 takes effect), "fp_strip_slots" (accumulator slots per lane group the strip kernel runs with),
  * "comm_rounds" (RCCL rounds -- one ncclGroup or one lone collective each -- this engine has enqueued since creation) */

@@ -1395,7 +1395,19 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
     FB_PUT(0) FB_PUT(1) FB_PUT(2) FB_PUT(3) FB_PUT(4) FB_PUT(5) FB_PUT(6) FB_PUT(7)
 #undef FB_PUT
     __syncthreads();
+    // the 8 column sums and the 8 reads of x go out together (clamped addresses for pixels outside the image, so that no branch
+    // separates them: one after the other they were 16 memory round trips in a row), then pixel by pixel the update and the store
     const int off = c * 64 + gl * 4;
+    float csv[8];
+    V xv[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        const int lp = g * 8 + J;
+        const int y = min(ty * FT_TY + lp / FT_TZ, n - 1), z = min(tz * FT_TZ + lp % FT_TZ, n - 1);
+        const size_t p = (size_t)y * n + z;
+        csv[J] = colsum ? colsum[p] : 1.f;
+        if (alpha != 0.f) xv[J] = nt_ld<64>(reinterpret_cast<const V *>(x + p * sx + off));
+    }
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
         int lp = g * 8 + J;
@@ -1403,10 +1415,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
         if (y < n && z < n) {
             size_t p = (size_t)y * n + z;
             V a = fb_lds[lp * 16 + gl];
-            if (colsum) { float cs = colsum[p]; a = cs > 0.f ? a / cs : vzero<4>(); }
+            if (colsum) { float cs = csv[J]; a = cs > 0.f ? a / cs : vzero<4>(); }
             float *xp = x + p * sx + off;
             V nv = beta * a;
-            if (alpha != 0.f) nv = bp_axpby(alpha, nt_ld<64>(reinterpret_cast<const V *>(xp)), beta, a);
+            if (alpha != 0.f) nv = bp_axpby(alpha, xv[J], beta, a);
             if (clamp) { nv[0] = fmaxf(nv[0], 0.f); nv[1] = fmaxf(nv[1], 0.f); nv[2] = fmaxf(nv[2], 0.f); nv[3] = fmaxf(nv[3], 0.f); }
             nt_st<64>(nv, reinterpret_cast<V *>(xp));
         }
@@ -1417,17 +1429,22 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
 // k_bp_tile shares a cell {row offset, weight} x 2 among the 16 lanes of a group by DPP rotation: 28 lane moves and 16 address adds
 // for every 8 pixels and angle, next to the 32 packed FMAs that do the work, and BOTH row reads of every pixel -- although a pixel has
 // a second ray of an angle in one case of four (the second read then fetches the zero row: 39 % of the LDS reads and of the FMAs).
-// Here a wave covers 128 slices (64 lanes x float2) and owns 32 pixels of the 32 x 16 tile (2 registers each: v[64:127]); what it
-// has to do in a stage of FB_A angles is a LIST of entries {window byte offset | accumulator register, weight}, one per NONZERO
-// weight (sysmat.cpp: build_bp_lists), fetched 16 at a time by scalar loads.  An entry costs one v_and_or_b32 (the address), one
-// ds_read_b64 and one v_pk_fma_f32 whose accumulator is picked by the VGPR index mode (s_set_gpr_idx_on: M0[7:0] is added to the
-// register number of src2 and dst), the weight being the scalar operand: no lane moves, no branches, no reads of zeros.  The loop is
-// one asm block on fixed registers (the index mode cannot be expressed otherwise): entries s[36:67] / s[68:99] (two sets: the next
-// batch is requested while the second half of this one is worked on; scalar loads return out of order with LDS reads, so they go out
-// only after the batch's last read has landed), rows v[32:63], list pointer in vcc.  The residual rows of a stage (<= 40 per angle,
-// 512 bytes each) are staged by LDS-DMA, the next stage into the other half of the LDS while this one is worked on (2 x 80 KB: all
-// of a CU's LDS; no registers, which the fixed blocks leave no room for).  A pixel's FMAs keep the order of k_bp_all (angles
+// Here a wave covers 128 slices (64 lanes x float2) and owns 32 pixels of a 16 x 16 tile (2 registers each: v[64:127]); what it
+// has to do in a stage of BL_A = 3 angles is a LIST of entries {window byte offset | accumulator register, weight}, one per NONZERO
+// weight (sysmat.cpp: build_bp_lists; 1.22 per pixel and angle), fetched 16 at a time by scalar loads.  An entry costs one
+// v_and_or_b32 (the address), one ds_read_b64 and one v_pk_fma_f32 whose accumulator is picked by the VGPR index mode
+// (s_set_gpr_idx_on: M0[7:0] is added to the register number of src2 and dst), the weight being the scalar operand: no lane moves,
+// no branches, no reads of zeros.  The loop is one asm block on fixed registers (the index mode cannot be expressed otherwise):
+// entries s[36:67] / s[68:99] (two sets: the scalar loads of the next batch go out before this batch's reads; a counted lgkmcnt
+// stays valid beside them, see BL_FMAS), rows v[32:63], list pointer in vcc.  The residual rows of a stage (<= 26 per angle,
+// 512 bytes each) are staged by LDS-DMA, the next stage into the other half of the workgroup's LDS while this one is worked on
+// (2 x 39 KB; no registers, which the fixed blocks leave no room for); 8 waves, two workgroups per CU.  The lists stream from HBM
+// once: a wave touches its next list with one vector load a stage ahead so that the scalar loads hit the L2, and the list bounds
+// and window words of all stages sit in registers (one stage per lane).  A pixel's FMAs keep the order of k_bp_all (angles
 // ascending, first ray before second); a skipped zero weight would have added +-0 to a sum that is never -0: bit-identical.
+// Measured at 512^3 x 90 (profiles/r04_bp_list_development.md): 1.01 ms against 1.35 ms for k_bp_tile; the entry work is bound by
+// vector-ALU issue (v_and_or_b32 and v_pk_fma_f32 are 4 cycles each: 9 cycles per entry and SIMD measured in isolation, 11 with the
+// LDS reads), the rest is the staging (DMA issue + the wait at the stage's end) and the epilogue.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v32f __attribute__((ext_vector_type(32)));
 constexpr int BL_TY = 16, BL_TZ = 16, BL_PIX = BL_TY * BL_TZ, BL_THREADS = 512, BL_WAVES = BL_THREADS / 64, BL_PPW = BL_PIX / BL_WAVES;
@@ -1436,15 +1453,7 @@ constexpr int BL_BUF = BL_A * BL_MAXR * BL_ROWB, BL_LDS_BYTES = 2 * BL_BUF;     
 constexpr int BL_PAIRS = BL_MAXR / 2, BL_STAGE_PAIRS = BL_A * BL_PAIRS;              // DMA pieces (row pairs) of an angle / a stage
 static_assert(BL_PPW == 32 && BL_MAXR % 2 == 0 && 2 * BL_LDS_BYTES <= 160 * 1024, "k_bp_list geometry");
 constexpr int BL_BATCH = 16;                            // entries per batch (two s_load_dwordx16)
-#ifndef BL_WHATIF
-#define BL_WHATIF 0                                     // timing experiments: 1 = the list pointer never advances, 2 = only stage 0 is staged, 4 = no LDS reads
-#endif
-
-#if BL_WHATIF & 4
-#define BL_DSREAD(K) ""
-#else
 #define BL_DSREAD(K) "ds_read_b64 v[32+2*" #K ":33+2*" #K "], v[32+2*" #K "]\n"
-#endif
 // entry K of the set that starts at SGPR SB: s[SB+2K] = row offset | register (rows are 512 bytes apart: the low 9 bits of the offset
 // are free; M0 takes the register from bits 7:0, the address is (entry & ~511) | 8 * lane), s[SB+2K+1] = weight; the row lands in
 // v[32+2K:33+2K]
@@ -1478,15 +1487,10 @@ constexpr int BL_BATCH = 16;                            // entries per batch (tw
 __global__ __launch_bounds__(BL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ win,
                const float *__restrict__ r, const float *__restrict__ colsum, float alpha, float beta, int clamp,
-               int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2, int skew)
+               int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2)
 {
     typedef VecOf<4>::T V;
     extern __shared__ V bl_lds[];
-    // Every workgroup does the same amount of work, so the ones that start together reach their epilogues (the only HBM traffic
-    // of the kernel: the tile of x, read and written) together: bursts the HBM serves while the CUs wait.  The workgroups of the
-    // first round start `skew` x (l mod 4) sleeps apart so that a CU's two workgroups stay out of phase.
-    if (skew > 0 && blockIdx.x < 4096u)
-        for (int k = ((blockIdx.x >> 3) & 3) * skew; k > 0; --k) __builtin_amdgcn_s_sleep(127);                       // [2][BL_A][BL_MAXR][32]: stage parity, slot (angle % 3), row of its window
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
     const int tile = (l / nchunk2) * 8 + xcd, c2 = l % nchunk2;
     if (tile >= ntiles) return;
@@ -1552,17 +1556,9 @@ void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
-#if (BL_WHATIF & 10) == 10
-#elif BL_WHATIF & 2
-        if (s + 1 < nstage) { BL_TOUCH(s + 1) }
-#else
         if (s + 1 < nstage) { BL_STAGE_DMA(s + 1) BL_TOUCH(s + 1) }
-#endif
         const uint32_t b0 = __builtin_amdgcn_readlane(pv0, s);
         uint32_t nb = __builtin_amdgcn_readlane(pv1, s) - b0;
-#if BL_WHATIF & 32
-        nb = 0;
-#endif
         if (nb != 0u) {
             const uint2 *ep = lent + (size_t)b0 * BL_BATCH;
             asm volatile("s_mov_b32 s33, m0\n"
@@ -1578,11 +1574,7 @@ void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint
                          "s_sub_u32 %[nb], %[nb], 1\n"
                          "s_cmp_eq_u32 %[nb], 0\n"
                          "s_cbranch_scc1 2f\n"
-#if BL_WHATIF & 1
-                         "s_add_u32 vcc_lo, vcc_lo, 0\n"
-#else
                          "s_add_u32 vcc_lo, vcc_lo, 0x100\n"
-#endif
                          "s_addc_u32 vcc_hi, vcc_hi, 0\n"
                          "s_load_dwordx16 s[36:51], vcc, 0x0\n"
                          "s_load_dwordx16 s[52:67], vcc, 0x40\n"
@@ -1599,10 +1591,7 @@ void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint
                          : BL_CLOBBERS);
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");     // this wave's pieces of the next stage have landed
-#if !(BL_WHATIF & 16)
-        __syncthreads();
-#endif
-        //                                       // ... everybody's have, and every wave is done with this stage's rows
+        __syncthreads();                                                    // ... everybody's have, and every wave is done with this stage's rows
     }
 #undef BL_STAGE_DMA
 #undef BL_DMA1

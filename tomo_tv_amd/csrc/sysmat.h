@@ -71,6 +71,7 @@ struct Tables {
     // {byte offset in the staged windows (a multiple of row_bytes >= 256) | register index of q, weight} of every nonzero weight, angles ascending, within an
     // angle the first rays of the wave's pixels and then the second rays (so that a pixel's sum keeps the order of k_bp_all), padded
     // to whole batches with zero-weight entries into accumulator 0.  Stage s is staged in LDS buffer s & 1.
+    static constexpr int BL_TY = 16, BL_TZ = 16, BL_WAVES = 8, BL_A = 3, BL_MAXR = 26, BL_ROWB = 512, BL_BATCH = 16, BL_REGS = 2;   // the geometry k_bp_list is built for
     bool bl_ok = false;                          // false: some window exceeds max_rows, or too many batches (the cell form stays)
     std::vector<uint32_t> bl_win;                // [ntiles * P]  first ray | rays << 16 (tiles of the LIST form's own size)
     std::unique_ptr<uint64_t[]> bl_ent;          // [bl_nbatch * batch + batch] (one batch of padding behind the last: the kernel prefetches)

@@ -209,7 +209,7 @@ struct tomo_engine {
     bool attr_bp2 = false, bl_ok = false;
     uint2 *d_bl_ent = nullptr;                    // k_bp_list: entry batches and the first batch of every (tile, stage, wave) list
     uint32_t *d_bl_ptr = nullptr, *d_bl_win = nullptr;
-    int bl_tiles_z = 0, bl_ntiles = 0, bl_skew = 0;
+    int bl_tiles_z = 0, bl_ntiles = 0;
     bool fb_ok = false;
     uint4 *d_fb_cell = nullptr;
     uint32_t *d_fb_win = nullptr;
@@ -819,7 +819,7 @@ static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *
         ProfScope ps(e, TOMO_K_BP_TILE);
         dim3 grid((unsigned)(8 * ((e->bl_ntiles + 7) / 8) * nchunk2)), block(BL_THREADS);
         hipLaunchKernelGGL(k_bp_list, grid, block, BL_LDS_BYTES, e->stream, x, e->d_bl_ent, e->d_bl_ptr, e->d_bl_win, r, colsum, alpha, beta, clamp,
-                           e->np, e->n, e->sx, e->bl_tiles_z, e->bl_ntiles, nchunk2, e->bl_skew);
+                           e->np, e->n, e->sx, e->bl_tiles_z, e->bl_ntiles, nchunk2);
         LAUNCHCHK();
         return TOMO_OK;
     }
@@ -1014,7 +1014,9 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             release(t.bp_cell);
         }
         lap("build_bp_tiles + upload");
-        build_bp_lists(e->n, e->np, BL_TY, BL_TZ, BL_A, BL_MAXR, BL_ROWB, BL_WAVES, BL_BATCH, 2, t);
+        static_assert(BL_TY == Tables::BL_TY && BL_TZ == Tables::BL_TZ && BL_WAVES == Tables::BL_WAVES && BL_A == Tables::BL_A && BL_MAXR == Tables::BL_MAXR &&
+                      BL_ROWB == Tables::BL_ROWB && BL_BATCH == Tables::BL_BATCH, "k_bp_list geometry (sysmat.h)");
+        build_bp_lists(e->n, e->np, BL_TY, BL_TZ, BL_A, BL_MAXR, BL_ROWB, BL_WAVES, BL_BATCH, Tables::BL_REGS, t);
         // (k_bp_list keeps a stage's list bounds and window words per lane; its staging offsets are 32-bit)
         e->bl_ok = t.bl_ok && (e->np + BL_A - 1) / BL_A <= 64;
         if (e->bl_ok) {
@@ -2940,7 +2942,6 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_list") == 0) { e->bp_list = value ? 1 : 0; return TOMO_OK; }
-    if (std::strcmp(name, "bp_list_skew") == 0) { e->bl_skew = value < 0 ? 0 : value; return TOMO_OK; }
     // all-angle FP form: "fp_strip" = 1 (default) sheared strips; asking for "fp_tile" = 1 / 0 explicitly selects the tile-stationary /
     // the ray-driven form (and takes the strips out of the way until "fp_strip" = 1 is set again)
     if (std::strcmp(name, "fp_strip") == 0) { e->fp_strip = value ? 1 : 0; return TOMO_OK; }
