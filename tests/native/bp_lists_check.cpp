@@ -1,9 +1,9 @@
 // Host-only check of the entry lists of the all-angle back-projector k_bp_list (sysmat.cpp: build_bp_lists).
-// Replays what the kernel does with the tables -- per (tile, stage, wave): whole batches of entries {window byte offset | accumulator
-// register, weight}, the offset resolved through the stage's staged windows (LDS buffer = stage parity, slot = angle % BL_A, row =
-// ray - first ray of the window), the accumulator through the wave's pixel numbering -- and requires that the entries are exactly
+// Replays what the kernel does with the tables -- per (tile, stage, wave): whole batches of PAIRS {window byte offset | accumulator
+// register, weight, accumulator register, weight} (two weights on one row, read once), the offset resolved through the stage's staged windows (LDS buffer = stage parity, slot = angle % BL_A, row =
+// ray - first ray of the window), the accumulator through the wave's pixel numbering (Tables::bl_pixel) -- and requires that the entries are exactly
 // the nonzero weights of the cell table: every (pixel, angle, ray) once, a pixel's entries in the order of k_bp_all (angles ascending,
-// first ray before second), padding only with weight 0 on a staged row.  In double precision on one slice it also compares the
+// first ray before second: rows ascend inside an angle), padding only with weight 0 on a staged row.  In double precision on one slice it also compares the
 // back projection with the plain CSR transpose product.
 // Usage: bp_lists_check N P max_abs_angle_deg [quiet]
 #include <cmath>
@@ -47,32 +47,40 @@ int main(int argc, char **argv)
                 const size_t li = ((size_t)k * nstage + s) * WAVES + w;
                 REQUIRE(t.bl_ptr[li] <= t.bl_ptr[li + 1], "list bounds");
                 int last_angle = -1;
-                for (size_t e = (size_t)t.bl_ptr[li] * BATCH; e < (size_t)t.bl_ptr[li + 1] * BATCH; ++e, ++slots) {
-                    const uint32_t e0 = (uint32_t)t.bl_ent[e], wb = (uint32_t)(t.bl_ent[e] >> 32);
-                    float wt; std::memcpy(&wt, &wb, 4);
-                    const uint32_t off = e0 & ~(uint32_t)(ROWB - 1), reg = e0 & (uint32_t)(ROWB - 1);
-                    REQUIRE(reg % REGS == 0 && reg / REGS < (uint32_t)PPW, "accumulator register %u", reg);
+                uint32_t last_ray = 0;
+                for (size_t pr = (size_t)t.bl_ptr[li] * BATCH; pr < (size_t)t.bl_ptr[li + 1] * BATCH; ++pr) {
+                    // one pair: {row offset | register 0, weight 0} {register 1, weight 1}, both weights on the SAME row
+                    const uint32_t e0 = (uint32_t)t.bl_ent[2 * pr];
+                    const uint32_t off = e0 & ~(uint32_t)(ROWB - 1);
                     const uint32_t buf = off / (A * MAXR * ROWB), in = off % (A * MAXR * ROWB), slot = in / (MAXR * ROWB), row = in % (MAXR * ROWB) / ROWB;
-                    REQUIRE(buf == (uint32_t)(s & 1), "entry of stage %d in LDS buffer %u", s, buf);
+                    REQUIRE(buf == (uint32_t)(s & 1), "pair of stage %d in LDS buffer %u", s, buf);
                     const int i = s * A + (int)slot;
-                    REQUIRE(i < P, "entry of an angle beyond the last");
+                    REQUIRE(i < P, "pair of an angle beyond the last");
                     const uint32_t win = t.bl_win[(size_t)k * P + i], lo = win & 0xFFFFu, nr = win >> 16;
                     REQUIRE(row < nr, "row %u outside the staged window of %u rows (tile %d angle %d)", row, nr, k, i);
-                    if (wt == 0.f) { REQUIRE(reg == 0, "padding must go to accumulator 0"); continue; }
-                    const int q = reg / REGS, lp = w * PPW + q, y = y0 + lp / TZ, z = z0 + lp % TZ;
-                    REQUIRE(y < N && z < N, "entry of a pixel outside the image");
-                    const int64_t p = (int64_t)y * N + z;
-                    const Cell &c = t.cell[(size_t)i * npix + p];
                     const uint32_t ray = lo + row;
-                    uint8_t &st = seen[(size_t)i * npix + p];
-                    REQUIRE(i >= last_angle, "angles of a list must ascend");
-                    last_angle = i;
-                    if (c.w0 != 0.f && st == 0 && ray == c.r0 && wt == c.w0) st = (c.w1 != 0.f) ? 1 : 2;
-                    else if (c.w1 != 0.f && st == (c.w0 != 0.f ? 1 : 0) && ray == c.r1 && wt == c.w1) st = 2;
-                    else REQUIRE(false, "entry (pixel %lld angle %d ray %u w %g) is not the next weight of its cell {%u %g %u %g} (state %d)",
-                                 (long long)p, i, ray, wt, c.r0, c.w0, c.r1, c.w1, (int)st);
-                    got[p] += (double)wt * r[(int64_t)i * N + ray];
-                    ++real;
+                    REQUIRE((uint32_t)(t.bl_ent[2 * pr + 1]) < (uint32_t)ROWB, "second half of a pair carries no offset");
+                    for (int h = 0; h < 2; ++h, ++slots) {
+                        const uint32_t reg = (uint32_t)t.bl_ent[2 * pr + h] & (uint32_t)(ROWB - 1), wb = (uint32_t)(t.bl_ent[2 * pr + h] >> 32);
+                        float wt; std::memcpy(&wt, &wb, 4);
+                        REQUIRE(reg % REGS == 0 && reg / REGS < (uint32_t)PPW, "accumulator register %u", reg);
+                        if (wt == 0.f) { REQUIRE(reg == 0, "padding must go to accumulator 0"); continue; }
+                        REQUIRE(i > last_angle || (i == last_angle && ray >= last_ray), "angles, and rows inside an angle, must ascend");
+                        last_angle = i; last_ray = ray;
+                        int ly, lz;
+                        Tables::bl_pixel(w, (int)(reg / REGS), ly, lz);
+                        const int y = y0 + ly, z = z0 + lz;
+                        REQUIRE(y < N && z < N, "entry of a pixel outside the image");
+                        const int64_t p = (int64_t)y * N + z;
+                        const Cell &c = t.cell[(size_t)i * npix + p];
+                        uint8_t &st = seen[(size_t)i * npix + p];
+                        if (c.w0 != 0.f && st == 0 && ray == c.r0 && wt == c.w0) st = (c.w1 != 0.f) ? 1 : 2;
+                        else if (c.w1 != 0.f && st == (c.w0 != 0.f ? 1 : 0) && ray == c.r1 && wt == c.w1) st = 2;
+                        else REQUIRE(false, "entry (pixel %lld angle %d ray %u w %g) is not the next weight of its cell {%u %g %u %g} (state %d)",
+                                     (long long)p, i, ray, wt, c.r0, c.w0, c.r1, c.w1, (int)st);
+                        got[p] += (double)wt * r[(int64_t)i * N + ray];
+                        ++real;
+                    }
                 }
             }
     }
@@ -89,8 +97,9 @@ int main(int argc, char **argv)
     double err = 0, nrm = 0;
     for (int64_t p = 0; p < npix; ++p) { err += (got[p] - want[p]) * (got[p] - want[p]); nrm += want[p] * want[p]; }
     REQUIRE(std::sqrt(err) <= 1e-12 * std::sqrt(nrm) + 1e-300, "back projection differs: %g", std::sqrt(err / (nrm + 1e-300)));
-    if (!quiet) std::printf("N %d P %d: %llu weights in %llu slots (padding %.1f %%), %.2f weights per pixel and angle\n", N, P, (unsigned long long)real,
-                            (unsigned long long)slots, 100.0 * (slots - real) / slots, (double)real / ((double)npix * P));
+    if (!quiet) std::printf("N %d P %d: %llu weights in %llu slots of %llu row reads (padding %.1f %%), %.2f weights per pixel and angle\n", N, P,
+                            (unsigned long long)real, (unsigned long long)slots, (unsigned long long)(slots / 2), 100.0 * (slots - real) / slots,
+                            (double)real / ((double)npix * P));
     std::printf("ok\n");
     return 0;
 }

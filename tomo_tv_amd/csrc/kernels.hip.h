@@ -1452,26 +1452,25 @@ constexpr int BL_A = 3, BL_MAXR = 26, BL_ROWB = 512;   // angles per stage, rows
 constexpr int BL_BUF = BL_A * BL_MAXR * BL_ROWB, BL_LDS_BYTES = 2 * BL_BUF;         // 79,872 bytes: two workgroups per CU
 constexpr int BL_PAIRS = BL_MAXR / 2, BL_STAGE_PAIRS = BL_A * BL_PAIRS;              // DMA pieces (row pairs) of an angle / a stage
 static_assert(BL_PPW == 32 && BL_MAXR % 2 == 0 && 2 * BL_LDS_BYTES <= 160 * 1024, "k_bp_list geometry");
-constexpr int BL_BATCH = 16;                            // entries per batch (two s_load_dwordx16)
-#define BL_DSREAD(K) "ds_read_b64 v[32+2*" #K ":33+2*" #K "], v[32+2*" #K "]\n"
-// entry K of the set that starts at SGPR SB: s[SB+2K] = row offset | register (rows are 512 bytes apart: the low 9 bits of the offset
-// are free; M0 takes the register from bits 7:0, the address is (entry & ~511) | 8 * lane), s[SB+2K+1] = weight; the row lands in
-// v[32+2K:33+2K]
+constexpr int BL_BATCH = 8;                             // pairs per batch (two s_load_dwordx16)
+// pixel q of wave w inside the tile (= Tables::bl_pixel, sysmat.h): waves own blocks of 8 x 4 pixels
+__device__ __forceinline__ int bl_ly(int w, int q) { return (w >> 2) * 8 + (q >> 2); }
+__device__ __forceinline__ int bl_lz(int w, int q) { return (w & 3) * 4 + (q & 3); }
+// pair K of the set that starts at SGPR SB: s[SB+4K] = row offset | register of its first pixel (rows are 512 bytes apart: the low
+// 9 bits of the offset are free; M0 takes the register from bits 7:0, the address is (entry & ~511) | 8 * lane), s[SB+4K+1] = that
+// pixel's weight, s[SB+4K+2] = register of the second pixel, s[SB+4K+3] = its weight; the row lands in v[32+2K:33+2K]
 #define BL_RD(SB, K)                                                                                      \
-    "v_and_or_b32 v[32+2*" #K "], s[" #SB "+2*" #K "], %[mask], %[base]\n"                                \
-    BL_DSREAD(K)
-#define BL_FMA(SB, K)                                                                                     \
-    "s_set_gpr_idx_on s[" #SB "+2*" #K "], gpr_idx(SRC2,DST)\n"                                           \
-    "v_pk_fma_f32 v[64:65], s[" #SB "+2*" #K ":" #SB "+2*" #K "+1], v[32+2*" #K ":33+2*" #K "], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
-#define BL_WFMA(SB, K, W) "s_waitcnt lgkmcnt(" #W ")\n" BL_FMA(SB, K)
-#define BL_READS(SB)                                                                                      \
-    BL_RD(SB, 0) BL_RD(SB, 1) BL_RD(SB, 2) BL_RD(SB, 3) BL_RD(SB, 4) BL_RD(SB, 5) BL_RD(SB, 6) BL_RD(SB, 7)             \
-    BL_RD(SB, 8) BL_RD(SB, 9) BL_RD(SB, 10) BL_RD(SB, 11) BL_RD(SB, 12) BL_RD(SB, 13) BL_RD(SB, 14) BL_RD(SB, 15)
-// (a counted wait stays valid with the scalar loads of the next batch in flight: lgkmcnt(15 - K) leaves at most 15 - K of the
-// 16 + 2 operations outstanding, so at least K + 1 LDS reads -- which return in order -- have landed whatever the scalar loads do)
+    "v_and_or_b32 v[32+2*" #K "], s[" #SB "+4*" #K "], %[mask], %[base]\n"                                \
+    "ds_read_b64 v[32+2*" #K ":33+2*" #K "], v[32+2*" #K "]\n"
+#define BL_FMA(SB, K, H)                                                                                  \
+    "s_set_gpr_idx_on s[" #SB "+4*" #K "+" #H "], gpr_idx(SRC2,DST)\n"                                    \
+    "v_pk_fma_f32 v[64:65], s[" #SB "+4*" #K "+" #H ":" #SB "+4*" #K "+" #H "+1], v[32+2*" #K ":33+2*" #K "], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
+#define BL_WFMA(SB, K, W) "s_waitcnt lgkmcnt(" #W ")\n" BL_FMA(SB, K, 0) BL_FMA(SB, K, 2)
+#define BL_READS(SB) BL_RD(SB, 0) BL_RD(SB, 1) BL_RD(SB, 2) BL_RD(SB, 3) BL_RD(SB, 4) BL_RD(SB, 5) BL_RD(SB, 6) BL_RD(SB, 7)
+// (a counted wait stays valid with the scalar loads of the next batch in flight: lgkmcnt(7 - K) leaves at most 7 - K of the
+// 8 + 2 operations outstanding, so at least K + 1 LDS reads -- which return in order -- have landed whatever the scalar loads do)
 #define BL_FMAS(SB)                                                                                       \
-    BL_WFMA(SB, 0, 15) BL_WFMA(SB, 1, 14) BL_WFMA(SB, 2, 13) BL_WFMA(SB, 3, 12) BL_WFMA(SB, 4, 11) BL_WFMA(SB, 5, 10) BL_WFMA(SB, 6, 9) BL_WFMA(SB, 7, 8) \
-    BL_WFMA(SB, 8, 7) BL_WFMA(SB, 9, 6) BL_WFMA(SB, 10, 5) BL_WFMA(SB, 11, 4) BL_WFMA(SB, 12, 3) BL_WFMA(SB, 13, 2) BL_WFMA(SB, 14, 1) BL_WFMA(SB, 15, 0) \
+    BL_WFMA(SB, 0, 7) BL_WFMA(SB, 1, 6) BL_WFMA(SB, 2, 5) BL_WFMA(SB, 3, 4) BL_WFMA(SB, 4, 3) BL_WFMA(SB, 5, 2) BL_WFMA(SB, 6, 1) BL_WFMA(SB, 7, 0) \
     "s_set_gpr_idx_off\n"
 #define BL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define BL_CLOBBERS                                                                                       \
@@ -1485,7 +1484,7 @@ constexpr int BL_BATCH = 16;                            // entries per batch (tw
     "vcc", "scc", "memory"
 
 __global__ __launch_bounds__(BL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ win,
+void k_bp_list(float *__restrict__ x, const uint4 *__restrict__ lent, const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ win,
                const float *__restrict__ r, const float *__restrict__ colsum, float alpha, float beta, int clamp,
                int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2)
 {
@@ -1545,7 +1544,7 @@ void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint
     // the column sums of the wave's pixels, pixel q in lane q (as scalar loads in the epilogue they were 32 misses in a row)
     float csv = 0.f;
     if (colsum && lane < BL_PPW) {
-        const int lpx = wave * BL_PPW + lane, y = ty * BL_TY + lpx / BL_TZ, z = tz * BL_TZ + lpx % BL_TZ;
+        const int y = ty * BL_TY + bl_ly(wave, lane), z = tz * BL_TZ + bl_lz(wave, lane);
         if (y < n && z < n) csv = colsum[(size_t)y * n + z];
     }
     v32f acc_lo, acc_hi;                                // pixel q of the wave: registers 2q, 2q+1 of v[64:127]
@@ -1560,7 +1559,7 @@ void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint
         const uint32_t b0 = __builtin_amdgcn_readlane(pv0, s);
         uint32_t nb = __builtin_amdgcn_readlane(pv1, s) - b0;
         if (nb != 0u) {
-            const uint2 *ep = lent + (size_t)b0 * BL_BATCH;
+            const uint4 *ep = lent + (size_t)b0 * BL_BATCH;
             asm volatile("s_mov_b32 s33, m0\n"
                          "s_mov_b64 vcc, %[ep]\n"
                          "s_load_dwordx16 s[36:51], vcc, 0x0\n"
@@ -1605,15 +1604,14 @@ void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint
         if (alpha != 0.f) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int lpx = wave * BL_PPW + h * 16 + k;
-                const int y = min(ty * BL_TY + lpx / BL_TZ, n - 1), z = min(tz * BL_TZ + lpx % BL_TZ, n - 1);
+                const int y = min(ty * BL_TY + bl_ly(wave, h * 16 + k), n - 1), z = min(tz * BL_TZ + bl_lz(wave, h * 16 + k), n - 1);
                 xv[k] = nt_ld<64>(reinterpret_cast<const v2f *>(x + ((size_t)y * n + z) * sx + off));
             }
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int q = h * 16 + k, lpx = wave * BL_PPW + q;
-            const int y = ty * BL_TY + lpx / BL_TZ, z = tz * BL_TZ + lpx % BL_TZ;
+            const int q = h * 16 + k;
+            const int y = ty * BL_TY + bl_ly(wave, q), z = tz * BL_TZ + bl_lz(wave, q);
             if (y < n && z < n) {
                 v2f a = h == 0 ? v2f{acc_lo[2 * k], acc_lo[2 * k + 1]} : v2f{acc_hi[2 * k], acc_hi[2 * k + 1]};
                 if (colsum) { const float cs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(csv), q)); a = cs > 0.f ? a / cs : v2f{0.f, 0.f}; }
@@ -1632,7 +1630,6 @@ void k_bp_list(float *__restrict__ x, const uint2 *__restrict__ lent, const uint
 #undef BL_WFMA
 #undef BL_FMA
 #undef BL_RD
-#undef BL_DSREAD
 
 // ---- ART (Kaczmarz), row-sequential by definition (ctvlib.cpp:137-155) -------------------------------
 // a = (b_j - A_j x)/|A_j|^2 ; x += A_j^T a beta, one row after the other: row j+1 shares pixels with row j, so

@@ -637,6 +637,8 @@ void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows
     // pass 0: the window {first ray | rays << 16} of every (tile, angle) and the batches of every list; pass 1 (after the prefix
     // sum) writes the lists
     auto work = [&](int th, int pass) {
+        struct Ent { uint32_t ray, q; float w; };
+        std::vector<Ent> ents;
         for (uint32_t k = ntiles * (uint64_t)th / nth; k < ntiles * (uint64_t)(th + 1) / nth; ++k) {
             const int y0 = (int)(k / tiles_z) * TY, z0 = (int)(k % tiles_z) * TZ;
             if (!pass)
@@ -648,6 +650,7 @@ void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows
                             const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
                             if (c.w0 != 0.f) { lo = std::min(lo, c.r0); hi = std::max(hi, c.r0); }
                             if (c.w1 != 0.f) { lo = std::min(lo, c.r1); hi = std::max(hi, c.r1); }
+                            if (c.w0 != 0.f && c.w1 != 0.f && c.r1 <= c.r0) bad[th] = 1;   // (rows are worked on in ascending order)
                         }
                     uint32_t nr = (lo == 0xFFFFFFFFu) ? 0u : hi - lo + 1;
                     if (nr == 0) lo = 0;
@@ -657,31 +660,42 @@ void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows
             for (int s = 0; s < nstage; ++s)
                 for (int w = 0; w < waves; ++w) {
                     const size_t li = ((size_t)k * nstage + s) * waves + w;
-                    uint64_t *out = pass ? t.bl_ent.get() + (size_t)t.bl_ptr[li] * batch : nullptr;
-                    uint32_t cnt = 0;
+                    uint64_t *out = pass ? t.bl_ent.get() + (size_t)t.bl_ptr[li] * batch * 2 : nullptr;
+                    uint32_t npair = 0, last_off = 0;
                     for (int i = s * stage_angles; i < std::min(P, (s + 1) * stage_angles); ++i) {
                         const Cell *ci = t.cell.data() + (size_t)i * npix;
                         const uint32_t lo = t.bl_win[(size_t)k * P + i] & 0xFFFFu;
                         const uint32_t slot_base = (uint32_t)(s & 1) * buf_bytes + (uint32_t)(i % stage_angles) * (uint32_t)max_rows * (uint32_t)row_bytes;
-                        for (int second = 0; second < 2; ++second)
-                            for (int q = 0; q < ppw; ++q) {
-                                const int lp = w * ppw + q, ly = lp / TZ, lz = lp % TZ;
-                                if (y0 + ly >= N || z0 + lz >= N) continue;
-                                const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
-                                const float wt = second ? c.w1 : c.w0;
-                                if (wt == 0.f) continue;
-                                if (pass) {
-                                    const uint32_t off = slot_base + ((second ? c.r1 : c.r0) - lo) * (uint32_t)row_bytes;
-                                    uint32_t wb;
-                                    std::memcpy(&wb, &wt, 4);
-                                    out[cnt] = ((uint64_t)wb << 32) | (uint64_t)(off | (uint32_t)(q * regs_per_pixel));
-                                }
-                                ++cnt;
+                        ents.clear();
+                        for (int q = 0; q < ppw; ++q) {
+                            int ly, lz;
+                            Tables::bl_pixel(w, q, ly, lz);
+                            if (y0 + ly >= N || z0 + lz >= N) continue;
+                            const Cell &c = ci[(int64_t)(y0 + ly) * N + z0 + lz];
+                            if (c.w0 != 0.f) ents.push_back({c.r0, (uint32_t)q, c.w0});
+                            if (c.w1 != 0.f) ents.push_back({c.r1, (uint32_t)q, c.w1});
+                        }
+                        // rows ascending (a pixel's first ray is its lower one), pixels ascending inside a row; a row's entries go out
+                        // in pairs that share one read of the row
+                        std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.ray < b.ray; });
+                        for (size_t j = 0; j < ents.size();) {
+                            const bool two = j + 1 < ents.size() && ents[j + 1].ray == ents[j].ray;
+                            if (pass) {
+                                const uint32_t off = slot_base + (ents[j].ray - lo) * (uint32_t)row_bytes;
+                                uint32_t w0b, w1b = 0, q1 = 0;
+                                std::memcpy(&w0b, &ents[j].w, 4);
+                                if (two) { std::memcpy(&w1b, &ents[j + 1].w, 4); q1 = ents[j + 1].q * regs_per_pixel; }
+                                out[2 * npair] = ((uint64_t)w0b << 32) | (uint64_t)(off | (ents[j].q * regs_per_pixel));
+                                out[2 * npair + 1] = ((uint64_t)w1b << 32) | (uint64_t)q1;
+                                last_off = off;
                             }
+                            ++npair;
+                            j += two ? 2 : 1;
+                        }
                     }
-                    const uint32_t batches = (cnt + batch - 1) / batch;
-                    // padding: weight 0 on the row of the list's last entry (staged, so finite), into accumulator 0
-                    if (pass) for (uint32_t j = cnt; j < batches * (uint32_t)batch; ++j) out[j] = out[cnt - 1] & (uint64_t)~(uint32_t)(row_bytes - 1);
+                    const uint32_t batches = (npair + batch - 1) / batch;
+                    // padding: weight 0 on the row of the list's last pair (staged, so finite), into accumulator 0
+                    if (pass) for (uint32_t j = npair; j < batches * (uint32_t)batch; ++j) { out[2 * j] = last_off; out[2 * j + 1] = 0; }
                     else nb[li] = batches;
                 }
         }
@@ -700,8 +714,8 @@ void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows
     t.bl_ptr[nlist] = (uint32_t)tot;
     if (tot >= 0xFFFFFFFFull) { t.bl_ptr.clear(); return; }
     t.bl_nbatch = tot;
-    t.bl_ent.reset(new uint64_t[(size_t)(tot + 1) * batch]);
-    for (int j = 0; j < batch; ++j) t.bl_ent[(size_t)tot * batch + j] = 0;          // (prefetched behind the last list, never worked on)
+    t.bl_ent.reset(new uint64_t[(size_t)(tot + 1) * batch * 2]);
+    for (int j = 0; j < batch * 2; ++j) t.bl_ent[(size_t)tot * batch * 2 + j] = 0;  // (prefetched behind the last list, never worked on)
     run(1);
     t.bl_ok = true;
 }

@@ -66,15 +66,19 @@ struct Tables {
     bool bp_tile_ok = false;                     // false: some window exceeds max_rows (kernel falls back)
     std::vector<uint32_t> bp_win;                // [ntiles * P]  first ray | rays << 16
     std::vector<TileCell> bp_cell;               // [(ntiles * P + pad) * TY*TZ], pixel order inside a tile: y-major
-    // The same matrix as entry LISTS of the wave-per-pixel-block form (k_bp_list): the tile's pixels are dealt to `waves` waves
-    // (pixel lp -> wave lp / ppw, accumulator q = lp % ppw); per (tile, stage of stage_angles angles, wave) the entries
-    // {byte offset in the staged windows (a multiple of row_bytes >= 256) | register index of q, weight} of every nonzero weight, angles ascending, within an
-    // angle the first rays of the wave's pixels and then the second rays (so that a pixel's sum keeps the order of k_bp_all), padded
-    // to whole batches with zero-weight entries into accumulator 0.  Stage s is staged in LDS buffer s & 1.
-    static constexpr int BL_TY = 16, BL_TZ = 16, BL_WAVES = 8, BL_A = 3, BL_MAXR = 26, BL_ROWB = 512, BL_BATCH = 16, BL_REGS = 2;   // the geometry k_bp_list is built for
+    // The same matrix as entry LISTS of the wave-per-pixel-block form (k_bp_list): a tile's pixels are dealt to `waves` waves in blocks
+    // of 8 x 4 (bl_pixel); per (tile, stage of stage_angles angles, wave) the nonzero weights of the wave's pixels, angles ascending,
+    // within an angle rows (rays) ascending -- a pixel's first ray is its lower one, so its sum keeps the order of k_bp_all -- as
+    // PAIRS that share one read of their row:  {byte offset of the row in the staged windows (a multiple of row_bytes >= 256) |
+    // register of pixel q0, weight 0, register of pixel q1, weight 1};  a row with an odd number of weights ends in a pair whose
+    // second weight is 0 (into accumulator 0); lists are padded to whole batches of `batch` pairs the same way.  Stage s is staged in
+    // LDS buffer s & 1.
+    static constexpr int BL_TY = 16, BL_TZ = 16, BL_WAVES = 8, BL_A = 3, BL_MAXR = 26, BL_ROWB = 512, BL_BATCH = 8, BL_REGS = 2;   // the geometry k_bp_list is built for
+    // pixel q (0..31) of wave w (0..7) inside the 16 x 16 tile: waves own 8 x 4 blocks (rows of a block share rays: 5.6 weights per ray)
+    static void bl_pixel(int w, int q, int &ly, int &lz) { ly = (w >> 2) * 8 + (q >> 2); lz = (w & 3) * 4 + (q & 3); }
     bool bl_ok = false;                          // false: some window exceeds max_rows, or too many batches (the cell form stays)
     std::vector<uint32_t> bl_win;                // [ntiles * P]  first ray | rays << 16 (tiles of the LIST form's own size)
-    std::unique_ptr<uint64_t[]> bl_ent;          // [bl_nbatch * batch + batch] (one batch of padding behind the last: the kernel prefetches)
+    std::unique_ptr<uint64_t[]> bl_ent;          // [(bl_nbatch + 1) * batch * 2] (one batch of padding behind the last: the kernel prefetches)
     uint64_t bl_nbatch = 0;
     std::vector<uint32_t> bl_ptr;                // [ntiles * nstage * waves + 1] first batch of a list
     // Per-angle tile tables of the fused SART step (k_sart_tile): tiles of st_ty x st_tz pixels, angle-major.

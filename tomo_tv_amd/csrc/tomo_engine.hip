@@ -207,7 +207,7 @@ struct tomo_engine {
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
     int bp_list = 1;                              // ... in its entry-list form (k_bp_list) when the slab is whole pairs of 64-slice chunks
     bool attr_bp2 = false, bl_ok = false;
-    uint2 *d_bl_ent = nullptr;                    // k_bp_list: entry batches and the first batch of every (tile, stage, wave) list
+    uint4 *d_bl_ent = nullptr;                    // k_bp_list: entry batches and the first batch of every (tile, stage, wave) list
     uint32_t *d_bl_ptr = nullptr, *d_bl_win = nullptr;
     int bl_tiles_z = 0, bl_ntiles = 0;
     bool fb_ok = false;
@@ -1023,10 +1023,10 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             const size_t nent = (size_t)(t.bl_nbatch + 1) * BL_BATCH;
             e->bl_tiles_z = (e->n + BL_TZ - 1) / BL_TZ;
             e->bl_ntiles = ((e->n + BL_TY - 1) / BL_TY) * e->bl_tiles_z;
-            if ((rc = dev_alloc((void **)&e->d_bl_ent, nent * sizeof(uint2), false, e->stream))) return rc;
+            if ((rc = dev_alloc((void **)&e->d_bl_ent, nent * sizeof(uint4), false, e->stream))) return rc;
             if ((rc = dev_alloc((void **)&e->d_bl_ptr, t.bl_ptr.size() * 4, false, e->stream))) return rc;
             if ((rc = dev_alloc((void **)&e->d_bl_win, t.bl_win.size() * 4, false, e->stream))) return rc;
-            HIPCHK(hipMemcpy(e->d_bl_ent, t.bl_ent.get(), nent * sizeof(uint2), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_bl_ent, t.bl_ent.get(), nent * sizeof(uint4), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_bl_ptr, t.bl_ptr.data(), t.bl_ptr.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_bl_win, t.bl_win.data(), t.bl_win.size() * 4, hipMemcpyHostToDevice));
             t.bl_ent.reset();
