@@ -419,7 +419,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     fp_ms = avg("k_fp_tile") + avg("k_fp_tile_reduce")
     # which form projected: sheared strips (k_fp_strip; large slabs, round 4) or image tiles (k_fp_tile) -- both log under the same slot
     strip = bool(t.get_option("fp_strip_ready") and t.get_option("fp_strip"))
-    fp_kernel = "k_fp_strip" if strip else "k_fp_tile"
+    fp_kernel = ("k_fp_list" if (t.get_option("fp_list_ready") and t.get_option("fp_list") and nx % 128 == 0) else "k_fp_strip") if strip else "k_fp_tile"
     bp_list = bool(t.get_option("bp_list_ready") and t.get_option("bp_list") and nx % 128 == 0)
     bp_kernel = "k_bp_list" if bp_list else "k_bp_tile"
     # the other form, for the record (same engine, one option)

@@ -293,10 +293,15 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "fp_strip" (1):   all-angle forward projection by sheared strips with the ray sums resident in registers (k_fp_strip) when the
  *                     engine built the strip tables (large slabs; "fp_strip_ready" of tomo_get_option); setting "fp_tile"
  *                     explicitly also sets "fp_strip" = 0, so that the tile / ray-driven forms can be selected
+ *   "fp_list" (1):    ... the strips as wave-uniform entry lists (k_fp_list: one angle per wave, one accumulator per ray picked by
+ *                     the VGPR index mode) when the engine built them ("fp_list_ready": where the strips are built and a tile's
+ *                     work spreads evenly enough over the waves; TOMO_FP_LIST = 0 / 1 overrides) and the slab is a whole number
+ *                     of 128-slice pieces; 0 = k_fp_strip
  *   "fp_tile_pipe" (0): experimental, P >= 2: the tile projector runs as P groups of 64-slice chunks, the reduce pass of one
  *                     group on a second stream beside the tile pass of the next (no gain measured) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
-/* read back a switch, or a fact about the engine: "fp_strip", "fp_tile", "bp_tile", "bp_list", "fp_reuse", "sart_tile", and
+/* read back a switch, or a fact about the engine: "fp_strip", "fp_list", "fp_tile", "bp_tile", "bp_list", "fp_reuse", "sart_tile", and
+ * "fp_list_ready" (1: the list form of the strips was built),
  * "bp_list_ready" (1: the entry lists of k_bp_list were built: every tile's ray windows fit and there are at most 192 angles),
  * "fp_strip_ready" (1: the sheared-strip tables were built at creation -- by the slab-size rule or TOMO_FP_STRIP=1 -- so
  * "fp_strip" = 1 takes effect), "fp_strip_slots" (accumulator slots per lane group the strip kernel runs with),

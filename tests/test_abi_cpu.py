@@ -162,6 +162,23 @@ def test_strip_tables_replay_the_matrix(tmp_path):
         assert r.returncode == 0 and r.stdout.rstrip().endswith("ok"), (N, P, amax, nchunk, r.stdout + r.stderr)
 
 
+def test_forward_projector_lists_replay_the_matrix(tmp_path):
+    """Host tables of the list form of the sheared-strip forward projector (sysmat.cpp: build_fp_lists), replayed on the CPU by
+    tests/native/fp_lists_check.cpp as k_fp_list walks them (tiles staged alternately into two buffers, per (tile, wave) entry
+    batches, then the flush records): every matrix entry in exactly one list, every accumulator clean when an item ends, every
+    partial sum written once and owned by one ray, forward = CSR product."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "flc")
+    src = [os.path.join(root, "tests", "native", "fp_lists_check.cpp"), os.path.join(root, "tomo_tv_amd", "csrc", "sysmat.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "tomo_tv_amd", "csrc"), *src, "-lpthread", "-o", exe],
+                   check=True)
+    for N, P, amax in [(50, 9, 89.0), (96, 17, 70.0), (33, 4, 45.0), (7, 3, 60.0), (64, 1, 0.0), (16, 5, 70.0), (129, 12, 80.0), (256, 60, 70.0),
+                       (200, 40, 70.0)]:
+        r = subprocess.run([exe, str(N), str(P), str(amax), "q"], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.rstrip().endswith("ok"), (N, P, amax, r.stdout + r.stderr)
+
+
 def test_back_projector_lists_replay_the_matrix(tmp_path):
     """Host tables of the entry-list back-projector (sysmat.cpp: build_bp_lists), replayed on the CPU by tests/native/bp_lists_check.cpp
     as k_bp_list walks them: every nonzero weight of the cell table exactly once, in the pixel's order of k_bp_all, its row inside the

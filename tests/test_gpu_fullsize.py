@@ -119,21 +119,25 @@ def test_strip_projector_equals_tile_form_at_full_size(big):
     if not t.get_option("fp_strip_ready"):
         pytest.skip("the engine built no strip tables for this slab (slab-size rule)")
     out = {}
-    for strip in (1, 0):
-        if strip:
-            t.set_option("fp_strip", 1)
-        else:
+    forms = (["list"] if t.get_option("fp_list_ready") else []) + ["strip", "tile"]   # (k_fp_list: the strips as wave-uniform entry lists)
+    for form in forms:
+        if form == "tile":
             t.set_option("fp_tile", 1)
+        else:
+            t.set_option("fp_strip", 1)
+            t.set_option("fp_list", 1 if form == "list" else 0)
         t.restart_recon()
         t.create_projections()
         b = t.get_projections()
         t.SIRT(2)
-        out[strip] = (b, t.get_volume(), t.data_distance())
+        out[form] = (b, t.get_volume(), t.data_distance())
     t.set_option("fp_strip", 1)
+    t.set_option("fp_list", 1)
     t.create_projections()                      # the fixture's tilt series as the default form makes it
     t.restart_recon()
-    assert rel_l2(out[1][0], out[0][0]) < 1e-6
-    assert rel_l2(out[1][1], out[0][1]) < 2e-6 and abs(out[1][2] - out[0][2]) <= 1e-5 * out[0][2]
+    for form in forms[:-1]:
+        assert rel_l2(out[form][0], out["tile"][0]) < 1e-6, form
+        assert rel_l2(out[form][1], out["tile"][1]) < 2e-6 and abs(out[form][2] - out["tile"][2]) <= 1e-5 * out["tile"][2], form
 
 
 @pytest.fixture(scope="module", params=[(512, 512), (128, 1024)], ids=["config3_512cube", "config4_shard_128x1024sq"])

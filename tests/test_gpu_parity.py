@@ -903,13 +903,16 @@ def test_strip_forward_projector_matches_tile_and_row_forms(gpu, monkeypatch, N,
     the tile-stationary and the ray-driven forms: the same matrix entries summed in a different order (<= 1e-6), in every epilogue
     mode the reduce kernel has (store, normalised residual inside SIRT, data distance, Poisson step), and against the oracle."""
     monkeypatch.setenv("TOMO_FP_STRIP", "1")        # (the engine builds the strip tables by itself only for large slabs)
+    monkeypatch.setenv("TOMO_FP_LIST", "1")         # ... and their wave-uniform list form (k_fp_list; runs where the slab is whole 128-slice pieces)
     ang = np.linspace(-amax, amax + 1.5, P) if P > 1 else np.array([17.0])
     x = ellipsoids(Nx, N, seed=5)
     out = {}
-    for form in ("strip", "tile", "rows"):
+    for form in ("list", "strip", "tile", "rows"):
         t = tomoengine(Nx, N, ang * np.pi / 180)
-        assert t.get_option("fp_strip_ready") == 1
-        if form != "strip":
+        assert t.get_option("fp_strip_ready") == 1 and t.get_option("fp_list_ready") == 1
+        if form == "strip":
+            t.set_option("fp_list", 0)
+        elif form != "list":
             t.set_option("fp_tile", 1 if form == "tile" else 0)
         t.set_volume(x, VOL_ORIGINAL)
         t.create_projections()
@@ -921,6 +924,9 @@ def test_strip_forward_projector_matches_tile_and_row_forms(gpu, monkeypatch, N,
         t.restart_recon()
         cost = t.poisson_ML(0.7)
         out[form] = (b, v, dd, t.get_volume(), cost)
+    for k in range(5):                              # the list form against the strip form
+        a, b = out["list"][k], out["strip"][k]
+        assert (rel_l2(a, b) < 1e-6) if isinstance(a, np.ndarray) else (abs(a - b) <= 1e-5 * abs(b)), k
     for other in ("tile", "rows"):
         assert rel_l2(out["strip"][0], out[other][0]) < 1e-6, other
         assert rel_l2(out["strip"][1], out[other][1]) < 1e-5, other
@@ -932,6 +938,7 @@ def test_strip_forward_projector_matches_tile_and_row_forms(gpu, monkeypatch, N,
     ref.original_volume = x.copy()
     ref.create_projections()
     assert rel_l2(out["strip"][0], ref.b) < 1e-6
+    assert rel_l2(out["list"][0], ref.b) < 1e-6
 
 
 @pytest.mark.parametrize("N,P,Nx", [(40, 7, 70), (100, 9, 128), (16, 1, 64)])

@@ -1631,6 +1631,193 @@ void k_bp_list(float *__restrict__ x, const uint4 *__restrict__ lent, const uint
 #undef BL_FMA
 #undef BL_RD
 
+// ---- forward projector, all angles, sheared strips with WAVE-UNIFORM entry lists (round 4) -------------------------------------------
+// The strip decomposition of k_fp_strip (passes of neighbouring angles, strips of 16 pixels sheared with the pass's mean direction,
+// march segments; sysmat.cpp: build_fp_lists) with the machinery of k_bp_list: a wave covers 128 slices (64 lanes x float2) and owns
+// the rays of ONE angle of the pass, ray j in accumulator j mod 32 (v[64:127]); per tile of 8 march steps (16 x 8 pixels x 512 B,
+// staged by LDS-DMA into one half of the LDS while the other is worked on; pixels outside the image read zeros) it works through a
+// list of entries {byte offset of the pixel in the staged tiles | accumulator register, weight} -- one v_and_or_b32, one ds_read_b64
+// and one v_pk_fma_f32 into the accumulator M0 picks, no lane moves and no per-lane entry loads -- and then through the tile's flush
+// records {accumulator register, partial-sum id}: the sums of the rays that leave the strip here are stored (read through the index
+// mode as well) and cleared.  16 waves (up to 16 angles of a pass side by side), one workgroup per CU.  A ray's entries keep their
+// order, so a partial sum is the same FMA chain as in k_fp_strip; k_fp_tile_reduce adds a ray's partial sums in ascending strip order.
+constexpr int FL_W = 16, FL_TH = 8, FL_PIX = FL_W * FL_TH, FL_THREADS = 1024, FL_WAVES = FL_THREADS / 64, FL_BATCH = 16, FL_PIXB = 512;
+constexpr int FL_TILE_BYTES = 2 * FL_PIX * FL_PIXB, FL_MAXSTEPS = 64 * FL_TH, FL_LDS_BYTES = FL_TILE_BYTES + FL_MAXSTEPS * 4;
+struct FlItemD { int pass, v0; uint32_t tile0, ntiles, lp0, work, pad0, pad1; };
+
+#define FL_RD(SB, K)                                                                                      \
+    "v_and_or_b32 v[32+2*" #K "], s[" #SB "+2*" #K "], %[mask], %[base]\n"                                \
+    "ds_read_b64 v[32+2*" #K ":33+2*" #K "], v[32+2*" #K "]\n"
+#define FL_FMA(SB, K, W)                                                                                  \
+    "s_waitcnt lgkmcnt(" #W ")\n"                                                                         \
+    "s_set_gpr_idx_on s[" #SB "+2*" #K "], gpr_idx(SRC2,DST)\n"                                           \
+    "v_pk_fma_f32 v[64:65], s[" #SB "+2*" #K ":" #SB "+2*" #K "+1], v[32+2*" #K ":33+2*" #K "], v[64:65] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
+#define FL_READS(SB)                                                                                      \
+    FL_RD(SB, 0) FL_RD(SB, 1) FL_RD(SB, 2) FL_RD(SB, 3) FL_RD(SB, 4) FL_RD(SB, 5) FL_RD(SB, 6) FL_RD(SB, 7)             \
+    FL_RD(SB, 8) FL_RD(SB, 9) FL_RD(SB, 10) FL_RD(SB, 11) FL_RD(SB, 12) FL_RD(SB, 13) FL_RD(SB, 14) FL_RD(SB, 15)
+#define FL_FMAS(SB)                                                                                       \
+    FL_FMA(SB, 0, 15) FL_FMA(SB, 1, 14) FL_FMA(SB, 2, 13) FL_FMA(SB, 3, 12) FL_FMA(SB, 4, 11) FL_FMA(SB, 5, 10) FL_FMA(SB, 6, 9) FL_FMA(SB, 7, 8) \
+    FL_FMA(SB, 8, 7) FL_FMA(SB, 9, 6) FL_FMA(SB, 10, 5) FL_FMA(SB, 11, 4) FL_FMA(SB, 12, 3) FL_FMA(SB, 13, 2) FL_FMA(SB, 14, 1) FL_FMA(SB, 15, 0) \
+    "s_set_gpr_idx_off\n"
+#define FL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
+#define FL_CLOBBERS                                                                                       \
+    FL_CLOB4(s, 36, 37, 38, 39), FL_CLOB4(s, 40, 41, 42, 43), FL_CLOB4(s, 44, 45, 46, 47), FL_CLOB4(s, 48, 49, 50, 51),      \
+    FL_CLOB4(s, 52, 53, 54, 55), FL_CLOB4(s, 56, 57, 58, 59), FL_CLOB4(s, 60, 61, 62, 63), FL_CLOB4(s, 64, 65, 66, 67),      \
+    FL_CLOB4(s, 68, 69, 70, 71), FL_CLOB4(s, 72, 73, 74, 75), FL_CLOB4(s, 76, 77, 78, 79), FL_CLOB4(s, 80, 81, 82, 83),      \
+    FL_CLOB4(s, 84, 85, 86, 87), FL_CLOB4(s, 88, 89, 90, 91), FL_CLOB4(s, 92, 93, 94, 95), FL_CLOB4(s, 96, 97, 98, 99),      \
+    "s33",                                                                                                \
+    FL_CLOB4(v, 32, 33, 34, 35), FL_CLOB4(v, 36, 37, 38, 39), FL_CLOB4(v, 40, 41, 42, 43), FL_CLOB4(v, 44, 45, 46, 47),      \
+    FL_CLOB4(v, 48, 49, 50, 51), FL_CLOB4(v, 52, 53, 54, 55), FL_CLOB4(v, 56, 57, 58, 59), FL_CLOB4(v, 60, 61, 62, 63),      \
+    "vcc", "scc", "memory"
+
+__global__ __launch_bounds__(FL_THREADS)
+void k_fp_list(const float *__restrict__ x, const FlItemD *__restrict__ items, const int *__restrict__ orient, const int *__restrict__ shift,
+               const uint2 *__restrict__ lent, const uint32_t *__restrict__ lptr, const uint2 *__restrict__ fent, const uint32_t *__restrict__ fptr,
+               float *__restrict__ part, int n, int sx, int nitems, int cpair0, int ncpp, int ncp, const float *__restrict__ zero)
+{
+    typedef VecOf<4>::T V;
+    extern __shared__ V fl_lds[];                       // [2][FL_PIX][32]: tile parity, pixel, 512 bytes; then the item's shifts
+    // all 128-slice pieces of an item run back to back on one XCD (workgroups b and b+8 share an XCD): they read the same tables
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int it = (l / ncpp) * 8 + xcd, c2 = l % ncpp;
+    if (it >= nitems) return;
+    const FlItemD I = items[it];
+    const int t = threadIdx.x, lane = t & 63, jl = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int o = orient[I.pass];
+    const int ntiles = (int)I.ntiles;
+    int *sh_l = reinterpret_cast<int *>(reinterpret_cast<char *>(fl_lds) + FL_TILE_BYTES);
+    {
+        const int *sh = shift + (size_t)I.pass * n;
+        for (int i = t; i < ntiles * FL_TH; i += FL_THREADS) sh_l[i] = sh[min((int)I.tile0 * FL_TH + i, n - 1)];
+    }
+    const float *xc = x + (size_t)(cpair0 + c2) * 128 + (lane & 31) * 4;
+    const float *zsrc = zero + (lane & 31) * 4;
+    // the list and flush-list bounds of all tiles, one tile per lane (ntiles <= 64)
+    const uint32_t *lp = lptr + I.lp0 + wave, *fp = fptr + I.lp0 + wave;
+    uint32_t pv0 = 0, pv1 = 0, fv0 = 0, fv1 = 0;
+    if (lane < ntiles) {
+        pv0 = lp[(size_t)lane * FL_WAVES]; pv1 = lp[(size_t)lane * FL_WAVES + 1];
+        fv0 = fp[(size_t)lane * FL_WAVES]; fv1 = fp[(size_t)lane * FL_WAVES + 1];
+    }
+    __syncthreads();                                    // the shifts are in place
+    // One DMA instruction moves 64 x 16 bytes = the 512-byte images of two neighbouring pixels (lanes 0-31 the even one); a tile has
+    // 64 such pairs, wave w moves pairs w, w + 16, w + 32, w + 48 (pair p = pixels 2p, 2p + 1 of march step p / 8)
+#define FL_STAGE(TT)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < FL_PIX / 2 / FL_WAVES; ++q) {                                   \
+        const int p = wave + FL_WAVES * q;                                                                \
+        const int lu = p >> 3, u = ((int)I.tile0 + (TT)) * FL_TH + lu;                                    \
+        const int vv = I.v0 + sh_l[(TT) * FL_TH + lu] + 2 * (p & 7) + jl;                                 \
+        const bool ok = u < n && (unsigned)vv < (unsigned)n;                                              \
+        const size_t pix = o ? (size_t)vv * n + u : (size_t)u * n + vv;                                   \
+        const float *src = ok ? xc + pix * sx : zsrc;                                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,             \
+                                         (__attribute__((address_space(3))) void *)(fl_lds + (((TT) & 1) * FL_PIX + 2 * p) * (FL_PIXB / 16)), 16, 0, 0); \
+    }
+#define FL_TOUCH(TT)                                                                                      \
+    {                                                                                                     \
+        const uint32_t t0 = __builtin_amdgcn_readlane(pv0, (TT)), t1 = __builtin_amdgcn_readlane(pv1, (TT)); \
+        if (t0 + lane < t1) touched = *reinterpret_cast<const uint32_t *>(lent + (size_t)(t0 + lane) * FL_BATCH);   /* (a list of > 64 batches is touched in part) */ \
+    }
+    uint32_t touched = 0;
+    FL_STAGE(0)
+    FL_TOUCH(0)
+    v32f acc_lo, acc_hi;                                // ray j of the wave's angle: registers 2 (j mod 32), + 1 of v[64:127]
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { acc_lo[q] = 0.f; acc_hi[q] = 0.f; }
+    // (the dynamic LDS block is the kernel's only one, so it starts at LDS address 0 and a pixel's offset IS its address)
+    const uint32_t base = (uint32_t)lane * 8u, mask = ~(uint32_t)(FL_PIXB - 1);
+    // partial sum `id` of this 128-slice piece: part[(id * ncp + 2 c2) * 64 + 2 lane]
+    const uint64_t pb = (uint64_t)(size_t)(part + (size_t)c2 * 128);
+    const uint32_t pb_lo = (uint32_t)pb, pb_hi = (uint32_t)(pb >> 32), pstride = (uint32_t)ncp * 256u;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");
+    __syncthreads();
+    for (int tt = 0; tt < ntiles; ++tt) {
+        if (tt + 1 < ntiles) { FL_STAGE(tt + 1) FL_TOUCH(tt + 1) }
+        const uint32_t b0 = __builtin_amdgcn_readlane(pv0, tt);
+        uint32_t nb = __builtin_amdgcn_readlane(pv1, tt) - b0;
+        {   // (an empty list is skipped inside the block: a branch around it would make the accumulators merge values, i.e. copies)
+            const uint2 *ep = lent + (size_t)b0 * FL_BATCH;
+            asm volatile("s_cmp_eq_u32 %[nb], 0\n"
+                         "s_cbranch_scc1 3f\n"
+                         "s_mov_b32 s33, m0\n"
+                         "s_mov_b64 vcc, %[ep]\n"
+                         "s_load_dwordx16 s[36:51], vcc, 0x0\n"
+                         "s_load_dwordx16 s[52:67], vcc, 0x40\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "1:\n"
+                         "s_load_dwordx16 s[68:83], vcc, 0x80\n"
+                         "s_load_dwordx16 s[84:99], vcc, 0xc0\n"
+                         FL_READS(36)
+                         FL_FMAS(36)
+                         "s_sub_u32 %[nb], %[nb], 1\n"
+                         "s_cmp_eq_u32 %[nb], 0\n"
+                         "s_cbranch_scc1 2f\n"
+                         "s_add_u32 vcc_lo, vcc_lo, 0x100\n"
+                         "s_addc_u32 vcc_hi, vcc_hi, 0\n"
+                         "s_load_dwordx16 s[36:51], vcc, 0x0\n"
+                         "s_load_dwordx16 s[52:67], vcc, 0x40\n"
+                         FL_READS(68)
+                         FL_FMAS(68)
+                         "s_sub_u32 %[nb], %[nb], 1\n"
+                         "s_cmp_lg_u32 %[nb], 0\n"
+                         "s_cbranch_scc1 1b\n"
+                         "2:\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "s_mov_b32 m0, s33\n"
+                         "3:\n"
+                         : "+{v[64:95]}"(acc_lo), "+{v[96:127]}"(acc_hi), [nb] "+s"(nb)
+                         : [ep] "s"(ep), [base] "v"(base), [mask] "v"(mask)
+                         : FL_CLOBBERS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");     // this wave's pieces of the next tile have landed (waited for before the flush, so that
+        // the flush's stores are not: they have the whole next tile to complete)
+        const uint32_t f0 = __builtin_amdgcn_readlane(fv0, tt);
+        uint32_t nf = __builtin_amdgcn_readlane(fv1, tt) - f0;
+        {   // the rays that leave the strip in this tile: accumulator (read through the index mode) -> partial sum, accumulator cleared
+            const uint2 *fr = fent + f0;
+            asm volatile("s_cmp_eq_u32 %[nf], 0\n"
+                         "s_cbranch_scc1 3f\n"
+                         "s_mov_b32 s33, m0\n"
+                         "s_mov_b64 vcc, %[fr]\n"
+                         "1:\n"
+                         "s_load_dwordx2 s[36:37], vcc, 0x0\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "s_set_gpr_idx_on s36, gpr_idx(SRC0)\n"
+                         "v_mov_b32 v32, v64\n"
+                         "v_mov_b32 v33, v65\n"
+                         "s_set_gpr_idx_on s36, gpr_idx(DST)\n"
+                         "v_mov_b32 v64, 0\n"
+                         "v_mov_b32 v65, 0\n"
+                         "s_set_gpr_idx_off\n"
+                         "s_mul_hi_u32 s39, s37, %[pstride]\n"
+                         "s_mul_i32 s38, s37, %[pstride]\n"
+                         "s_add_u32 s38, s38, %[pb_lo]\n"
+                         "s_addc_u32 s39, s39, %[pb_hi]\n"
+                         "global_store_dwordx2 %[base], v[32:33], s[38:39]\n"
+                         "s_add_u32 vcc_lo, vcc_lo, 8\n"
+                         "s_addc_u32 vcc_hi, vcc_hi, 0\n"
+                         "s_sub_u32 %[nf], %[nf], 1\n"
+                         "s_cmp_lg_u32 %[nf], 0\n"
+                         "s_cbranch_scc1 1b\n"
+                         "s_mov_b32 m0, s33\n"
+                         "3:\n"
+                         : "+{v[64:95]}"(acc_lo), "+{v[96:127]}"(acc_hi), [nf] "+s"(nf)
+                         : [fr] "s"(fr), [base] "v"(base), [pstride] "s"(pstride), [pb_lo] "s"(pb_lo), [pb_hi] "s"(pb_hi)
+                         : "s33", "s36", "s37", "s38", "s39", "v32", "v33", "vcc", "scc", "memory");
+        }
+        __syncthreads();                                                    // ... everybody's have, and every wave is done with this tile
+    }
+#undef FL_TOUCH
+#undef FL_STAGE
+}
+#undef FL_CLOBBERS
+#undef FL_CLOB4
+#undef FL_FMAS
+#undef FL_READS
+#undef FL_FMA
+#undef FL_RD
+
 // ---- ART (Kaczmarz), row-sequential by definition (ctvlib.cpp:137-155) -------------------------------
 // a = (b_j - A_j x)/|A_j|^2 ; x += A_j^T a beta, one row after the other: row j+1 shares pixels with row j, so
 // rows cannot run side by side.  The parallelism that exists is across slices (lanes) and inside a row: one

@@ -1185,4 +1185,276 @@ bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Ta
     return true;
 }
 
+// Entry lists of k_fp_list (see sysmat.h): the strips of build_fp_strips with one ANGLE per wave and one accumulator per ray.
+bool build_fp_lists(const Coo &m, int N, int P, Tables &t, std::string &why)
+{
+    constexpr int W = Tables::FL_W, H = Tables::FL_H, TH = Tables::FL_TH, WAVES = Tables::FL_WAVES, ACC = Tables::FL_ACC, BATCH = Tables::FL_BATCH,
+                  PIXB = Tables::FL_PIXB, REGS = Tables::FL_REGS;
+    t.fl_ok = false;
+    const int64_t nrows = (int64_t)N * P;
+    const int64_t nnz = m.ptr[nrows];
+    if (N < 1 || P < 1 || nnz <= 0 || N > 32768) { why = "empty geometry"; return false; }
+    const unsigned hw = std::min(builder_threads(), 32u);
+    // ---- 1. direction of every angle (as build_fp_strips)
+    std::vector<int> orient(P, 0);
+    std::vector<double> slope(P, 0.0);
+    for (int i = 0; i < P; ++i) {
+        int64_t best = (int64_t)i * N;
+        for (int j = 0; j < N; ++j) { int64_t r = (int64_t)i * N + j; if (m.ptr[r + 1] - m.ptr[r] > m.ptr[best + 1] - m.ptr[best]) best = r; }
+        const int64_t b = m.ptr[best], e = m.ptr[best + 1];
+        if (e - b < 2) continue;
+        int ymin = N, ymax = -1, zmin = N, zmax = -1;
+        for (int64_t k = b; k < e; ++k) { int y = (int)(m.col[k] / (uint32_t)N), z = (int)(m.col[k] % (uint32_t)N); ymin = std::min(ymin, y); ymax = std::max(ymax, y); zmin = std::min(zmin, z); zmax = std::max(zmax, z); }
+        orient[i] = (ymax - ymin >= zmax - zmin) ? 0 : 1;
+        double su = 0, sv = 0, suu = 0, suv = 0; const double n = (double)(e - b);
+        for (int64_t k = b; k < e; ++k) {
+            int y = (int)(m.col[k] / (uint32_t)N), z = (int)(m.col[k] % (uint32_t)N);
+            double u = orient[i] ? z : y, v = orient[i] ? y : z;
+            su += u; sv += v; suu += u * u; suv += u * v;
+        }
+        const double den = n * suu - su * su;
+        slope[i] = den > 0 ? (n * suv - su * sv) / den : 0.0;
+    }
+    // ---- 2. passes of at most WAVES angles (one per wave), as even as the orientation's angle count allows
+    struct Pass { int orient; double tg; std::vector<int> ang; };
+    std::vector<Pass> passes;
+    auto form_passes = [&](double dt_max) {
+        passes.clear();
+        for (int o = 0; o < 2; ++o) {
+            std::vector<int> a;
+            for (int i = 0; i < P; ++i) if (orient[i] == o) a.push_back(i);
+            std::sort(a.begin(), a.end(), [&](int x, int y) { return slope[x] != slope[y] ? slope[x] < slope[y] : x < y; });
+            // as few passes as the wave count and the slope range allow, the angles dealt evenly (an empty wave idles for the whole item)
+            if (a.empty()) continue;
+            size_t np = (a.size() + WAVES - 1) / WAVES;
+            for (;; ++np) {
+                bool fits = true;
+                for (size_t c = 0; c < np && fits; ++c) {
+                    const size_t b = a.size() * c / np, e = a.size() * (c + 1) / np;
+                    fits = e > b && (e - b) <= (size_t)WAVES && slope[a[e - 1]] - slope[a[b]] <= dt_max;
+                }
+                if (fits || np >= a.size()) break;
+            }
+            for (size_t c = 0; c < np; ++c) {
+                const size_t b = a.size() * c / np, e = a.size() * (c + 1) / np;
+                if (e == b) continue;
+                Pass ps; ps.orient = o; ps.tg = 0.5 * (slope[a[b]] + slope[a[e - 1]]);
+                ps.ang.assign(a.begin() + b, a.begin() + e);
+                passes.push_back(std::move(ps));
+            }
+        }
+    };
+    double dt_max = 0.72;
+    if (const char *sdt = std::getenv("TOMO_FL_DT")) { double v = std::atof(sdt); if (v > 0) dt_max = v; }
+    std::vector<uint16_t> eu(nnz);
+    std::vector<uint8_t> elv(nnz);
+    std::vector<float> ew(nnz);
+    std::vector<std::vector<FsRowSeg>> rsegs;
+    std::vector<int32_t> shift;
+    std::vector<int> pass_of(P, 0), wave_of(P, 0);
+    const int OFF = N;
+    int nsegs = 1, seglen = 1 << 30;
+    struct Item { int32_t pass, strip; uint32_t tile0 = 0, ntiles = 0; std::vector<uint32_t> rows, qs; uint64_t work = 0; };
+    std::vector<Item> items;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        form_passes(dt_max);
+        const int npass = (int)passes.size();
+        shift.assign((size_t)npass * N, 0);
+        for (int ps = 0; ps < npass; ++ps) {
+            for (size_t w = 0; w < passes[ps].ang.size(); ++w) { pass_of[passes[ps].ang[w]] = ps; wave_of[passes[ps].ang[w]] = (int)w; }
+            for (int u = 0; u < N; ++u) {
+                double sh = passes[ps].tg * (u - 0.5 * (N - 1));
+                sh = std::max(-(double)N, std::min((double)N, sh));
+                shift[(size_t)ps * N + u] = (int32_t)std::floor(sh + 0.5);
+            }
+        }
+        {   // march segments by the image size only (see build_fp_strips): half a strip, 4 ... 16 tiles of H steps
+            const int tiles_per_strip = (N + H - 1) / H;
+            int len = std::max(4, std::min(16, tiles_per_strip / 2));
+            len = std::max(1, std::min(len, tiles_per_strip));
+            nsegs = (tiles_per_strip + len - 1) / len;
+            seglen = (tiles_per_strip + nsegs - 1) / nsegs;
+        }
+        // ---- 3. every ray: entries sorted by (strip segment, march coordinate, cross coordinate), cut into stays
+        rsegs.assign(nrows, {});
+        fs_parallel((size_t)nrows, hw, [&](size_t r) {
+            const int i = (int)(r / N), ps = pass_of[i], o = passes[ps].orient;
+            const int32_t *sh = shift.data() + (size_t)ps * N;
+            const int64_t b = m.ptr[r], e = m.ptr[r + 1];
+            const int n = (int)(e - b);
+            if (n == 0) return;
+            struct K { int32_t strip; uint16_t u; uint8_t lv; float w; };
+            std::vector<K> key(n);
+            for (int k = 0; k < n; ++k) {
+                uint32_t p = m.col[b + k];
+                int y = (int)(p / (uint32_t)N), z = (int)(p % (uint32_t)N);
+                int u = o ? z : y, v = o ? y : z;
+                int vs = v - sh[u] + OFF;
+                key[k] = {(vs / W) * nsegs + (u / H) / seglen, (uint16_t)u, (uint8_t)(vs % W), m.val[b + k]};
+            }
+            std::sort(key.begin(), key.end(), [](const K &a, const K &c) { return a.strip != c.strip ? a.strip < c.strip : a.u != c.u ? a.u < c.u : a.lv < c.lv; });
+            auto &rs = rsegs[r];
+            for (int k = 0; k < n; ++k) {
+                eu[b + k] = key[k].u; elv[b + k] = key[k].lv; ew[b + k] = key[k].w;
+                // t0 / t1 in tiles of TH march steps
+                if (rs.empty() || rs.back().strip != key[k].strip) rs.push_back({key[k].strip, (uint32_t)(b + k), 0u, (uint32_t)key[k].u / TH, 0u});
+                rs.back().cnt++; rs.back().t1 = (uint32_t)key[k].u / TH;
+            }
+        });
+        // ---- 4. items = non-empty (pass, strip segment) buckets
+        const int nstrip_max = ((3 * N + W - 1) / W + 2) * nsegs;
+        std::vector<uint32_t> iptr((size_t)npass * nstrip_max + 1, 0);
+        for (int64_t r = 0; r < nrows; ++r) { const int ps = pass_of[r / N]; for (auto &sg : rsegs[r]) iptr[(size_t)ps * nstrip_max + sg.strip + 1]++; }
+        for (size_t k = 0; k + 1 < iptr.size(); ++k) iptr[k + 1] += iptr[k];
+        struct Ref { uint32_t row, q; };
+        std::vector<Ref> refs(iptr.back() ? iptr.back() : 1);
+        {
+            std::vector<uint32_t> fill(iptr.begin(), iptr.end() - 1);
+            for (int64_t r = 0; r < nrows; ++r) {
+                const int ps = pass_of[r / N];
+                for (uint32_t q = 0; q < rsegs[r].size(); ++q) refs[fill[(size_t)ps * nstrip_max + rsegs[r][q].strip]++] = {(uint32_t)r, q};
+            }
+        }
+        items.clear();
+        for (size_t k = 0; k + 1 < iptr.size(); ++k) {
+            if (iptr[k + 1] == iptr[k]) continue;
+            Item itx; itx.pass = (int32_t)(k / nstrip_max); itx.strip = (int32_t)(k % nstrip_max);
+            uint32_t lo = 0xFFFFFFFFu, hi = 0;
+            for (uint32_t x = iptr[k]; x < iptr[k + 1]; ++x) {
+                const FsRowSeg &rs = rsegs[refs[x].row][refs[x].q];
+                itx.rows.push_back(refs[x].row); itx.qs.push_back(refs[x].q);
+                lo = std::min(lo, rs.t0); hi = std::max(hi, rs.t1); itx.work += rs.cnt;
+            }
+            itx.tile0 = lo; itx.ntiles = hi - lo + 1;
+            items.push_back(std::move(itx));
+        }
+        // ---- 5. a ray j of an angle lives in accumulator j mod ACC of that angle's wave: two stays may share one only one after the other
+        bool clash = false;
+        for (auto &itx : items) {
+            if (itx.ntiles > 64) { clash = true; break; }             // (the kernel keeps an item's list bounds one tile per lane)
+            std::vector<uint32_t> busy_until((size_t)WAVES * ACC, 0);  // tile index + 1 up to which the accumulator is taken
+            std::vector<uint32_t> ord(itx.rows.size());
+            for (uint32_t x = 0; x < ord.size(); ++x) ord[x] = x;
+            std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+                const FsRowSeg &A = rsegs[itx.rows[a]][itx.qs[a]], &B = rsegs[itx.rows[b]][itx.qs[b]];
+                return A.t0 != B.t0 ? A.t0 < B.t0 : itx.rows[a] < itx.rows[b];
+            });
+            for (uint32_t x : ord) {
+                const uint32_t row = itx.rows[x];
+                const FsRowSeg &rs = rsegs[row][itx.qs[x]];
+                uint32_t &bu = busy_until[(size_t)wave_of[row / N] * ACC + (row % N) % ACC];
+                if (bu > rs.t0 - itx.tile0) { clash = true; break; }
+                bu = rs.t1 - itx.tile0 + 1;
+            }
+            if (clash) break;
+        }
+        if (!clash) break;
+        if (attempt == 5) { why = "a strip holds more live rays of one angle than a wave has accumulators"; return false; }
+        dt_max *= 0.7;
+    }
+    const int npass = (int)passes.size();
+    // ---- 6. layout: items heaviest first; list and flush-list bounds
+    std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.work != b.work ? a.work > b.work : (a.pass != b.pass ? a.pass < b.pass : a.strip < b.strip); });
+    const size_t nitems = items.size();
+    t.fl_item.assign(nitems, {});
+    size_t nlist = 0;
+    for (size_t o = 0; o < nitems; ++o) {
+        Tables::FlItem &f = t.fl_item[o];
+        f.pass = items[o].pass; f.v0 = (items[o].strip / nsegs) * W - OFF; f.tile0 = items[o].tile0; f.ntiles = items[o].ntiles;
+        f.lp0 = (uint32_t)nlist; f.work = (uint32_t)std::min<uint64_t>(items[o].work, 0xFFFFFFFFu); f.pad0 = f.pad1 = 0;
+        nlist += (size_t)items[o].ntiles * WAVES;
+    }
+    if (nlist >= (1ull << 31)) { why = "list tables exceed 32-bit offsets"; return false; }
+    // per list: entries and flushes (counting pass), then prefix sums, then emission
+    std::vector<uint32_t> nbat(nlist, 0), nfl(nlist, 0);
+    struct E { uint16_t lu; uint8_t lv, slot; float w; };
+    auto walk = [&](size_t o, bool emit) {
+        const Item &itx = items[o];
+        const Tables::FlItem &f = t.fl_item[o];
+        // entries of every (tile, wave), in the order (march step, cross coordinate, ray): a ray's own entries keep their order
+        std::vector<std::vector<E>> ents(emit ? (size_t)itx.ntiles * WAVES : 0);
+        std::vector<uint32_t> cnt((size_t)itx.ntiles * WAVES, 0);
+        for (uint32_t x = 0; x < itx.rows.size(); ++x) {
+            const uint32_t row = itx.rows[x];
+            const FsRowSeg &rs = rsegs[row][itx.qs[x]];
+            const int w = wave_of[row / N];
+            const uint8_t slot = (uint8_t)((row % N) % ACC);
+            for (uint32_t k = rs.off; k < rs.off + rs.cnt; ++k) {
+                const size_t li = (size_t)((uint32_t)eu[k] / TH - itx.tile0) * WAVES + w;
+                ++cnt[li];
+                if (emit) ents[li].push_back({(uint16_t)((uint32_t)eu[k] % TH), elv[k], slot, ew[k]});
+            }
+            const size_t lf = (size_t)(rs.t1 - itx.tile0) * WAVES + w;
+            if (!emit) ++nfl[f.lp0 + lf];
+        }
+        if (!emit) { for (size_t li = 0; li < cnt.size(); ++li) nbat[f.lp0 + li] = (cnt[li] + BATCH - 1) / BATCH; return; }
+        for (size_t li = 0; li < ents.size(); ++li) {
+            auto &v = ents[li];
+            std::stable_sort(v.begin(), v.end(), [](const E &a, const E &b) { return a.lu != b.lu ? a.lu < b.lu : a.lv < b.lv; });
+            const uint32_t buf = (uint32_t)((li / WAVES) & 1) * (uint32_t)(W * TH);
+            uint64_t *out = t.fl_ent.get() + (size_t)t.fl_ptr[f.lp0 + li] * BATCH;
+            uint32_t last = 0;
+            for (size_t k = 0; k < v.size(); ++k) {
+                last = (buf + (uint32_t)v[k].lu * W + v[k].lv) * (uint32_t)PIXB;
+                out[k] = Tables::fs_pack(last | (uint32_t)(v[k].slot * REGS), v[k].w);
+            }
+            const size_t padded = (size_t)nbat[f.lp0 + li] * BATCH;
+            for (size_t k = v.size(); k < padded; ++k) out[k] = Tables::fs_pack(last, 0.f);     // weight 0 on a staged pixel, into accumulator 0
+        }
+        // flush records, partial-sum ids in the order (tile, wave, ray)
+        std::vector<uint32_t> ord(itx.rows.size());
+        for (uint32_t x = 0; x < ord.size(); ++x) ord[x] = x;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+            const FsRowSeg &A = rsegs[itx.rows[a]][itx.qs[a]], &B = rsegs[itx.rows[b]][itx.qs[b]];
+            const int wa = wave_of[itx.rows[a] / N], wb = wave_of[itx.rows[b] / N];
+            return A.t1 != B.t1 ? A.t1 < B.t1 : wa != wb ? wa < wb : itx.rows[a] < itx.rows[b];
+        });
+        std::vector<uint32_t> fill((size_t)itx.ntiles * WAVES, 0);
+        for (uint32_t x : ord) {
+            const uint32_t row = itx.rows[x];
+            const FsRowSeg &rs = rsegs[row][itx.qs[x]];
+            const size_t lf = (size_t)(rs.t1 - itx.tile0) * WAVES + wave_of[row / N];
+            const uint32_t id = t.fl_fptr[f.lp0 + lf] + fill[lf]++;
+            t.fl_flush[id] = (uint64_t)(((row % N) % ACC) * REGS) | ((uint64_t)id << 32);
+            t.fl_rseg_idx[t.fl_rseg_ptr[row] + itx.qs[x]] = id;
+        }
+    };
+    fs_parallel(nitems, hw, [&](size_t o) { walk(o, false); });
+    {   // how evenly a tile's work is spread over the waves (they meet at a barrier after every tile): mean / max batches per wave
+        uint64_t sum = 0, summax = 0;
+        for (size_t li = 0; li < nlist; li += WAVES) {
+            uint32_t mx = 0;
+            for (int w = 0; w < WAVES; ++w) { sum += nbat[li + w]; mx = std::max(mx, nbat[li + w]); }
+            summax += mx;
+        }
+        t.fl_balance = summax ? (double)sum / ((double)summax * WAVES) : 0.0;
+    }
+    t.fl_ptr.assign(nlist + 1, 0);
+    t.fl_fptr.assign(nlist + 1, 0);
+    uint64_t nb = 0, nf = 0;
+    for (size_t li = 0; li < nlist; ++li) { t.fl_ptr[li] = (uint32_t)nb; t.fl_fptr[li] = (uint32_t)nf; nb += nbat[li]; nf += nfl[li]; }
+    if (nb >= (1ull << 32) / BATCH || nf >= (1ull << 32)) { why = "list tables exceed 32-bit offsets"; return false; }
+    t.fl_ptr[nlist] = (uint32_t)nb; t.fl_fptr[nlist] = (uint32_t)nf;
+    t.fl_nseg = (uint32_t)nf;
+    t.fl_ent_n = (size_t)(nb + 1) * BATCH;
+    t.fl_ent.reset(new uint64_t[t.fl_ent_n]);
+    for (size_t k = (size_t)nb * BATCH; k < t.fl_ent_n; ++k) t.fl_ent[k] = 0;
+    t.fl_flush.assign(nf ? nf : 1, 0);
+    t.fl_rseg_ptr.assign(nrows + 1, 0);
+    for (int64_t r = 0; r < nrows; ++r) t.fl_rseg_ptr[r + 1] = t.fl_rseg_ptr[r] + (uint32_t)rsegs[r].size();
+    if (t.fl_rseg_ptr[nrows] != nf) { why = "stays and flush records disagree"; return false; }
+    t.fl_rseg_idx.assign(nf ? nf : 1, 0);
+    fs_parallel(nitems, hw, [&](size_t o) { walk(o, true); });
+    t.fl_npass = npass;
+    t.fl_orient.assign(npass, 0);
+    for (int ps = 0; ps < npass; ++ps) t.fl_orient[ps] = passes[ps].orient;
+    t.fl_shift = shift;
+    t.fl_real_entries = (uint64_t)nnz;
+    t.fl_slots = nb * BATCH;
+    t.fl_staged_pixels = 0;
+    for (auto &f : t.fl_item) t.fl_staged_pixels += (uint64_t)f.ntiles * W * TH;
+    t.fl_ok = true;
+    return true;
+}
+
 }  // namespace tomo

@@ -131,6 +131,25 @@ struct Tables {
     // WITHOUT initialisation and filled by the emission threads (1.6 GB at 1024^2 x 120: a zero fill alone cost seconds)
     std::unique_ptr<uint64_t[]> fs_ent;
     size_t fs_ent_n = 0;
+    // The same strips as entry LISTS of the wave-per-angle form (k_fp_list, round 4): a workgroup of FL_WAVES waves marches an item (pass,
+    // strip of FL_W pixels, march segment) in tiles of FL_TH march steps; wave w owns the rays of the pass's w-th angle, ray j in
+    // accumulator j mod FL_ACC (two registers: 128 slices); per (item, tile, wave) a list of entries {byte offset of the pixel in the
+    // double-buffered LDS tile | accumulator register, weight} padded to whole batches of FL_BATCH, and a list of flush records
+    // {accumulator register, partial-sum id} of the rays whose stay in the strip ends in that tile.
+    static constexpr int FL_W = 16, FL_H = 16, FL_TH = 8, FL_WAVES = 16, FL_ACC = 32, FL_BATCH = 16, FL_PIXB = 512, FL_REGS = 2;
+    struct FlItem { int32_t pass, v0; uint32_t tile0, ntiles, lp0, work, pad0, pad1; };
+    bool fl_ok = false;
+    int fl_npass = 0;
+    uint32_t fl_nseg = 0;
+    uint64_t fl_real_entries = 0, fl_slots = 0, fl_staged_pixels = 0;
+    double fl_balance = 0.0;                     // mean / max batches per wave of a tile, over all tiles (1 = every wave equally loaded)
+    std::vector<FlItem> fl_item;                 // heaviest first
+    std::vector<int32_t> fl_orient, fl_shift;    // [npass], [npass * N]
+    std::vector<uint32_t> fl_ptr, fl_fptr;       // [sum of ntiles * FL_WAVES + 1] first batch / first flush record of list lp0 + tile * FL_WAVES + wave
+    std::unique_ptr<uint64_t[]> fl_ent;          // [(batches + 1) * FL_BATCH]
+    size_t fl_ent_n = 0;
+    std::vector<uint64_t> fl_flush;              // register | id << 32
+    std::vector<uint32_t> fl_rseg_ptr, fl_rseg_idx;   // per ray the partial-sum ids of its stays, ascending strip (the reduce kernel's fixed order)
     static uint64_t fs_pack(uint32_t off, float w) { uint32_t b; std::memcpy(&b, &w, 4); return (uint64_t)off | ((uint64_t)b << 32); }
     static uint32_t fs_off_of(uint64_t e) { return (uint32_t)e; }
     static float fs_w_of(uint64_t e) { uint32_t b = (uint32_t)(e >> 32); float w; std::memcpy(&w, &b, 4); return w; }
@@ -149,6 +168,7 @@ void build_sart_tiles(const Coo &m, int N, int P, int TY, int TZ, int max_rows, 
 void build_bp_tiles(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int pad_angles, Tables &t);
 // needs t.cell (build_tables); regs_per_pixel: accumulator registers of one pixel (index step)
 void build_bp_lists(int N, int P, int TY, int TZ, int stage_angles, int max_rows, int row_bytes, int waves, int batch, int regs_per_pixel, Tables &t);
+bool build_fp_lists(const Coo &m, int N, int P, Tables &t, std::string &why);
 bool build_fp_strips(const Coo &m, int N, int P, int pixel_bytes, int nchunk, Tables &t, std::string &why);   // nchunk: 64-slice chunks of the slab
 
 }  // namespace tomo

@@ -165,6 +165,15 @@ struct tomo_engine {
     uint2 *d_fs_ent = nullptr;
     float *d_fs_zero = nullptr;                   // 256 bytes of zeros: what a strip tile's pixels outside the image are staged from
     float *fs_part = nullptr, *fs_part_aux = nullptr;
+    // ... and as wave-uniform entry lists (k_fp_list) when the slab is a whole number of 128-slice pieces
+    int fp_list = 1, fl_nitems = 0, fl_ncp = 0;
+    bool fl_ok = false, attr_fl = false;
+    uint32_t fl_nseg = 0;
+    FlItemD *d_fl_items = nullptr;
+    int *d_fl_orient = nullptr, *d_fl_shift = nullptr;
+    uint2 *d_fl_ent = nullptr, *d_fl_fent = nullptr;
+    uint32_t *d_fl_ptr = nullptr, *d_fl_fptr = nullptr, *d_fl_rsptr = nullptr, *d_fl_rsidx = nullptr;
+    float *d_fl_zero = nullptr, *fl_part = nullptr, *fl_part_aux = nullptr;
     // all-angle FP as a two-stage pipeline over groups of 64-slice chunks ("fp_tile_pipe"): [0] main stream, [1] second stream
     int fp_tile_pipe = 0;   // off: measured (round 3) 1.50 vs 1.52 ms at 512^3 x 90, 1.91 vs 1.83 ms at 128 x 1024^2 x 120, 0.127 vs 0.154 ms at 256^3 x 60
     hipStream_t fp_red_stream[2] = {nullptr, nullptr};
@@ -524,10 +533,51 @@ static int launch_fp_strip(tomo_engine *e, const float *x, const float *b, float
     return TOMO_OK;
 }
 
+// all-angle FP, sheared strips as wave-uniform entry lists (k_fp_list + k_fp_tile_reduce on the lists' row lists)
+template <int MODE>
+static int launch_fp_list(tomo_engine *e, const float *x, const float *b, float *out)
+{
+    const int nchunk = e->sxc / 64;
+    if (!e->fl_ncp) {
+        size_t per_chunk = (size_t)std::max<uint32_t>(1, e->fl_nseg) * 64 * sizeof(float);
+        int ncp = (int)std::min<size_t>(nchunk, std::max<size_t>(2, e->ft_scratch_cap / per_chunk));
+        if (e->ft_ncp_forced > 0) ncp = std::min(nchunk, std::max(2, e->ft_ncp_forced));
+        if (ncp >= 4) ncp &= ~3; else ncp = 2;                       // whole 128-slice pieces
+        e->fl_ncp = ncp;
+    }
+    if (!e->attr_fl) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_fp_list, hipFuncAttributeMaxDynamicSharedMemorySize, FL_LDS_BYTES));
+        e->attr_fl = true;
+    }
+    const int which = (e->aux && e->stream == e->aux) ? 1 : 0;
+    float **slot = which ? &e->fl_part_aux : &e->fl_part;
+    if (!*slot) {
+        int rc = dev_alloc((void **)slot, (size_t)std::max<uint32_t>(1, e->fl_nseg) * e->fl_ncp * 64 * sizeof(float), false, e->stream);
+        if (rc) return rc;
+    }
+    for (int c0 = 0; c0 < nchunk; c0 += e->fl_ncp) {
+        const int ncp = std::min(e->fl_ncp, nchunk - c0);            // even: the slab is whole 128-slice pieces
+        {
+            ProfScope ps(e, TOMO_K_FP_TILE);
+            dim3 grid((unsigned)(8 * ((e->fl_nitems + 7) / 8) * (ncp / 2))), block(FL_THREADS);
+            hipLaunchKernelGGL(k_fp_list, grid, block, FL_LDS_BYTES, e->stream, x, e->d_fl_items, e->d_fl_orient, e->d_fl_shift, e->d_fl_ent, e->d_fl_ptr,
+                               e->d_fl_fent, e->d_fl_fptr, *slot, e->n, e->sx, e->fl_nitems, c0 / 2, ncp / 2, ncp, e->d_fl_zero);
+            LAUNCHCHK();
+        }
+        {
+            ProfScope ps(e, TOMO_K_FP_REDUCE);
+            launch_fp_reduce<MODE>(e, e->stream, *slot, e->d_fl_rsptr, e->d_fl_rsidx, b, out, c0, ncp);
+            LAUNCHCHK();
+        }
+    }
+    return TOMO_OK;
+}
+
 // all-angle FP: sheared-strip form, else the tile-stationary form (k_fp_tile + k_fp_tile_reduce) unless switched off, else the ray-driven form
 template <int MODE>
 static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *out)
 {
+    if (e->fp_strip && e->fp_list && e->fl_ok && e->sxc % 128 == 0) return launch_fp_list<MODE>(e, x, b, out);
     if (e->fp_strip && e->fs_ok) return launch_fp_strip<MODE>(e, x, b, out);
     if (!e->fp_tile) return launch_fp<MODE>(e, x, 0, (int)e->nrows, b, out, e->fp_all_lpr);
     const int nchunk = e->sxc / 64;
@@ -978,6 +1028,43 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             t.fs_ent.reset(); t.fs_ent_n = 0; release(t.fs_cnt); release(t.fs_rseg_idx); release(t.fs_rseg_ptr); release(t.fs_gstart); release(t.fs_gseg0);
         }
         lap("build_fp_strips + upload");
+        {   // the same strips as wave-uniform entry lists (k_fp_list); by the same rule (TOMO_FP_LIST = 0 / 1 overrides it)
+            std::string why;
+            static_assert(Tables::FL_W == FL_W && Tables::FL_TH == FL_TH && Tables::FL_WAVES == FL_WAVES && Tables::FL_BATCH == FL_BATCH && Tables::FL_PIXB == FL_PIXB, "list shape");
+            static_assert(sizeof(Tables::FlItem) == sizeof(FlItemD), "list item layout");
+            bool want = e->fs_ok;
+            if (const char *env = std::getenv("TOMO_FP_LIST")) want = std::atoi(env) != 0;
+            e->fl_ok = want && build_fp_lists(m, e->n, e->np, t, why);
+            // One angle per wave: a pass with fewer angles than waves, or angles of very different weight counts (1.0 ... 1.41 per pixel),
+            // leaves waves waiting at every tile's barrier.  Measured (MI355X, FP alone, lists against strips): 512^3 x 90 1.14 / 1.21 ms
+            // (balance 0.86), 512^3 x 70 0.96 / 1.06 (0.80), 1024 x 512^2 x 90 2.26 / 2.42, 1024^3 x 120 11.3 / 12.1 (0.79), but
+            // 128 x 1024^2 x 120 1.74 / 1.58 (0.79), 256^3 x 60 0.155 / 0.147 (0.69): lists from a balance of 0.8 on.
+            if (e->fl_ok && !std::getenv("TOMO_FP_LIST") && t.fl_balance < 0.8) e->fl_ok = false;
+            if (e->fl_ok) {
+                e->fl_nitems = (int)t.fl_item.size(); e->fl_nseg = t.fl_nseg;
+                if ((rc = dev_alloc((void **)&e->d_fl_items, t.fl_item.size() * sizeof(FlItemD), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_orient, t.fl_orient.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_shift, t.fl_shift.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_ent, t.fl_ent_n * sizeof(uint2), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_ptr, t.fl_ptr.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_fent, t.fl_flush.size() * sizeof(uint2), false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_fptr, t.fl_fptr.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_rsptr, t.fl_rseg_ptr.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_rsidx, t.fl_rseg_idx.size() * 4, false, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->d_fl_zero, 512, true, e->stream))) return rc;
+                HIPCHK(hipMemcpy(e->d_fl_items, t.fl_item.data(), t.fl_item.size() * sizeof(FlItemD), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_orient, t.fl_orient.data(), t.fl_orient.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_shift, t.fl_shift.data(), t.fl_shift.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_ent, t.fl_ent.get(), t.fl_ent_n * sizeof(uint2), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_ptr, t.fl_ptr.data(), t.fl_ptr.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_fent, t.fl_flush.data(), t.fl_flush.size() * sizeof(uint2), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_fptr, t.fl_fptr.data(), t.fl_fptr.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_rsptr, t.fl_rseg_ptr.data(), t.fl_rseg_ptr.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_fl_rsidx, t.fl_rseg_idx.data(), t.fl_rseg_idx.size() * 4, hipMemcpyHostToDevice));
+            }
+            t.fl_ent.reset(); t.fl_ent_n = 0; release(t.fl_flush); release(t.fl_ptr); release(t.fl_fptr); release(t.fl_rseg_ptr); release(t.fl_rseg_idx); release(t.fl_item); release(t.fl_shift);
+        }
+        lap("build_fp_lists + upload");
         build_sart_tiles(m, e->n, e->np, ST_TY, ST_TZ, ST_MAXR, 256, t);
         static_assert(Tables::ST_MAXSEG == ST_MAXSEG, "segment slots per tile");
         e->st_ok = t.st_ok;
@@ -1215,7 +1302,9 @@ static void free_geometry(tomo_engine *e)
                      (void **)&e->d_rptr, (void **)&e->d_rent, (void **)&e->d_rowsum, (void **)&e->d_rowinner, (void **)&e->d_colsum_all,
                      (void **)&e->d_rowcross, (void **)&e->d_cell,
                      (void **)&e->d_fs_items, (void **)&e->d_fs_orient, (void **)&e->d_fs_shift, (void **)&e->d_fs_cnt, (void **)&e->d_fs_gstart,
-                     (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_zero, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux};
+                     (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_zero, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux,
+                     (void **)&e->d_fl_items, (void **)&e->d_fl_orient, (void **)&e->d_fl_shift, (void **)&e->d_fl_ent, (void **)&e->d_fl_ptr, (void **)&e->d_fl_fent, (void **)&e->d_fl_fptr,
+                     (void **)&e->d_fl_rsptr, (void **)&e->d_fl_rsidx, (void **)&e->d_fl_zero, (void **)&e->fl_part, (void **)&e->fl_part_aux};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
     if (e->g_prev) { (void)hipFree(e->g_prev); e->g_prev = nullptr; }
@@ -2914,6 +3003,8 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "fp_tile") == 0) { *value = e->fp_tile; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { *value = e->bp_tile; return TOMO_OK; }
     if (std::strcmp(name, "bp_list") == 0) { *value = e->bp_list; return TOMO_OK; }
+    if (std::strcmp(name, "fp_list") == 0) { *value = e->fp_list; return TOMO_OK; }
+    if (std::strcmp(name, "fp_list_ready") == 0) { *value = e->fl_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_list_ready") == 0) { *value = e->bl_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_reuse") == 0) { *value = e->fp_reuse; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { *value = e->sart_tile; return TOMO_OK; }
@@ -2942,17 +3033,18 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_list") == 0) { e->bp_list = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fp_list") == 0) { e->fp_list = value ? 1 : 0; return TOMO_OK; }
     // all-angle FP form: "fp_strip" = 1 (default) sheared strips; asking for "fp_tile" = 1 / 0 explicitly selects the tile-stationary /
     // the ray-driven form (and takes the strips out of the way until "fp_strip" = 1 is set again)
     if (std::strcmp(name, "fp_strip") == 0) { e->fp_strip = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile") == 0) { e->fp_tile = value ? 1 : 0; e->fp_strip = 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_chunks_per_pass") == 0) {   // any count >= 1 (0 = from the scratch cap); before the first projection
-        if (value < 0 || e->ft_part || e->ft_part_aux || e->fs_part || e->fs_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_chunks_per_pass must be set before the first projection");
-        e->ft_ncp_forced = value; e->ft_ncp = 0; e->fs_ncp = 0; return TOMO_OK;
+        if (value < 0 || e->ft_part || e->ft_part_aux || e->fs_part || e->fs_part_aux || e->fl_part || e->fl_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_chunks_per_pass must be set before the first projection");
+        e->ft_ncp_forced = value; e->ft_ncp = 0; e->fs_ncp = 0; e->fl_ncp = 0; return TOMO_OK;
     }
     if (std::strcmp(name, "fp_tile_scratch_mib") == 0) {   // cap of the partial-sum scratch; takes effect before the first all-angle FP
-        if (value <= 0 || e->ft_part || e->ft_part_aux || e->fs_part || e->fs_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
-        e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; e->fs_ncp = 0; return TOMO_OK;
+        if (value <= 0 || e->ft_part || e->ft_part_aux || e->fs_part || e->fs_part_aux || e->fl_part || e->fl_part_aux) return fail(TOMO_ERR_STATE, "fp_tile_scratch_mib must be positive and set before the first projection");
+        e->ft_scratch_cap = (size_t)value << 20; e->ft_ncp = 0; e->fs_ncp = 0; e->fl_ncp = 0; return TOMO_OK;
     }
     if (std::strcmp(name, "tv_gnorm_slot") == 0) {
         if (value < 0 || value >= TOMO_S_COUNT) return fail(TOMO_ERR_ARG, "bad scalar slot");
