@@ -1215,23 +1215,22 @@ bool build_fp_lists(const Coo &m, int N, int P, Tables &t, std::string &why)
         const double den = n * suu - su * su;
         slope[i] = den > 0 ? (n * suv - su * sv) / den : 0.0;
     }
-    // ---- 2. passes of at most WAVES angles (one per wave), as even as the orientation's angle count allows
+    // ---- 2. passes: angles of one orientation, neighbouring slopes (as few as the slope range allows, the angles dealt evenly)
     struct Pass { int orient; double tg; std::vector<int> ang; };
     std::vector<Pass> passes;
-    auto form_passes = [&](double dt_max) {
+    auto form_passes = [&](double dt_max, int amax) {
         passes.clear();
         for (int o = 0; o < 2; ++o) {
             std::vector<int> a;
             for (int i = 0; i < P; ++i) if (orient[i] == o) a.push_back(i);
             std::sort(a.begin(), a.end(), [&](int x, int y) { return slope[x] != slope[y] ? slope[x] < slope[y] : x < y; });
-            // as few passes as the wave count and the slope range allow, the angles dealt evenly (an empty wave idles for the whole item)
             if (a.empty()) continue;
-            size_t np = (a.size() + WAVES - 1) / WAVES;
+            size_t np = (a.size() + amax - 1) / amax;
             for (;; ++np) {
                 bool fits = true;
                 for (size_t c = 0; c < np && fits; ++c) {
                     const size_t b = a.size() * c / np, e = a.size() * (c + 1) / np;
-                    fits = e > b && (e - b) <= (size_t)WAVES && slope[a[e - 1]] - slope[a[b]] <= dt_max;
+                    fits = e > b && (e - b) <= (size_t)amax && slope[a[e - 1]] - slope[a[b]] <= dt_max;
                 }
                 if (fits || np >= a.size()) break;
             }
@@ -1244,24 +1243,25 @@ bool build_fp_lists(const Coo &m, int N, int P, Tables &t, std::string &why)
             }
         }
     };
-    double dt_max = 0.72;
+    double dt_max = 0.72; int amax = 20;
     if (const char *sdt = std::getenv("TOMO_FL_DT")) { double v = std::atof(sdt); if (v > 0) dt_max = v; }
+    if (const char *sa = std::getenv("TOMO_FL_AMAX")) { int v = std::atoi(sa); if (v > 0) amax = v; }
     std::vector<uint16_t> eu(nnz);
     std::vector<uint8_t> elv(nnz);
     std::vector<float> ew(nnz);
     std::vector<std::vector<FsRowSeg>> rsegs;
     std::vector<int32_t> shift;
-    std::vector<int> pass_of(P, 0), wave_of(P, 0);
+    std::vector<int> pass_of(P, 0);
     const int OFF = N;
     int nsegs = 1, seglen = 1 << 30;
-    struct Item { int32_t pass, strip; uint32_t tile0 = 0, ntiles = 0; std::vector<uint32_t> rows, qs; uint64_t work = 0; };
+    struct Item { int32_t pass, strip; uint32_t tile0 = 0, ntiles = 0; std::vector<uint32_t> rows, qs; std::vector<uint8_t> wv, sl; uint64_t work = 0; };
     std::vector<Item> items;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        form_passes(dt_max);
+        form_passes(dt_max, amax);
         const int npass = (int)passes.size();
         shift.assign((size_t)npass * N, 0);
         for (int ps = 0; ps < npass; ++ps) {
-            for (size_t w = 0; w < passes[ps].ang.size(); ++w) { pass_of[passes[ps].ang[w]] = ps; wave_of[passes[ps].ang[w]] = (int)w; }
+            for (int a : passes[ps].ang) pass_of[a] = ps;
             for (int u = 0; u < N; ++u) {
                 double sh = passes[ps].tg * (u - 0.5 * (N - 1));
                 sh = std::max(-(double)N, std::min((double)N, sh));
@@ -1328,29 +1328,42 @@ bool build_fp_lists(const Coo &m, int N, int P, Tables &t, std::string &why)
             itx.tile0 = lo; itx.ntiles = hi - lo + 1;
             items.push_back(std::move(itx));
         }
-        // ---- 5. a ray j of an angle lives in accumulator j mod ACC of that angle's wave: two stays may share one only one after the other
-        bool clash = false;
-        for (auto &itx : items) {
-            if (itx.ntiles > 64) { clash = true; break; }             // (the kernel keeps an item's list bounds one tile per lane)
-            std::vector<uint32_t> busy_until((size_t)WAVES * ACC, 0);  // tile index + 1 up to which the accumulator is taken
-            std::vector<uint32_t> ord(itx.rows.size());
-            for (uint32_t x = 0; x < ord.size(); ++x) ord[x] = x;
+        // ---- 5. every stay of a ray in the item gets an accumulator (wave, slot) for its tiles t0 .. t1: in the order of arrival to
+        // the wave with a free slot whose live stays bring the fewest entries per tile -- the waves meet at a barrier after every tile,
+        // so a tile costs its busiest wave
+        std::vector<uint8_t> over(items.size(), 0);
+        fs_parallel(items.size(), hw, [&](size_t it) {
+            Item &itx = items[it];
+            if (itx.ntiles > 64) { over[it] = 1; return; }             // (the kernel keeps an item's list bounds one tile per lane)
+            const size_t ns = itx.rows.size();
+            itx.wv.assign(ns, 0); itx.sl.assign(ns, 0);
+            std::vector<uint32_t> ord(ns);
+            for (uint32_t x = 0; x < ns; ++x) ord[x] = x;
             std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
                 const FsRowSeg &A = rsegs[itx.rows[a]][itx.qs[a]], &B = rsegs[itx.rows[b]][itx.qs[b]];
                 return A.t0 != B.t0 ? A.t0 < B.t0 : itx.rows[a] < itx.rows[b];
             });
+            std::vector<uint32_t> until((size_t)WAVES * ACC, 0);       // tile (relative) + 1 up to which the slot is taken
+            std::vector<float> rate((size_t)WAVES * ACC, 0.f);         // entries per tile of the stay in the slot
             for (uint32_t x : ord) {
-                const uint32_t row = itx.rows[x];
-                const FsRowSeg &rs = rsegs[row][itx.qs[x]];
-                uint32_t &bu = busy_until[(size_t)wave_of[row / N] * ACC + (row % N) % ACC];
-                if (bu > rs.t0 - itx.tile0) { clash = true; break; }
-                bu = rs.t1 - itx.tile0 + 1;
+                const FsRowSeg &rs = rsegs[itx.rows[x]][itx.qs[x]];
+                const uint32_t t0 = rs.t0 - itx.tile0, t1 = rs.t1 - itx.tile0;
+                int bw = -1, bs = -1; float br = 0.f;
+                for (int w = 0; w < WAVES; ++w) {
+                    float r = 0.f; int fs = -1;
+                    for (int k = 0; k < ACC; ++k) { if (until[(size_t)w * ACC + k] > t0) r += rate[(size_t)w * ACC + k]; else if (fs < 0) fs = k; }
+                    if (fs >= 0 && (bw < 0 || r < br)) { bw = w; bs = fs; br = r; }
+                }
+                if (bw < 0) { over[it] = 1; return; }
+                itx.wv[x] = (uint8_t)bw; itx.sl[x] = (uint8_t)bs;
+                until[(size_t)bw * ACC + bs] = t1 + 1; rate[(size_t)bw * ACC + bs] = (float)rs.cnt / (float)(t1 - t0 + 1);
             }
-            if (clash) break;
-        }
+        });
+        bool clash = false;
+        for (uint8_t o : over) clash |= o != 0;
         if (!clash) break;
-        if (attempt == 5) { why = "a strip holds more live rays of one angle than a wave has accumulators"; return false; }
-        dt_max *= 0.7;
+        if (attempt == 5) { why = "a strip holds more live rays than a workgroup has accumulators"; return false; }
+        dt_max *= 0.7; amax = std::max(1, amax * 3 / 4);
     }
     const int npass = (int)passes.size();
     // ---- 6. layout: items heaviest first; list and flush-list bounds
@@ -1377,8 +1390,8 @@ bool build_fp_lists(const Coo &m, int N, int P, Tables &t, std::string &why)
         for (uint32_t x = 0; x < itx.rows.size(); ++x) {
             const uint32_t row = itx.rows[x];
             const FsRowSeg &rs = rsegs[row][itx.qs[x]];
-            const int w = wave_of[row / N];
-            const uint8_t slot = (uint8_t)((row % N) % ACC);
+            const int w = itx.wv[x];
+            const uint8_t slot = itx.sl[x];
             for (uint32_t k = rs.off; k < rs.off + rs.cnt; ++k) {
                 const size_t li = (size_t)((uint32_t)eu[k] / TH - itx.tile0) * WAVES + w;
                 ++cnt[li];
@@ -1406,16 +1419,16 @@ bool build_fp_lists(const Coo &m, int N, int P, Tables &t, std::string &why)
         for (uint32_t x = 0; x < ord.size(); ++x) ord[x] = x;
         std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
             const FsRowSeg &A = rsegs[itx.rows[a]][itx.qs[a]], &B = rsegs[itx.rows[b]][itx.qs[b]];
-            const int wa = wave_of[itx.rows[a] / N], wb = wave_of[itx.rows[b] / N];
+            const int wa = itx.wv[a], wb = itx.wv[b];
             return A.t1 != B.t1 ? A.t1 < B.t1 : wa != wb ? wa < wb : itx.rows[a] < itx.rows[b];
         });
         std::vector<uint32_t> fill((size_t)itx.ntiles * WAVES, 0);
         for (uint32_t x : ord) {
             const uint32_t row = itx.rows[x];
             const FsRowSeg &rs = rsegs[row][itx.qs[x]];
-            const size_t lf = (size_t)(rs.t1 - itx.tile0) * WAVES + wave_of[row / N];
+            const size_t lf = (size_t)(rs.t1 - itx.tile0) * WAVES + itx.wv[x];
             const uint32_t id = t.fl_fptr[f.lp0 + lf] + fill[lf]++;
-            t.fl_flush[id] = (uint64_t)(((row % N) % ACC) * REGS) | ((uint64_t)id << 32);
+            t.fl_flush[id] = (uint64_t)((uint32_t)itx.sl[x] * REGS) | ((uint64_t)id << 32);
             t.fl_rseg_idx[t.fl_rseg_ptr[row] + itx.qs[x]] = id;
         }
     };

@@ -1035,10 +1035,10 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
             bool want = e->fs_ok;
             if (const char *env = std::getenv("TOMO_FP_LIST")) want = std::atoi(env) != 0;
             e->fl_ok = want && build_fp_lists(m, e->n, e->np, t, why);
-            // One angle per wave: a pass with fewer angles than waves, or angles of very different weight counts (1.0 ... 1.41 per pixel),
-            // leaves waves waiting at every tile's barrier.  Measured (MI355X, FP alone, lists against strips): 512^3 x 90 1.14 / 1.21 ms
-            // (balance 0.86), 512^3 x 70 0.96 / 1.06 (0.80), 1024 x 512^2 x 90 2.26 / 2.42, 1024^3 x 120 11.3 / 12.1 (0.79), but
-            // 128 x 1024^2 x 120 1.74 / 1.58 (0.79), 256^3 x 60 0.155 / 0.147 (0.69): lists from a balance of 0.8 on.
+            // The waves of a workgroup meet at a barrier after every tile, so a tile costs its busiest wave; build_fp_lists deals the rays
+            // to the waves by load (fl_balance = mean / max batches per wave and tile: 0.89-0.90 on the BASELINE geometries).  Measured
+            // (MI355X, FP alone, lists against strips): 512^3 x 90 1.12 / 1.22 ms, 512^3 x 70 0.92 / 1.06, 128 x 512^2 x 90 0.35 / 0.39,
+            // 256^3 x 60 0.138 / 0.147, 128 x 1024^2 x 120 1.58 / 1.58.  A geometry that cannot be balanced keeps the strips.
             if (e->fl_ok && !std::getenv("TOMO_FP_LIST") && t.fl_balance < 0.8) e->fl_ok = false;
             if (e->fl_ok) {
                 e->fl_nitems = (int)t.fl_item.size(); e->fl_nseg = t.fl_nseg;
