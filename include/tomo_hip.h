@@ -221,6 +221,8 @@ int tomo_fgp_end(tomo_engine *e, int iters);                            /* :272 
 int tomo_bind_fgp_halo(tomo_engine *e, void *lo, void *hi, void *send_first, void *send_last);
 int tomo_fgp_fused_begin(tomo_engine *e, int vol);
 int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration);
+int tomo_fgp_fused_step2(tomo_engine *e, float lambda, int first_iteration);   /* TWO iterations in one pass (P stays on chip between
+                                                                                * them; the same bits as two steps); whole-volume slabs only */
 int tomo_fgp_fused_end(tomo_engine *e, float lambda);                   /* the last iteration: D over the input volume */
 
 /* whole-call forms for a single slab (= the reference's single-GPU calls) */
@@ -250,6 +252,8 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     x_new into a second buffer" instead of "gradient pass (store g) + update pass (read x, g; write x)": one volume
  *                     write instead of two -- HBM writes are the scarce resource (3 TB/s against ~6 for reads); bit-identical
  *   "fgp_fused" (1):  one fused kernel per FGP iteration (single slab)
+ *   "fgp_pair" (1):   ... and two iterations per pass where the slab is the whole volume (k_fgp_fused2: 28 bytes per voxel for two
+ *                     iterations; the same bits); 0 = one iteration per pass
  *   "art_chain" (1):  tomo_art in natural row order as per-angle FP + ray recurrence + BP (k_art_chain) instead of
  *                     row-by-row steps (k_art, which still serves tomo_art_order with a permutation)
  *   "art_tile" (1):   the chained ART sweep as fused tile steps (BP of the previous angle + FP of the next in k_sart_tile's ART

@@ -872,6 +872,22 @@ def test_tile_projectors_match_row_and_pixel_driven_forms(gpu, N, P, Nx):
     assert np.array_equal(t0.get_volume(), t1.get_volume())
 
 
+@pytest.mark.parametrize("N,Nx,iters", [(40, 70, 7), (33, 130, 4), (64, 64, 3), (17, 5, 6), (96, 128, 10), (8, 200, 5), (72, 1, 8)])
+def test_two_fgp_iterations_per_pass_equal_two_passes(gpu, N, Nx, iters):
+    """k_fgp_fused2 (round 4: P carried through two FGP iterations on chip, halo cells recomputed) == two passes of k_fgp_fused,
+    bit for bit: odd and even iteration counts (the odd one out runs the one-iteration kernel), tiles cut by every face, one slice."""
+    x = ellipsoids(Nx, N, seed=9) + np.float32(0.1) * np.random.default_rng(2).random((Nx, N, N), dtype=np.float32)
+    out = {}
+    for pair in (1, 0):
+        t = tomoengine(Nx, N, np.deg2rad(np.array([-20.0, 35.0])))
+        t.set_option("fgp_pair", pair)
+        t.set_volume(x, VOL_RECON)
+        tv0 = t.tv_fgp(iters, 0.07)
+        out[pair] = (tv0, t.get_volume())
+    assert out[1][0] == out[0][0]
+    assert np.array_equal(out[1][1], out[0][1])
+
+
 @pytest.mark.parametrize("N,P,Nx", [(40, 7, 70), (96, 13, 128), (33, 5, 256), (16, 1, 128), (128, 31, 384), (50, 4, 100), (64, 9, 192)])
 def test_wave_uniform_back_projector_is_bit_identical(gpu, N, P, Nx):
     """k_bp_list (round 4: a wave = 128 slices of 32 pixels, the matrix as scalar-loaded entry lists of nonzero weights, accumulators

@@ -3214,6 +3214,25 @@ __global__ __launch_bounds__(256) void k_fgp_grad(const float *__restrict__ D, f
     }
 }
 
+// The two expressions of an FGP iteration, spelled out operation by operation (no contraction left to the compiler), so that
+// every kernel that evaluates them -- one iteration per pass, two per pass -- rounds alike: the forms are compared bit for bit.
+__device__ __forceinline__ float fgp_d_of(float a, float lambda, float p1, float p2, float p3, float v1, float v2, float v3)
+{
+#pragma clang fp contract(off)
+    const float t = p1 + p2 + p3 - v1 - v2 - v3;
+    return fmaxf(__builtin_fmaf(-lambda, t, a), 0.f);
+}
+__device__ __forceinline__ void fgp_p_of(float &a, float &b, float &c, float multip, float v1, float v2, float v3)
+{
+#pragma clang fp contract(off)
+    a = __builtin_fmaf(multip, v1, a); b = __builtin_fmaf(multip, v2, b); c = __builtin_fmaf(multip, v3, c);
+    const float denom = __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
+    if (denom > 1.0f) {
+        const float sq = 1.0f / sqrtf(denom);
+        a *= sq; b *= sq; c *= sq;
+    }
+}
+
 // ---- fused FGP iteration (single slab): D = max(0, A - lambda div P) is NOT written, only P_new ---------------
 // The reference runs Obj, nonneg, Grad, Proj as four full-volume kernels per iteration (tv_fgp.cu:244-268,
 // ~80 B/voxel); the two-kernel form above moves 48 B/voxel.  Here one kernel per iteration reads A and P (16 B),
@@ -3310,8 +3329,7 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
             float v1 = pl[0][par][zi][si - 1];                       // P1(s-1): zero-loaded below slice 0
             float v2 = y > 0 ? pl[1][par ^ 1][zi][si] : 0.f;         // P2(y-1)
             float v3 = pl[2][par][zi - 1][si];                       // P3(z-1): zero-loaded left of column 0
-            float d = al[zi][si] - lambda * (pl[0][par][zi][si] + pl[1][par][zi][si] + pl[2][par][zi][si] - v1 - v2 - v3);
-            dl[par][zq][sq] = fmaxf(d, 0.f);
+            dl[par][zq][sq] = fgp_d_of(al[zi][si], lambda, pl[0][par][zi][si], pl[1][par][zi][si], pl[2][par][zi][si], v1, v2, v3);
         }
     };
     fetch(y0 - 1); stash((y0 + 1) & 1);        // only P2(y0-1) is used
@@ -3343,12 +3361,8 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
                 float v1 = (s + 1 < nx || (SHARDED && !ed.last)) ? dc - dl[par][zq][sq + 1] : 0.f;
                 float v2 = y + 1 < n ? dc - dl[nxt][zq][sq] : 0.f;
                 float v3 = z + 1 < n ? dc - dl[par][zq + 1][sq] : 0.f;
-                float a = keep[q][0] + multip * v1, b = keep[q][1] + multip * v2, c = keep[q][2] + multip * v3;
-                float denom = a * a + b * b + c * c;
-                if (denom > 1.0f) {
-                    float sq_ = 1.0f / sqrtf(denom);
-                    a *= sq_; b *= sq_; c *= sq_;
-                }
+                float a = keep[q][0], b = keep[q][1], c = keep[q][2];
+                fgp_p_of(a, b, c, multip, v1, v2, v3);
                 size_t o = (size_t)(y * n + z) * sx + s;
                 nt_st<256>(a, P1o + o); nt_st<256>(b, P2o + o); nt_st<256>(c, P3o + o);
                 if (SHARDED) {
@@ -3360,6 +3374,168 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
         }
         __syncthreads();
     }
+}
+
+// ---- TWO fused FGP iterations per pass (single slab; round 4) -------------------------------------------------------------------
+// k_fgp_fused moves 28 B per voxel and iteration (A and P in, P_new out) and is bound by exactly that (0.72 ms at the 5.2 TB/s a
+// read + write stream gets, against ~0.4 ms of arithmetic).  Here a workgroup carries P through two iterations before it stores it:
+// per pixel row it rebuilds D^k on its tile + 2 halo cells, P^(k+1) on tile + 1 (the halo cells are recomputed, not exchanged:
+// (TZ+2)(64+2) / (TZ 64) = 1.29 x the tile), D^(k+1), and stores P^(k+2) of the tile: 28 B per voxel for TWO iterations, against
+// 2.27 x the arithmetic of one.  Every value is computed by the expressions of k_fgp_fused on the same operands, in the same order:
+// the result equals two passes of it bit for bit.  Rows travel global -> registers -> LDS one iteration ahead; rings of two rows.
+//   needs, for the stored row y:   D1(y), D1(y+1)  <-  P1(y), P1(y+1), P1_2(y-1)  <-  D0(y) .. D0(y+2)  <-  P0(y-1 .. y+2), A
+#ifndef F2_TZ_V
+#define F2_TZ_V 8
+#endif
+#ifndef F2_SC_V
+#define F2_SC_V 32
+#endif
+constexpr int F2_TZ = F2_TZ_V, F2_R = F2_TZ + 4, F2_SC = F2_SC_V, F2_S = F2_SC + 4;   // core slices per workgroup   // rows zi = column z0-2+zi, elements si = slice s0-2+si
+
+__global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A, const float *__restrict__ P1i,
+                                                     const float *__restrict__ P2i, const float *__restrict__ P3i,
+                                                     float *__restrict__ P1o, float *__restrict__ P2o, float *__restrict__ P3o,
+                                                     float lambda, float multip, int n, int nx, int sx, int yseg, int zero_p)
+{
+    __shared__ float pk[3][2][F2_R][F2_S];              // P^k, rows r (slot r & 1)
+    __shared__ float ak[2][F2_R][F2_S];                 // A
+    __shared__ float dk[2][F2_R][F2_S];                 // D^k
+    __shared__ float pn[3][2][F2_R][F2_S];              // P^(k+1)
+    __shared__ float dn[2][F2_R][F2_S];                 // D^(k+1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nzb = (n + F2_TZ - 1) / F2_TZ, nchunk = (nx + F2_SC - 1) / F2_SC, nys = (n + yseg - 1) / yseg;
+    int bz, bs, ysi;                                    // the item map of k_fgp_fused
+    if ((nzb & 7) == 0) {
+        const int zpx = nzb >> 3;
+        const int64_t li = blockIdx.x >> 3;
+        bs = (int)(li % nchunk); bz = (int)(blockIdx.x & 7) * zpx + (int)((li / nchunk) % zpx); ysi = (int)(li / ((int64_t)nchunk * zpx));
+    } else {
+        bs = (int)(blockIdx.x % nchunk); bz = (int)((blockIdx.x / nchunk) % nzb); ysi = (int)(blockIdx.x / ((int64_t)nchunk * nzb));
+    }
+    if (ysi >= nys) return;
+    const int y0 = ysi * yseg, y1 = min(y0 + yseg, n);
+    const int z0 = bz * F2_TZ, s0 = bs * F2_SC;
+    constexpr int NE = F2_R * F2_S, NT = (NE + 255) / 256;
+    // this thread's elements of a staged row: e = tid + 256 t -> (zi, si)
+    int ezi[NT], esi[NT];
+    bool einv[NT];                                      // inside the volume in z and s
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int e = tid + 256 * t;
+        ezi[t] = e / F2_S; esi[t] = e - ezi[t] * F2_S;
+        const int z = z0 - 2 + ezi[t], s = s0 - 2 + esi[t];
+        einv[t] = e < NE && z >= 0 && z < n && s >= 0 && s < nx;
+    }
+    float rg[4][NT];
+    auto fetch = [&](int y) {
+        const bool yin = y >= 0 && y < n;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool ok = yin && einv[t];
+            const size_t o = ok ? (size_t)(y * n + (z0 - 2 + ezi[t])) * sx + (s0 - 2 + esi[t]) : 0;
+            rg[0][t] = (ok && !zero_p) ? P1i[o] : 0.f;
+            rg[1][t] = (ok && !zero_p) ? P2i[o] : 0.f;
+            rg[2][t] = (ok && !zero_p) ? P3i[o] : 0.f;
+            rg[3][t] = ok ? A[o] : 0.f;
+        }
+    };
+    auto stash = [&](int par) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (tid + 256 * t < NE) {
+                pk[0][par][ezi[t]][esi[t]] = rg[0][t]; pk[1][par][ezi[t]][esi[t]] = rg[1][t];
+                pk[2][par][ezi[t]][esi[t]] = rg[2][t]; ak[par][ezi[t]][esi[t]] = rg[3][t];
+            }
+    };
+    // D of row r from the P fields `pf` (pk or pn), rows zi >= lo, elements si >= lo, into `df`
+#define F2_D(pf, df, r, lo)                                                                               \
+    {                                                                                                     \
+        const int par = (r) & 1;                                                                          \
+        constexpr int NR = F2_R - 2 * (lo) + 1, NS = F2_S - 2 * (lo) + 1;   /* zi, si = lo .. size - lo */        \
+        for (int e = tid; e < NR * NS; e += 256) {                                                        \
+            const int zq = e / NS, zi = zq + (lo), si = e - zq * NS + (lo);                               \
+            float v1 = pf[0][par][zi][si - 1];                                                            \
+            float v2 = (r) > 0 ? pf[1][par ^ 1][zi][si] : 0.f;                                            \
+            float v3 = pf[2][par][zi - 1][si];                                                            \
+            df[par][zi][si] = fgp_d_of(ak[par][zi][si], lambda, pf[0][par][zi][si], pf[1][par][zi][si], pf[2][par][zi][si], v1, v2, v3); \
+        }                                                                                                 \
+    }
+    // the P update of k_fgp_fused on one element: old P (a, b, c), D of the element and its three upper neighbours
+#define F2_P(a, b, c, dc, ds, dy, dz, y, z, s)                                                            \
+    {                                                                                                     \
+        float v1 = ((s) + 1 < nx) ? dc - ds : 0.f;                                                        \
+        float v2 = (y) + 1 < n ? dc - dy : 0.f;                                                           \
+        float v3 = (z) + 1 < n ? dc - dz : 0.f;                                                           \
+        fgp_p_of(a, b, c, multip, v1, v2, v3);                                                            \
+    }
+    // P^(k+1) of row r on rows zi 1 .. F2_R-2, elements si 1 .. F2_S-2 (zero outside the volume, as a load of it would give)
+    auto compute_pn = [&](int r) {
+        const int par = r & 1;
+        constexpr int NR = F2_R - 2, NS = F2_S - 2;
+        for (int e = tid; e < NR * NS; e += 256) {
+            const int zq = e / NS, zi = zq + 1, si = e - zq * NS + 1;
+            const int z = z0 - 2 + zi, s = s0 - 2 + si;
+            float a = 0.f, b = 0.f, c = 0.f;
+            if (r >= 0 && r < n && z >= 0 && z < n && s >= 0 && s < nx) {
+                a = pk[0][par][zi][si]; b = pk[1][par][zi][si]; c = pk[2][par][zi][si];
+                const float dc = dk[par][zi][si];
+                F2_P(a, b, c, dc, dk[par][zi][si + 1], dk[par ^ 1][zi][si], dk[par][zi + 1][si], r, z, s)
+            }
+            pn[0][par][zi][si] = a; pn[1][par][zi][si] = b; pn[2][par][zi][si] = c;
+        }
+    };
+    fetch(y0 - 2); stash(y0 & 1);                       // only P2(y0-2) is used
+    __syncthreads();
+    fetch(y0 - 1); stash((y0 - 1) & 1);
+    fetch(y0);
+    __syncthreads();
+    F2_D(pk, dk, y0 - 1, 1)
+    __syncthreads();
+    stash(y0 & 1);                                      // row y0 replaces row y0-2
+    fetch(y0 + 1);
+    __syncthreads();
+    F2_D(pk, dk, y0, 1)
+    __syncthreads();
+    compute_pn(y0 - 1);
+    __syncthreads();
+    stash((y0 + 1) & 1);                                // row y0+1 replaces row y0-1 (P, A) ...
+    fetch(y0 + 2);
+    __syncthreads();
+    F2_D(pk, dk, y0 + 1, 1)                             // ... and its D
+    __syncthreads();
+    compute_pn(y0);
+    __syncthreads();
+    F2_D(pn, dn, y0, 2)
+    __syncthreads();
+    for (int y = y0; y < y1; ++y) {
+        const int par = y & 1, nxt = par ^ 1;
+        stash(par);                                     // row y+2 replaces row y (P^k, A)
+        if (y + 1 < y1) fetch(y + 3);
+        __syncthreads();
+        F2_D(pk, dk, y + 2, 1)                          // D^k(y+2) replaces D^k(y)
+        __syncthreads();
+        compute_pn(y + 1);                              // P^(k+1)(y+1) replaces P^(k+1)(y-1)
+        __syncthreads();
+        F2_D(pn, dn, y + 1, 2)                          // D^(k+1)(y+1) replaces D^(k+1)(y-1)
+        __syncthreads();
+        // the tile's F2_TZ x F2_SC outputs of this row, 256 at a time
+#pragma unroll
+        for (int q = 0; q < F2_TZ * F2_SC / 256; ++q) {
+            const int o_ = tid + 256 * q, zi = 2 + o_ / F2_SC, si = 2 + o_ % F2_SC;
+            const int z = z0 - 2 + zi, s = s0 - 2 + si;
+            if (z < n && s < nx) {
+                float a = pn[0][par][zi][si], b = pn[1][par][zi][si], c = pn[2][par][zi][si];
+                const float dc = dn[par][zi][si];
+                F2_P(a, b, c, dc, dn[par][zi][si + 1], dn[nxt][zi][si], dn[par][zi + 1][si], y, z, s)
+                const size_t o = (size_t)(y * n + z) * sx + s;
+                nt_st<256>(a, P1o + o); nt_st<256>(b, P2o + o); nt_st<256>(c, P3o + o);
+            }
+        }
+        // (the next iteration's stash / D^k / P^(k+1) phases write slots this phase does not read; its D^(k+1) phase, which does,
+        // comes behind three barriers)
+    }
+#undef F2_P
+#undef F2_D
 }
 
 }  // namespace tomo

@@ -238,6 +238,7 @@ struct tomo_engine {
     float *fgp_p[3] = {nullptr, nullptr, nullptr};
     float *fgp_q[3] = {nullptr, nullptr, nullptr};   // ping-pong partners for the fused FGP iteration
     int fgp_fused = 1;
+    int fgp_pair = 1;                             // ... two iterations per pass (k_fgp_fused2) where the slab is not sharded
     float *stage = nullptr;
     size_t stage_bytes = 0;
     // scalars
@@ -2703,6 +2704,26 @@ int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration)
     return TOMO_OK;
 }
 
+// two iterations in one pass (k_fgp_fused2: P stays on chip between them; single slab only -- a sharded slab would need two-deep halos)
+int tomo_fgp_fused_step2(tomo_engine *e, float lambda, int first_iteration)
+{
+    NEED(e);
+    if (!e->fgp_q[2] || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
+    if (fgp_sharded(e)) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_step2 is for a slab that is the whole volume");
+    const int yseg = 32;
+    const int nzb = (e->n + F2_TZ - 1) / F2_TZ, nys = (e->n + yseg - 1) / yseg, nchunk = (e->nx + F2_SC - 1) / F2_SC;
+    dim3 grid((nzb & 7) == 0 ? 8u * (unsigned)((nzb >> 3) * nchunk * nys) : (unsigned)(nzb * nchunk * nys));
+    const float multip = 1.0f / (26.0f * lambda);
+    {
+        ProfScope ps(e, TOMO_K_FGP_GRAD);
+        hipLaunchKernelGGL(k_fgp_fused2, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0);
+    }
+    LAUNCHCHK();
+    for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
+    return TOMO_OK;
+}
+
 // the last iteration only needs D (tv_fgp.cu:272), written straight over the target volume
 int tomo_fgp_fused_end(tomo_engine *e, float lambda)
 {
@@ -2728,7 +2749,9 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
     if (fused) {
         // iterations 0..iters-2: one fused kernel each (D stays on chip); the last iteration only needs D
         rc = tomo_fgp_fused_begin(e, vol);
-        for (int i = 0; i + 1 < iters && !rc; ++i) rc = tomo_fgp_fused_step(e, lambda, i == 0);
+        int i = 0;
+        if (e->fgp_pair) for (; i + 2 < iters && !rc; i += 2) rc = tomo_fgp_fused_step2(e, lambda, i == 0);     // pairs, P kept on chip between
+        for (; i + 1 < iters && !rc; ++i) rc = tomo_fgp_fused_step(e, lambda, i == 0);
         if (!rc) rc = tomo_fgp_fused_end(e, lambda);
         e->is_first = f; e->is_last = l;
         return rc;
@@ -3016,6 +3039,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
 {
     if (!e || !name) return fail(TOMO_ERR_ARG, "null argument");
     if (std::strcmp(name, "fgp_fused") == 0) { e->fgp_fused = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "fgp_pair") == 0) { e->fgp_pair = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_fused") == 0) { e->sart_fused = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "art_chain") == 0) { e->art_chain = value ? 1 : 0; return TOMO_OK; }
