@@ -181,6 +181,17 @@ def test_fgp_fused_equals_two_kernel_form_at_full_size(tvbig):
     t.set_option("fgp_fused", 1)
     assert res[1][0] == res[0][0]
     assert np.array_equal(res[1][1], res[0][1]) or rel_l2(res[1][1], res[0][1]) < 1e-7
+    # two iterations per pass (k_fgp_fused2, what res[1] ran with) == one per pass, bit for bit, at an even and an odd count
+    for iters in (4, 7):
+        pair = {}
+        for p in (1, 0):
+            t.set_option("fgp_pair", p)
+            t.set_volume(x, VOL_RECON)
+            t.tv_fgp(iters, 0.1)
+            pair[p] = t.get_volume()
+        t.set_option("fgp_pair", 1)
+        assert np.array_equal(pair[1], pair[0]), iters
+    t.set_volume(res[1][1], VOL_RECON)
     t.tv_eps = 1e-6
     assert res[1][1].min() >= 0 and t.tv() < res[1][0]
 

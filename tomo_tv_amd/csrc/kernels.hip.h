@@ -3390,19 +3390,21 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
 #ifndef F2_SC_V
 #define F2_SC_V 32
 #endif
-constexpr int F2_TZ = F2_TZ_V, F2_R = F2_TZ + 4, F2_SC = F2_SC_V, F2_S = F2_SC + 4;   // core slices per workgroup   // rows zi = column z0-2+zi, elements si = slice s0-2+si
+constexpr int F2_TZ = F2_TZ_V, F2_R = F2_TZ + 4, F2_SC = F2_SC_V, F2_S = F2_SC + 4;   // columns x slices of a tile (8 x 32: 31 KB of LDS, five workgroups per CU;
+                                                                                        // 8 x 64 = 59 KB, two per CU, ran at 880 us per iteration against 604)   // rows zi = column z0-2+zi, elements si = slice s0-2+si
 
 __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A, const float *__restrict__ P1i,
                                                      const float *__restrict__ P2i, const float *__restrict__ P3i,
                                                      float *__restrict__ P1o, float *__restrict__ P2o, float *__restrict__ P3o,
                                                      float lambda, float multip, int n, int nx, int sx, int yseg, int zero_p)
 {
-    __shared__ float pk[3][2][F2_R][F2_S];              // P^k, rows r (slot r & 1)
-    __shared__ float ak[2][F2_R][F2_S];                 // A
-    __shared__ float dk[2][F2_R][F2_S];                 // D^k
-    __shared__ float pn[3][2][F2_R][F2_S];              // P^(k+1)
-    __shared__ float dn[2][F2_R][F2_S];                 // D^(k+1)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PL = F2_R * F2_S;                     // a staged plane: element zi * F2_S + si
+    __shared__ float pk[3][2][PL];                      // P^k, rows r (slot r & 1)
+    __shared__ float ak[2][PL];                         // A
+    __shared__ float dk[2][PL];                         // D^k
+    __shared__ float pn[3][2][PL];                      // P^(k+1)
+    __shared__ float dn[2][PL];                         // D^(k+1)
+    const int tid = threadIdx.x;
     const int nzb = (n + F2_TZ - 1) / F2_TZ, nchunk = (nx + F2_SC - 1) / F2_SC, nys = (n + yseg - 1) / yseg;
     int bz, bs, ysi;                                    // the item map of k_fgp_fused
     if ((nzb & 7) == 0) {
@@ -3415,24 +3417,49 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
     if (ysi >= nys) return;
     const int y0 = ysi * yseg, y1 = min(y0 + yseg, n);
     const int z0 = bz * F2_TZ, s0 = bs * F2_SC;
-    constexpr int NE = F2_R * F2_S, NT = (NE + 255) / 256;
-    // this thread's elements of a staged row: e = tid + 256 t -> (zi, si)
-    int ezi[NT], esi[NT];
-    bool einv[NT];                                      // inside the volume in z and s
+    // Every phase works on a rectangle of the staged plane, 256 elements a round; which elements are this thread's, where they sit
+    // and what the volume's faces make of them does not change along y: worked out once.
+    //   staged row (fetch / stash): zi 0 .. R-1, si 0 .. S-1       D^k:      zi 1 .. R-1, si 1 .. S-1
+    //   P^(k+1):                    zi 1 .. R-2, si 1 .. S-2       D^(k+1):  zi 2 .. R-2, si 2 .. S-2      output: zi 2 .. R-3, si 2 .. S-3
+    constexpr int NT = (PL + 255) / 256;
+    constexpr int ND = (F2_R - 1) * (F2_S - 1), RD = (ND + 255) / 256;
+    constexpr int NP = (F2_R - 2) * (F2_S - 2), RP = (NP + 255) / 256;
+    constexpr int NN = (F2_R - 3) * (F2_S - 3), RN = (NN + 255) / 256;
+    static_assert(F2_TZ * F2_SC == 256, "one output per thread and row");
+    int eo[NT]; size_t eg[NT]; bool einv[NT];           // staged element: plane offset (-1: none), offset in a volume row, inside in z and s
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int e = tid + 256 * t;
-        ezi[t] = e / F2_S; esi[t] = e - ezi[t] * F2_S;
-        const int z = z0 - 2 + ezi[t], s = s0 - 2 + esi[t];
-        einv[t] = e < NE && z >= 0 && z < n && s >= 0 && s < nx;
+        const int e = tid + 256 * t, zi = e / F2_S, si = e - zi * F2_S;
+        const int z = z0 - 2 + zi, s = s0 - 2 + si;
+        eo[t] = e < PL ? e : -1;
+        einv[t] = e < PL && z >= 0 && z < n && s >= 0 && s < nx;
+        eg[t] = einv[t] ? (size_t)z * sx + s : 0;
     }
+    int od[RD], op[RP], on[RN];
+    unsigned pf_[RP];                                   // P^(k+1) element: bit 0 inside the volume in z and s, bit 1 s+1 < nx, bit 2 z+1 < n
+#pragma unroll
+    for (int r = 0; r < RD; ++r) { const int e = tid + 256 * r, zq = e / (F2_S - 1); od[r] = e < ND ? (zq + 1) * F2_S + (e - zq * (F2_S - 1)) + 1 : -1; }
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        const int e = tid + 256 * r, zq = e / (F2_S - 2), zi = zq + 1, si = e - zq * (F2_S - 2) + 1;
+        const int z = z0 - 2 + zi, s = s0 - 2 + si;
+        op[r] = e < NP ? zi * F2_S + si : -1;
+        pf_[r] = (z >= 0 && z < n && s >= 0 && s < nx ? 1u : 0u) | (s + 1 < nx ? 2u : 0u) | (z + 1 < n ? 4u : 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < RN; ++r) { const int e = tid + 256 * r, zq = e / (F2_S - 3); on[r] = e < NN ? (zq + 2) * F2_S + (e - zq * (F2_S - 3)) + 2 : -1; }
+    const int ozi = 2 + tid / F2_SC, osi = 2 + tid % F2_SC, oo = ozi * F2_S + osi;
+    const int oz = z0 - 2 + ozi, os = s0 - 2 + osi;
+    const bool oin = oz < n && os < nx, os1 = os + 1 < nx, oz1 = oz + 1 < n;
+    const size_t og = (size_t)oz * sx + os;
     float rg[4][NT];
     auto fetch = [&](int y) {
         const bool yin = y >= 0 && y < n;
+        const size_t row = yin ? (size_t)y * n * sx : 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const bool ok = yin && einv[t];
-            const size_t o = ok ? (size_t)(y * n + (z0 - 2 + ezi[t])) * sx + (s0 - 2 + esi[t]) : 0;
+            const size_t o = row + eg[t];
             rg[0][t] = (ok && !zero_p) ? P1i[o] : 0.f;
             rg[1][t] = (ok && !zero_p) ? P2i[o] : 0.f;
             rg[2][t] = (ok && !zero_p) ? P3i[o] : 0.f;
@@ -3442,46 +3469,41 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
     auto stash = [&](int par) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            if (tid + 256 * t < NE) {
-                pk[0][par][ezi[t]][esi[t]] = rg[0][t]; pk[1][par][ezi[t]][esi[t]] = rg[1][t];
-                pk[2][par][ezi[t]][esi[t]] = rg[2][t]; ak[par][ezi[t]][esi[t]] = rg[3][t];
-            }
+            if (eo[t] >= 0) { pk[0][par][eo[t]] = rg[0][t]; pk[1][par][eo[t]] = rg[1][t]; pk[2][par][eo[t]] = rg[2][t]; ak[par][eo[t]] = rg[3][t]; }
     };
-    // D of row r from the P fields `pf` (pk or pn), rows zi >= lo, elements si >= lo, into `df`
-#define F2_D(pf, df, r, lo)                                                                               \
+    // D of row r from the P fields `pf` (pk or pn) at this thread's elements `off` (od or on) into `df`
+#define F2_D(pf, df, r, off, NRND)                                                                        \
     {                                                                                                     \
         const int par = (r) & 1;                                                                          \
-        constexpr int NR = F2_R - 2 * (lo) + 1, NS = F2_S - 2 * (lo) + 1;   /* zi, si = lo .. size - lo */        \
-        for (int e = tid; e < NR * NS; e += 256) {                                                        \
-            const int zq = e / NS, zi = zq + (lo), si = e - zq * NS + (lo);                               \
-            float v1 = pf[0][par][zi][si - 1];                                                            \
-            float v2 = (r) > 0 ? pf[1][par ^ 1][zi][si] : 0.f;                                            \
-            float v3 = pf[2][par][zi - 1][si];                                                            \
-            df[par][zi][si] = fgp_d_of(ak[par][zi][si], lambda, pf[0][par][zi][si], pf[1][par][zi][si], pf[2][par][zi][si], v1, v2, v3); \
+        _Pragma("unroll") for (int q = 0; q < NRND; ++q) {                                                \
+            const int o = off[q];                                                                         \
+            if (o >= 0) {                                                                                 \
+                float v1 = pf[0][par][o - 1];                                                             \
+                float v2 = (r) > 0 ? pf[1][par ^ 1][o] : 0.f;                                             \
+                float v3 = pf[2][par][o - F2_S];                                                          \
+                df[par][o] = fgp_d_of(ak[par][o], lambda, pf[0][par][o], pf[1][par][o], pf[2][par][o], v1, v2, v3); \
+            }                                                                                             \
         }                                                                                                 \
     }
-    // the P update of k_fgp_fused on one element: old P (a, b, c), D of the element and its three upper neighbours
-#define F2_P(a, b, c, dc, ds, dy, dz, y, z, s)                                                            \
-    {                                                                                                     \
-        float v1 = ((s) + 1 < nx) ? dc - ds : 0.f;                                                        \
-        float v2 = (y) + 1 < n ? dc - dy : 0.f;                                                           \
-        float v3 = (z) + 1 < n ? dc - dz : 0.f;                                                           \
-        fgp_p_of(a, b, c, multip, v1, v2, v3);                                                            \
-    }
-    // P^(k+1) of row r on rows zi 1 .. F2_R-2, elements si 1 .. F2_S-2 (zero outside the volume, as a load of it would give)
+    // P^(k+1) of row r (zero outside the volume, as a load of it would give)
     auto compute_pn = [&](int r) {
         const int par = r & 1;
-        constexpr int NR = F2_R - 2, NS = F2_S - 2;
-        for (int e = tid; e < NR * NS; e += 256) {
-            const int zq = e / NS, zi = zq + 1, si = e - zq * NS + 1;
-            const int z = z0 - 2 + zi, s = s0 - 2 + si;
-            float a = 0.f, b = 0.f, c = 0.f;
-            if (r >= 0 && r < n && z >= 0 && z < n && s >= 0 && s < nx) {
-                a = pk[0][par][zi][si]; b = pk[1][par][zi][si]; c = pk[2][par][zi][si];
-                const float dc = dk[par][zi][si];
-                F2_P(a, b, c, dc, dk[par][zi][si + 1], dk[par ^ 1][zi][si], dk[par][zi + 1][si], r, z, s)
+        const bool rin = r >= 0 && r < n, r1 = r + 1 < n;
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+            const int o = op[q];
+            if (o >= 0) {
+                float a = 0.f, b = 0.f, c = 0.f;
+                if (rin && (pf_[q] & 1u)) {
+                    a = pk[0][par][o]; b = pk[1][par][o]; c = pk[2][par][o];
+                    const float dc = dk[par][o];
+                    const float v1 = (pf_[q] & 2u) ? dc - dk[par][o + 1] : 0.f;
+                    const float v2 = r1 ? dc - dk[par ^ 1][o] : 0.f;
+                    const float v3 = (pf_[q] & 4u) ? dc - dk[par][o + F2_S] : 0.f;
+                    fgp_p_of(a, b, c, multip, v1, v2, v3);
+                }
+                pn[0][par][o] = a; pn[1][par][o] = b; pn[2][par][o] = c;
             }
-            pn[0][par][zi][si] = a; pn[1][par][zi][si] = b; pn[2][par][zi][si] = c;
         }
     };
     fetch(y0 - 2); stash(y0 & 1);                       // only P2(y0-2) is used
@@ -3489,52 +3511,48 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
     fetch(y0 - 1); stash((y0 - 1) & 1);
     fetch(y0);
     __syncthreads();
-    F2_D(pk, dk, y0 - 1, 1)
+    F2_D(pk, dk, y0 - 1, od, RD)
     __syncthreads();
     stash(y0 & 1);                                      // row y0 replaces row y0-2
     fetch(y0 + 1);
     __syncthreads();
-    F2_D(pk, dk, y0, 1)
+    F2_D(pk, dk, y0, od, RD)
     __syncthreads();
     compute_pn(y0 - 1);
     __syncthreads();
     stash((y0 + 1) & 1);                                // row y0+1 replaces row y0-1 (P, A) ...
     fetch(y0 + 2);
     __syncthreads();
-    F2_D(pk, dk, y0 + 1, 1)                             // ... and its D
+    F2_D(pk, dk, y0 + 1, od, RD)                        // ... and its D
     __syncthreads();
     compute_pn(y0);
     __syncthreads();
-    F2_D(pn, dn, y0, 2)
+    F2_D(pn, dn, y0, on, RN)
     __syncthreads();
     for (int y = y0; y < y1; ++y) {
         const int par = y & 1, nxt = par ^ 1;
         stash(par);                                     // row y+2 replaces row y (P^k, A)
         if (y + 1 < y1) fetch(y + 3);
         __syncthreads();
-        F2_D(pk, dk, y + 2, 1)                          // D^k(y+2) replaces D^k(y)
+        F2_D(pk, dk, y + 2, od, RD)                     // D^k(y+2) replaces D^k(y)
         __syncthreads();
         compute_pn(y + 1);                              // P^(k+1)(y+1) replaces P^(k+1)(y-1)
         __syncthreads();
-        F2_D(pn, dn, y + 1, 2)                          // D^(k+1)(y+1) replaces D^(k+1)(y-1)
+        F2_D(pn, dn, y + 1, on, RN)                     // D^(k+1)(y+1) replaces D^(k+1)(y-1)
         __syncthreads();
-        // the tile's F2_TZ x F2_SC outputs of this row, 256 at a time
-#pragma unroll
-        for (int q = 0; q < F2_TZ * F2_SC / 256; ++q) {
-            const int o_ = tid + 256 * q, zi = 2 + o_ / F2_SC, si = 2 + o_ % F2_SC;
-            const int z = z0 - 2 + zi, s = s0 - 2 + si;
-            if (z < n && s < nx) {
-                float a = pn[0][par][zi][si], b = pn[1][par][zi][si], c = pn[2][par][zi][si];
-                const float dc = dn[par][zi][si];
-                F2_P(a, b, c, dc, dn[par][zi][si + 1], dn[nxt][zi][si], dn[par][zi + 1][si], y, z, s)
-                const size_t o = (size_t)(y * n + z) * sx + s;
-                nt_st<256>(a, P1o + o); nt_st<256>(b, P2o + o); nt_st<256>(c, P3o + o);
-            }
+        if (oin) {                                      // the tile's 256 outputs of this row
+            float a = pn[0][par][oo], b = pn[1][par][oo], c = pn[2][par][oo];
+            const float dc = dn[par][oo];
+            const float v1 = os1 ? dc - dn[par][oo + 1] : 0.f;
+            const float v2 = y + 1 < n ? dc - dn[nxt][oo] : 0.f;
+            const float v3 = oz1 ? dc - dn[par][oo + F2_S] : 0.f;
+            fgp_p_of(a, b, c, multip, v1, v2, v3);
+            const size_t o = (size_t)y * n * sx + og;
+            nt_st<256>(a, P1o + o); nt_st<256>(b, P2o + o); nt_st<256>(c, P3o + o);
         }
         // (the next iteration's stash / D^k / P^(k+1) phases write slots this phase does not read; its D^(k+1) phase, which does,
         // comes behind three barriers)
     }
-#undef F2_P
 #undef F2_D
 }
 

@@ -2710,7 +2710,7 @@ int tomo_fgp_fused_step2(tomo_engine *e, float lambda, int first_iteration)
     NEED(e);
     if (!e->fgp_q[2] || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
     if (fgp_sharded(e)) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_step2 is for a slab that is the whole volume");
-    const int yseg = 32;
+    const int yseg = 32;                                 // (16 ... 64 within 3 %; 128 and more lose to the tail)
     const int nzb = (e->n + F2_TZ - 1) / F2_TZ, nys = (e->n + yseg - 1) / yseg, nchunk = (e->nx + F2_SC - 1) / F2_SC;
     dim3 grid((nzb & 7) == 0 ? 8u * (unsigned)((nzb >> 3) * nchunk * nys) : (unsigned)(nzb * nchunk * nys));
     const float multip = 1.0f / (26.0f * lambda);
