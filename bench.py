@@ -401,9 +401,15 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     t.set_option("fp_reuse", 0)
     ms_noreuse = _time_steps(t, fista_iter, 5)
     t.set_option("fp_reuse", 1)
+    # tv_fgp(10): 9 fused FGP iterations + the final D pass.  With "fgp_pair" (round 4) they run as 4 launches of k_fgp_fused2 (two
+    # iterations each: A and P in, P out ONCE per pair) + 1 of k_fgp_fused, all logged under one slot: the roofline prices a launch at
+    # the bytes it has to move, 28 V per launch whether it advances P by one iteration or by two
+    pair = bool(t.get_option("fgp_pair"))
+    fgp = roof("k_fgp_fused2 (x4) + k_fgp_fused (x1)" if pair else "k_fgp_fused", cnt, tot, 28 * V, busy_ms=busy)
+    fgp["fgp_iterations_per_step"] = 9
+    fgp["ms_per_fgp_iteration"] = tot / max(cnt, 1) * (5 if pair else 9) / 9
     out["config3_fista_512cube_x90tilts"] = {"ms_per_step": ms, "ms_per_step_every_projection_recomputed": ms_noreuse,
-                                             "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
-                                             "roofline": roof("k_fgp_fused", cnt, tot, 28 * V, busy_ms=busy)}
+                                             "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6, "roofline": fgp}
     t.remove_momentum()
     t.restart_recon()
     log = KernelLog(t, {"k_fp_tile": K_FP_TILE, "k_fp_tile_reduce": K_FP_REDUCE, "k_bp_tile": K_BP_TILE})

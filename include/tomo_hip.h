@@ -304,7 +304,7 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *   "fp_tile_pipe" (0): experimental, P >= 2: the tile projector runs as P groups of 64-slice chunks, the reduce pass of one
  *                     group on a second stream beside the tile pass of the next (no gain measured) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
-/* read back a switch, or a fact about the engine: "fp_strip", "fp_list", "fp_tile", "bp_tile", "bp_list", "fp_reuse", "sart_tile", and
+/* read back a switch, or a fact about the engine: "fp_strip", "fp_list", "fp_tile", "bp_tile", "bp_list", "fgp_pair", "fp_reuse", "sart_tile", and
  * "fp_list_ready" (1: the list form of the strips was built),
  * "bp_list_ready" (1: the entry lists of k_bp_list were built: every tile's ray windows fit and there are at most 192 angles),
  * "fp_strip_ready" (1: the sheared-strip tables were built at creation -- by the slab-size rule or TOMO_FP_STRIP=1 -- so

@@ -3026,6 +3026,7 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "fp_tile") == 0) { *value = e->fp_tile; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { *value = e->bp_tile; return TOMO_OK; }
     if (std::strcmp(name, "bp_list") == 0) { *value = e->bp_list; return TOMO_OK; }
+    if (std::strcmp(name, "fgp_pair") == 0) { *value = e->fgp_pair; return TOMO_OK; }
     if (std::strcmp(name, "fp_list") == 0) { *value = e->fp_list; return TOMO_OK; }
     if (std::strcmp(name, "fp_list_ready") == 0) { *value = e->fl_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_list_ready") == 0) { *value = e->bl_ok ? 1 : 0; return TOMO_OK; }
