@@ -367,7 +367,7 @@ def _time_steps(t, fn, steps, warmup=1):
 
 def secondary_configs(nnz_per_pixel_angle=1.22):
     from tomo_tv_amd import pytvlib
-    from tomo_tv_amd._lib import K_BP_TILE, K_FGP_GRAD, K_FP_REDUCE, K_FP_TILE, K_SART_FUSED, VOL_YK
+    from tomo_tv_amd._lib import K_BP_TILE, K_FGP_GRAD, K_FGP_OBJ, K_FP_REDUCE, K_FP_TILE, K_SART_FUSED, VOL_YK
     out = {}
     # ---- config 2: 256^3, 60 tilts, SART (beta 1, sequential) + data_distance per iteration
     t = _engine(256, 256, 60)
@@ -395,19 +395,23 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
         cost = 0.5 * t.data_distance() ** 2 + 0.1 * t.tv()
         t.fista_project_yk()            # what TomoGPU.fista does: A yk for the next step from this A r and the last (linearity)
         return cost
-    log = KernelLog(t, {"k_fgp_fused": K_FGP_GRAD})
+    log = KernelLog(t, {"k_fgp_fused": K_FGP_GRAD, "k_fgp_last": K_FGP_OBJ})
     ms = _time_steps(t, fista_iter, 5)
-    cnt, tot, busy = log.read()["k_fgp_fused"]
+    rd = log.read()
+    (cnt, tot, busy), last = rd["k_fgp_fused"], rd["k_fgp_last"]
     t.set_option("fp_reuse", 0)
     ms_noreuse = _time_steps(t, fista_iter, 5)
     t.set_option("fp_reuse", 1)
-    # tv_fgp(10): 9 fused FGP iterations + the final D pass.  With "fgp_pair" (round 4) they run as 4 launches of k_fgp_fused2 (two
-    # iterations each: A and P in, P out ONCE per pair) + 1 of k_fgp_fused, all logged under one slot: the roofline prices a launch at
-    # the bytes it has to move, 28 V per launch whether it advances P by one iteration or by two
+    # tv_fgp(10): 9 FGP iterations + D of the last one.  With "fgp_pair" (round 4) that is 4 launches of k_fgp_fused2 (two iterations
+    # each: A and P in, P out ONCE per pair) + 1 launch of its FINAL form (the ninth iteration and D in one pass: A and P in, D out),
+    # logged under the GRAD and OBJ slots; without it 9 launches of k_fgp_fused + k_fgp_obj.  The roofline prices a pair launch at the
+    # bytes it has to move: 28 V whether it advances P by one iteration or by two
     pair = bool(t.get_option("fgp_pair"))
-    fgp = roof("k_fgp_fused2 (x4) + k_fgp_fused (x1)" if pair else "k_fgp_fused", cnt, tot, 28 * V, busy_ms=busy)
+    fgp = roof("k_fgp_fused2<false> (two iterations per launch)" if pair else "k_fgp_fused", cnt, tot, 28 * V, busy_ms=busy)
     fgp["fgp_iterations_per_step"] = 9
-    fgp["ms_per_fgp_iteration"] = tot / max(cnt, 1) * (5 if pair else 9) / 9
+    fgp["last_pass"] = dict(zip(("launches", "total_ms", "busy_ms"), last), kernel="k_fgp_fused2<true> (iteration + D)" if pair else "k_fgp_obj",
+                            algorithmic_bytes_per_launch=20 * V)
+    fgp["ms_per_fgp_iteration"] = (tot + last[1]) / max(last[0], 1) / 9          # all passes of a tv_fgp call over its 9 iterations
     out["config3_fista_512cube_x90tilts"] = {"ms_per_step": ms, "ms_per_step_every_projection_recomputed": ms_noreuse,
                                              "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6, "roofline": fgp}
     t.remove_momentum()

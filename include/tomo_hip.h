@@ -224,6 +224,8 @@ int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration);
 int tomo_fgp_fused_step2(tomo_engine *e, float lambda, int first_iteration);   /* TWO iterations in one pass (P stays on chip between
                                                                                 * them; the same bits as two steps); whole-volume slabs only */
 int tomo_fgp_fused_end(tomo_engine *e, float lambda);                   /* the last iteration: D over the input volume */
+int tomo_fgp_fused_last(tomo_engine *e, float lambda, int first_iteration);   /* one more step AND the end in one pass (the same bits);
+                                                                               * whole-volume slabs only */
 
 /* whole-call forms for a single slab (= the reference's single-GPU calls) */
 int tomo_tv(tomo_engine *e, int vol, float eps);                        /* tomoengine.cpp:439-442 tv_3D -> TOMO_S_TV */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "tomo_fgp_fused_begin": [_p, _i],
     "tomo_fgp_fused_step": [_p, _f, _i],
     "tomo_fgp_fused_step2": [_p, _f, _i],
+    "tomo_fgp_fused_last": [_p, _f, _i],
     "tomo_fgp_fused_end": [_p, _f],
     "tomo_get_stream": [_p, _pp],
     "tomo_mm_model": [_p, _p, _i, _p, _f, _p, _i],

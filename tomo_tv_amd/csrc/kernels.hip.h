@@ -3156,6 +3156,25 @@ __global__ __launch_bounds__(256) void k_tv_update(f4 *__restrict__ x, const f4 
 
 // FGP-TV (tv_fgp.cu).  Non-periodic: i-1 below the first GLOBAL slice and i+1 above the last are "0" terms.
 // D = max(0, A - lambda (P1 + P2 + P3 - P1[i-1] - P2[j-1] - P3[k-1]))        (:44-65, :143-154)
+// The two expressions of an FGP iteration, spelled out operation by operation (no contraction left to the compiler), so that
+// every kernel that evaluates them -- one iteration per pass, two per pass -- rounds alike: the forms are compared bit for bit.
+__device__ __forceinline__ float fgp_d_of(float a, float lambda, float p1, float p2, float p3, float v1, float v2, float v3)
+{
+#pragma clang fp contract(off)
+    const float t = p1 + p2 + p3 - v1 - v2 - v3;
+    return fmaxf(__builtin_fmaf(-lambda, t, a), 0.f);
+}
+__device__ __forceinline__ void fgp_p_of(float &a, float &b, float &c, float multip, float v1, float v2, float v3)
+{
+#pragma clang fp contract(off)
+    a = __builtin_fmaf(multip, v1, a); b = __builtin_fmaf(multip, v2, b); c = __builtin_fmaf(multip, v3, c);
+    const float denom = __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
+    if (denom > 1.0f) {
+        const float sq = 1.0f / sqrtf(denom);
+        a *= sq; b *= sq; c *= sq;
+    }
+}
+
 // D may be A itself (the fused single-slab form finishes in place: each voxel reads only its own A)
 __global__ __launch_bounds__(256) void k_fgp_obj(const float *A, float *D,
                                                   const float *__restrict__ P1, const float *__restrict__ P2,
@@ -3176,8 +3195,7 @@ __global__ __launch_bounds__(256) void k_fgp_obj(const float *A, float *D,
             float v1 = s > 0 ? P1[q - 1] : (first ? 0.f : p1_lo[p]);
             float v2 = y > 0 ? P2[q - (size_t)n * sx] : 0.f;
             float v3 = z > 0 ? P3[q - sx] : 0.f;
-            float d = A[q] - lambda * (P1[q] + P2[q] + P3[q] - v1 - v2 - v3);
-            D[q] = fmaxf(d, 0.f);
+            D[q] = fgp_d_of(A[q], lambda, P1[q], P2[q], P3[q], v1, v2, v3);
         }
     }
 }
@@ -3203,33 +3221,10 @@ __global__ __launch_bounds__(256) void k_fgp_grad(const float *__restrict__ D, f
             float v1 = s + 1 < nx ? dc - D[q + 1] : (last ? 0.f : dc - d_hi[p]);
             float v2 = y + 1 < n ? dc - D[q + (size_t)n * sx] : 0.f;
             float v3 = z + 1 < n ? dc - D[q + sx] : 0.f;
-            float a = P1[q] + multip * v1, b = P2[q] + multip * v2, c = P3[q] + multip * v3;
-            float denom = a * a + b * b + c * c;
-            if (denom > 1.0f) {
-                float sq = 1.0f / sqrtf(denom);
-                a *= sq; b *= sq; c *= sq;
-            }
+            float a = P1[q], b = P2[q], c = P3[q];
+            fgp_p_of(a, b, c, multip, v1, v2, v3);
             P1[q] = a; P2[q] = b; P3[q] = c;
         }
-    }
-}
-
-// The two expressions of an FGP iteration, spelled out operation by operation (no contraction left to the compiler), so that
-// every kernel that evaluates them -- one iteration per pass, two per pass -- rounds alike: the forms are compared bit for bit.
-__device__ __forceinline__ float fgp_d_of(float a, float lambda, float p1, float p2, float p3, float v1, float v2, float v3)
-{
-#pragma clang fp contract(off)
-    const float t = p1 + p2 + p3 - v1 - v2 - v3;
-    return fmaxf(__builtin_fmaf(-lambda, t, a), 0.f);
-}
-__device__ __forceinline__ void fgp_p_of(float &a, float &b, float &c, float multip, float v1, float v2, float v3)
-{
-#pragma clang fp contract(off)
-    a = __builtin_fmaf(multip, v1, a); b = __builtin_fmaf(multip, v2, b); c = __builtin_fmaf(multip, v3, c);
-    const float denom = __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
-    if (denom > 1.0f) {
-        const float sq = 1.0f / sqrtf(denom);
-        a *= sq; b *= sq; c *= sq;
     }
 }
 
@@ -3393,6 +3388,10 @@ __global__ __launch_bounds__(256) void k_fgp_fused(const float *__restrict__ A, 
 constexpr int F2_TZ = F2_TZ_V, F2_R = F2_TZ + 4, F2_SC = F2_SC_V, F2_S = F2_SC + 4;   // columns x slices of a tile (8 x 32: 31 KB of LDS, five workgroups per CU;
                                                                                         // 8 x 64 = 59 KB, two per CU, ran at 880 us per iteration against 604)   // rows zi = column z0-2+zi, elements si = slice s0-2+si
 
+// FINAL: the call's last pass -- one iteration and then D = max(0, A - lambda div P) of the result, which is all the last iteration
+// of tv_fgp.cu needs (:272): D^(k+1) of the tile goes to P1o (a scratch volume: A's halo cells are other tiles' outputs, so the
+// result cannot land on A in place; the engine swaps the buffers), P^(k+1) is never stored.
+template <bool FINAL>
 __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A, const float *__restrict__ P1i,
                                                      const float *__restrict__ P2i, const float *__restrict__ P3i,
                                                      float *__restrict__ P1o, float *__restrict__ P2o, float *__restrict__ P3o,
@@ -3540,7 +3539,9 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
         __syncthreads();
         F2_D(pn, dn, y + 1, on, RN)                     // D^(k+1)(y+1) replaces D^(k+1)(y-1)
         __syncthreads();
-        if (oin) {                                      // the tile's 256 outputs of this row
+        if (FINAL) {
+            if (oin) nt_st<256>(dn[par][oo], P1o + (size_t)y * n * sx + og);
+        } else if (oin) {                               // the tile's 256 outputs of this row
             float a = pn[0][par][oo], b = pn[1][par][oo], c = pn[2][par][oo];
             const float dc = dn[par][oo];
             const float v1 = os1 ? dc - dn[par][oo + 1] : 0.f;

@@ -2716,11 +2716,34 @@ int tomo_fgp_fused_step2(tomo_engine *e, float lambda, int first_iteration)
     const float multip = 1.0f / (26.0f * lambda);
     {
         ProfScope ps(e, TOMO_K_FGP_GRAD);
-        hipLaunchKernelGGL(k_fgp_fused2, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+        hipLaunchKernelGGL(k_fgp_fused2<false>, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
                            e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0);
     }
     LAUNCHCHK();
     for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
+    return TOMO_OK;
+}
+
+// one more iteration AND the call's result in one pass (k_fgp_fused2<true>): D of the iteration's P, which is never stored; the
+// result is written to a scratch volume that then changes places with the target's buffer.  Whole-volume slabs only.
+int tomo_fgp_fused_last(tomo_engine *e, float lambda, int first_iteration)
+{
+    NEED(e);
+    if (!e->fgp_q[2] || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
+    if (fgp_sharded(e)) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_last is for a slab that is the whole volume");
+    if (e->fgp_target < 0 || e->fgp_target >= TOMO_VOL_SLOTS) return fail(TOMO_ERR_STATE, "no target volume");
+    const int yseg = 32;
+    const int nzb = (e->n + F2_TZ - 1) / F2_TZ, nys = (e->n + yseg - 1) / yseg, nchunk = (e->nx + F2_SC - 1) / F2_SC;
+    dim3 grid((nzb & 7) == 0 ? 8u * (unsigned)((nzb >> 3) * nchunk * nys) : (unsigned)(nzb * nchunk * nys));
+    const float multip = 1.0f / (26.0f * lambda);
+    {
+        ProfScope ps(e, TOMO_K_FGP_OBJ);
+        hipLaunchKernelGGL(k_fgp_fused2<true>, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0);
+    }
+    LAUNCHCHK();
+    std::swap(e->vol[e->fgp_target], e->fgp_q[0]);         // the prox result's buffer becomes the volume; the old one is scratch now
+    ++e->vol_version[e->fgp_target];
     return TOMO_OK;
 }
 
@@ -2751,8 +2774,12 @@ int tomo_tv_fgp_vol(tomo_engine *e, int vol, int iters, float lambda)
         rc = tomo_fgp_fused_begin(e, vol);
         int i = 0;
         if (e->fgp_pair) for (; i + 2 < iters && !rc; i += 2) rc = tomo_fgp_fused_step2(e, lambda, i == 0);     // pairs, P kept on chip between
-        for (; i + 1 < iters && !rc; ++i) rc = tomo_fgp_fused_step(e, lambda, i == 0);
-        if (!rc) rc = tomo_fgp_fused_end(e, lambda);
+        if (e->fgp_pair && i + 2 == iters) {              // an odd iteration out and the result: one pass
+            if (!rc) rc = tomo_fgp_fused_last(e, lambda, i == 0);
+        } else {
+            for (; i + 1 < iters && !rc; ++i) rc = tomo_fgp_fused_step(e, lambda, i == 0);
+            if (!rc) rc = tomo_fgp_fused_end(e, lambda);
+        }
         e->is_first = f; e->is_last = l;
         return rc;
     }
