@@ -1551,6 +1551,7 @@ void k_bp_list(float *__restrict__ x, const uint4 *__restrict__ lent, const uint
 #pragma unroll
     for (int q = 0; q < 32; ++q) { acc_lo[q] = 0.f; acc_hi[q] = 0.f; }
     // (the dynamic LDS block is the kernel's only one, so it starts at LDS address 0 and a row offset IS its address)
+    if ((uint32_t)(size_t)(__attribute__((address_space(3))) V *)bl_lds != 0u) __builtin_trap();
     const uint32_t base = (uint32_t)lane * 8u, mask = ~(uint32_t)(BL_ROWB - 1);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");
     __syncthreads();
@@ -1726,6 +1727,7 @@ void k_fp_list(const float *__restrict__ x, const FlItemD *__restrict__ items, c
 #pragma unroll
     for (int q = 0; q < 32; ++q) { acc_lo[q] = 0.f; acc_hi[q] = 0.f; }
     // (the dynamic LDS block is the kernel's only one, so it starts at LDS address 0 and a pixel's offset IS its address)
+    if ((uint32_t)(size_t)(__attribute__((address_space(3))) V *)fl_lds != 0u) __builtin_trap();
     const uint32_t base = (uint32_t)lane * 8u, mask = ~(uint32_t)(FL_PIXB - 1);
     // partial sum `id` of this 128-slice piece: part[(id * ncp + 2 c2) * 64 + 2 lane]
     const uint64_t pb = (uint64_t)(size_t)(part + (size_t)c2 * 128);
