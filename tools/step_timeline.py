@@ -11,7 +11,7 @@ def fam(n):
     if n.startswith("k_sart_tile<false"): return "fp_angle"
     if n.startswith("k_sart_tile"): return "sart_tile"
     if n.startswith("k_tv_march4"): return "tv"
-    if n.startswith("k_fp_tile"): return "fp_all"
+    if n.startswith(("k_fp_tile", "k_fp_strip", "k_fp_list")): return "fp_all"
     return n.split("<")[0]
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), fam(r["Kernel_Name"])) for r in rows]
 # a sweep starts with two fp_angle launches (two chains) close together
