@@ -6,6 +6,8 @@ import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import oracle
+import torch
+torch.cuda.init()          # before the library touches the device (torch started second found "No HIP GPUs" on this image)
 from local_ring import ThreadRing
 from tomo_tv_amd._lib import VOL_ORIGINAL, VOL_RECON
 from tomo_tv_amd.engine import ctvlib, system_matrix, tomoengine
