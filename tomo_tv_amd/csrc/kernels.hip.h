@@ -1447,6 +1447,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_bp_tile(float *__restrict__ x, c
 // LDS reads), the rest is the staging (DMA issue + the wait at the stage's end) and the epilogue.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v32f __attribute__((ext_vector_type(32)));
+typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 constexpr int BL_TY = 16, BL_TZ = 16, BL_PIX = BL_TY * BL_TZ, BL_THREADS = 512, BL_WAVES = BL_THREADS / 64, BL_PPW = BL_PIX / BL_WAVES;
 constexpr int BL_A = 3, BL_MAXR = 26, BL_ROWB = 512;   // angles per stage, rows of a 16 x 16 tile's window (<= 16 sqrt 2 + 2), bytes of a row
 constexpr int BL_BUF = BL_A * BL_MAXR * BL_ROWB, BL_LDS_BYTES = 2 * BL_BUF;         // 79,872 bytes: two workgroups per CU
@@ -1474,8 +1475,6 @@ __device__ __forceinline__ int bl_lz(int w, int q) { return (w & 3) * 4 + (q & 3
     "s_set_gpr_idx_off\n"
 #define BL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define BL_CLOBBERS                                                                                       \
-    BL_CLOB4(s, 36, 37, 38, 39), BL_CLOB4(s, 40, 41, 42, 43), BL_CLOB4(s, 44, 45, 46, 47), BL_CLOB4(s, 48, 49, 50, 51),      \
-    BL_CLOB4(s, 52, 53, 54, 55), BL_CLOB4(s, 56, 57, 58, 59), BL_CLOB4(s, 60, 61, 62, 63), BL_CLOB4(s, 64, 65, 66, 67),      \
     BL_CLOB4(s, 68, 69, 70, 71), BL_CLOB4(s, 72, 73, 74, 75), BL_CLOB4(s, 76, 77, 78, 79), BL_CLOB4(s, 80, 81, 82, 83),      \
     BL_CLOB4(s, 84, 85, 86, 87), BL_CLOB4(s, 88, 89, 90, 91), BL_CLOB4(s, 92, 93, 94, 95), BL_CLOB4(s, 96, 97, 98, 99),      \
     "s33",                                                                                                \
@@ -1556,16 +1555,21 @@ void k_bp_list(float *__restrict__ x, const uint4 *__restrict__ lent, const uint
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) { BL_STAGE_DMA(s + 1) BL_TOUCH(s + 1) }
+        // the stage's first batch is requested before anything else of the stage (as two 16-dword values bound to the registers the
+        // loop keeps its first entry set in), so that it arrives behind the staging code instead of in front of the loop
         const uint32_t b0 = __builtin_amdgcn_readlane(pv0, s);
         uint32_t nb = __builtin_amdgcn_readlane(pv1, s) - b0;
-        if (nb != 0u) {
-            const uint4 *ep = lent + (size_t)b0 * BL_BATCH;
-            asm volatile("s_mov_b32 s33, m0\n"
+        const uint4 *ep = lent + (size_t)b0 * BL_BATCH;
+        u16v ea, eb;
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n"
+                     "s_load_dwordx16 %1, %2, 0x40\n" : "={s[36:51]}"(ea), "={s[52:67]}"(eb) : "s"(ep));   // (waited for inside the loop's block)
+        if (s + 1 < nstage) { BL_STAGE_DMA(s + 1) BL_TOUCH(s + 1) }
+        {   // (an empty list is skipped inside the block: a branch around it would make the accumulators merge values)
+            asm volatile("s_waitcnt lgkmcnt(0)\n"         /* the first batch (also when the list is empty: nothing may land later) */
+                         "s_cmp_eq_u32 %[nb], 0\n"
+                         "s_cbranch_scc1 3f\n"
+                         "s_mov_b32 s33, m0\n"
                          "s_mov_b64 vcc, %[ep]\n"
-                         "s_load_dwordx16 s[36:51], vcc, 0x0\n"
-                         "s_load_dwordx16 s[52:67], vcc, 0x40\n"
-                         "s_waitcnt lgkmcnt(0)\n"
                          "1:\n"
                          "s_load_dwordx16 s[68:83], vcc, 0x80\n"
                          "s_load_dwordx16 s[84:99], vcc, 0xc0\n"
@@ -1586,7 +1590,8 @@ void k_bp_list(float *__restrict__ x, const uint4 *__restrict__ lent, const uint
                          "2:\n"
                          "s_waitcnt lgkmcnt(0)\n"
                          "s_mov_b32 m0, s33\n"
-                         : "+{v[64:95]}"(acc_lo), "+{v[96:127]}"(acc_hi), [nb] "+s"(nb)
+                         "3:\n"
+                         : "+{v[64:95]}"(acc_lo), "+{v[96:127]}"(acc_hi), [nb] "+s"(nb), "+{s[36:51]}"(ea), "+{s[52:67]}"(eb)
                          : [ep] "s"(ep), [base] "v"(base), [mask] "v"(mask)
                          : BL_CLOBBERS);
         }
@@ -1662,8 +1667,6 @@ struct FlItemD { int pass, v0; uint32_t tile0, ntiles, lp0, work, pad0, pad1; };
     "s_set_gpr_idx_off\n"
 #define FL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define FL_CLOBBERS                                                                                       \
-    FL_CLOB4(s, 36, 37, 38, 39), FL_CLOB4(s, 40, 41, 42, 43), FL_CLOB4(s, 44, 45, 46, 47), FL_CLOB4(s, 48, 49, 50, 51),      \
-    FL_CLOB4(s, 52, 53, 54, 55), FL_CLOB4(s, 56, 57, 58, 59), FL_CLOB4(s, 60, 61, 62, 63), FL_CLOB4(s, 64, 65, 66, 67),      \
     FL_CLOB4(s, 68, 69, 70, 71), FL_CLOB4(s, 72, 73, 74, 75), FL_CLOB4(s, 76, 77, 78, 79), FL_CLOB4(s, 80, 81, 82, 83),      \
     FL_CLOB4(s, 84, 85, 86, 87), FL_CLOB4(s, 88, 89, 90, 91), FL_CLOB4(s, 92, 93, 94, 95), FL_CLOB4(s, 96, 97, 98, 99),      \
     "s33",                                                                                                \
@@ -1735,18 +1738,21 @@ void k_fp_list(const float *__restrict__ x, const FlItemD *__restrict__ items, c
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) :: "memory");
     __syncthreads();
     for (int tt = 0; tt < ntiles; ++tt) {
-        if (tt + 1 < ntiles) { FL_STAGE(tt + 1) FL_TOUCH(tt + 1) }
+        // the tile's first batch is requested before anything else of the tile (two 16-dword values bound to the registers the loop
+        // keeps its first entry set in): it arrives behind the staging code instead of in front of the loop
         const uint32_t b0 = __builtin_amdgcn_readlane(pv0, tt);
         uint32_t nb = __builtin_amdgcn_readlane(pv1, tt) - b0;
+        const uint2 *ep = lent + (size_t)b0 * FL_BATCH;
+        u16v ea, eb;
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n"
+                     "s_load_dwordx16 %1, %2, 0x40\n" : "={s[36:51]}"(ea), "={s[52:67]}"(eb) : "s"(ep));   // (waited for inside the loop's block)
+        if (tt + 1 < ntiles) { FL_STAGE(tt + 1) FL_TOUCH(tt + 1) }
         {   // (an empty list is skipped inside the block: a branch around it would make the accumulators merge values, i.e. copies)
-            const uint2 *ep = lent + (size_t)b0 * FL_BATCH;
-            asm volatile("s_cmp_eq_u32 %[nb], 0\n"
+            asm volatile("s_waitcnt lgkmcnt(0)\n"         /* the first batch (also when the list is empty: nothing may land later) */
+                         "s_cmp_eq_u32 %[nb], 0\n"
                          "s_cbranch_scc1 3f\n"
                          "s_mov_b32 s33, m0\n"
                          "s_mov_b64 vcc, %[ep]\n"
-                         "s_load_dwordx16 s[36:51], vcc, 0x0\n"
-                         "s_load_dwordx16 s[52:67], vcc, 0x40\n"
-                         "s_waitcnt lgkmcnt(0)\n"
                          "1:\n"
                          "s_load_dwordx16 s[68:83], vcc, 0x80\n"
                          "s_load_dwordx16 s[84:99], vcc, 0xc0\n"
@@ -1768,7 +1774,7 @@ void k_fp_list(const float *__restrict__ x, const FlItemD *__restrict__ items, c
                          "s_waitcnt lgkmcnt(0)\n"
                          "s_mov_b32 m0, s33\n"
                          "3:\n"
-                         : "+{v[64:95]}"(acc_lo), "+{v[96:127]}"(acc_hi), [nb] "+s"(nb)
+                         : "+{v[64:95]}"(acc_lo), "+{v[96:127]}"(acc_hi), [nb] "+s"(nb), "+{s[36:51]}"(ea), "+{s[52:67]}"(eb)
                          : [ep] "s"(ep), [base] "v"(base), [mask] "v"(mask)
                          : FL_CLOBBERS);
         }
