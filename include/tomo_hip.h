@@ -349,7 +349,8 @@ int tomo_sart_chain_count(tomo_engine *e, int *count);
  * and resets the log. */
 enum tomo_kernel_id { TOMO_K_BP_ANGLE = 0, TOMO_K_FP_ANGLE = 1, TOMO_K_TV_GRAD = 2, TOMO_K_TV_UPDATE = 3,
                       TOMO_K_FGP_OBJ = 4, TOMO_K_FGP_GRAD = 5 /* also the fused FGP iteration */, TOMO_K_SART_FUSED = 6,
-                      TOMO_K_FP_TILE = 7, TOMO_K_BP_TILE = 8, TOMO_K_FP_REDUCE = 9 };
+                      TOMO_K_FP_TILE = 7, TOMO_K_BP_TILE = 8, TOMO_K_FP_REDUCE = 9,
+                      TOMO_K_SART_RESIDENT = 10 /* one launch = one whole SART sweep of the slab (volume-resident form) */ };
 int tomo_profile_enable(tomo_engine *e, int kernel, int on);
 int tomo_profile_read(tomo_engine *e, int kernel, int64_t *launches, double *total_ms);
 /* the same, also busy_ms = time during which at least one launch of the kernel was executing (union of the launch

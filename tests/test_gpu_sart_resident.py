@@ -1,0 +1,109 @@
+"""The volume-resident SART sweep (k_sart_resident, tomo_tv_amd/csrc/sart_resident.hip.h: one launch per sweep, a 64-slice chunk of
+the whole image held in vector registers over all angles, ray sums exchanged between the workgroups as tagged granules) against
+the streamed form it replaces (k_sart_tile + k_resid_finish per angle + k_bp_angle) and against the oracle.
+
+The two forms apply the SAME voxel update (k_bp_angle's expression, rounding for rounding) to residual rows whose ray sums are
+added in a different order (8 x 8 blocks inside 32 x 32 tiles instead of segments of 16 x 16 tiles): sweeps agree to ~1e-7, not
+to the bit -- the bound here is 1e-6.  The kernel's own arithmetic is held to the bit by the CPU replay in its
+order of operations (tools/experiments/resident_probe.hip, run on the GPU box during the round; profiles/r05_resident_sweep.md).
+Reference semantics: tomofusion/gpu/utils/tomoengine.cpp:162-179 (ASTRA SART, angles in sequence or in a given order, min-constraint 0).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from tomo_tv_amd._lib import VOL_ORIGINAL, VOL_RECON
+from tomo_tv_amd.engine import tomoengine
+from tomo_tv_amd.phantom import ellipsoids, tilt_angles
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(ns, n, nproj, resident, seed=11, noisy=False):
+    ang = np.deg2rad(tilt_angles(nproj))
+    t = tomoengine(ns, n, ang)
+    t.set_option("sart_resident", resident)
+    vol = ellipsoids(ns, n, seed=seed)
+    t.set_volume(vol, VOL_ORIGINAL)
+    t.create_projections()
+    if noisy:
+        b = t.get_projections()
+        rng = np.random.default_rng(3)
+        t.set_tilt_series((b * (1.0 + 0.05 * rng.standard_normal(b.shape)) + 0.5).astype(np.float32))
+    return t
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("ns,n,nproj", [(6, 32, 7), (64, 64, 9), (70, 40, 7), (130, 96, 12), (64, 128, 31), (256, 128, 6), (192, 256, 20), (3, 8, 3)])
+def test_resident_sweep_equals_streamed_sweep(gpu, ns, n, nproj):
+    out = {}
+    for resident in (0, 1):
+        t = _engine(ns, n, nproj, resident, noisy=True)
+        assert t.get_option("sart_resident_ready") == 1
+        t.SART(0.7, 2)
+        out[resident] = t.get_volume(VOL_RECON)
+    assert np.isfinite(out[1]).all() and out[1].max() > 0
+    assert _rel(out[1], out[0]) <= 1e-6, _rel(out[1], out[0])
+
+
+def test_resident_sweep_random_order_and_tracked_norm(gpu):
+    ns, n, nproj = 200, 64, 11
+    got = {}
+    for resident in (0, 1):
+        t = _engine(ns, n, nproj, resident)
+        t.initialize_SART("random")
+        t._order_rng = np.random.default_rng(5)
+        t.copy_recon()
+        nrm = t.SART_tracked(0.7, 3)
+        got[resident] = (t.get_volume(VOL_RECON), nrm, t.matrix_2norm())
+    assert _rel(got[1][0], got[0][0]) <= 1e-6
+    assert abs(got[1][1] - got[0][1]) <= 1e-5 * abs(got[0][1])
+    assert got[1][2] == 0.0 and got[0][2] == 0.0          # the snapshot volume IS the swept volume after a tracked sweep
+
+
+@pytest.mark.parametrize("ns,n,nproj", [(6, 32, 7), (70, 64, 16)])
+def test_resident_sweep_against_the_oracle(gpu, ns, n, nproj):
+    ang_deg = tilt_angles(nproj)
+    t = _engine(ns, n, nproj, 1)
+    t.SART(0.5, 2)
+    got = t.get_volume(VOL_RECON)
+    ref = oracle.ctvlib(ns, n, nproj)
+    ref.load_A(oracle.parallel_ray(n, ang_deg))
+    ref.original_volume = ellipsoids(ns, n, seed=11).copy()
+    ref.create_projections()
+    ref.SART(0.5, 2)
+    assert _rel(got, ref.recon) <= 1e-5, _rel(got, ref.recon)
+
+
+def test_two_engines_on_one_device_do_not_starve_each_other(gpu):
+    """Two resident sweeps enqueued side by side on two streams of one device: each launch needs every CU, so the library chains
+    them (launch_sart_resident); both must come out right and nobody may give up."""
+    import threading
+    ns, n, nproj = 64, 256, 12
+    eng = [_engine(ns, n, nproj, 1, seed=11 + i) for i in range(2)]
+    ref = []
+    for i in range(2):
+        r = _engine(ns, n, nproj, 0, seed=11 + i)
+        r.SART(0.7, 2)
+        ref.append(r.get_volume(VOL_RECON))
+    th = [threading.Thread(target=lambda e=e: e.SART(0.7, 2)) for e in eng]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for i in range(2):
+        assert _rel(eng[i].get_volume(VOL_RECON), ref[i]) <= 1e-6
+
+
+def test_resident_form_is_refused_where_it_cannot_run(gpu):
+    t = _engine(5, 36, 5, 0)          # N not a multiple of 8: no tables
+    assert t.get_option("sart_resident_ready") == 0
+    t.set_option("sart_resident", 1)
+    with pytest.raises(RuntimeError):
+        t.SART(0.5, 1)
+    t.set_option("sart_resident", -1)
+    t.SART(0.5, 1)                    # automatic: the streamed form
+    assert np.isfinite(t.get_volume(VOL_RECON)).all()

@@ -6,7 +6,9 @@
 // resident in HBM for the life of the engine.
 #include "../../include/tomo_hip.h"
 #include "kernels.hip.h"
+#include "sart_resident.hip.h"
 #include "sysmat.h"
+#include "resident.h"
 
 #include <dlfcn.h>
 #if __has_include(<rccl/rccl.h>)
@@ -50,7 +52,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(TOMO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));                 \
     } while (0)
 #define LAUNCHCHK() HIPCHK(hipGetLastError())
-#define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); if ((e)->geometry_released) return fail(TOMO_ERR_STATE, "engine geometry was released"); HIPCHK(hipSetDevice((e)->device)); } while (0)
+#define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); if ((e)->geometry_released) return fail(TOMO_ERR_STATE, "engine geometry was released"); HIPCHK(hipSetDevice((e)->device)); RS_CHECK(e); } while (0)
+// a resident SART sweep whose workgroups could not all run at once gives up instead of hanging (sart_resident.hip.h): the volume it
+// swept is garbage, and the first call that looks (every entry point, and every read-back after its synchronisation) says so
+#define RS_CHECK(e) do { if ((e)->rs_abort && *(e)->rs_abort) return rs_gave_up(e); } while (0)
 
 enum { PROF_MAX_KERNELS = 12, PROF_MAX_EVENTS = 1 << 19 };   // 262144 launches per kernel id between two reads
 
@@ -210,6 +215,24 @@ struct tomo_engine {
     // (64 slices: 37.0 vs 30.8 us, 5.25 vs 4.87 ms per step): the first workgroups cannot start their voxel update before
     // the rows exist, so the reduction is serial either way and only moves inside the launch.
     int sart_coop = 0, sart_coop_spin = 4096, st_resident = 0;
+    // "sart_resident" (round 5): the sweep as ONE launch of k_sart_resident -- a 64-slice chunk of the whole image stays in the chip's
+    // vector registers over all angles of the sweep and the workgroups exchange only ray sums (sart_resident.hip.h).  -1 = automatic
+    // (whenever the tables exist: N a multiple of 8 with at most one 32 x 32 tile per CU, a matrix whose ray windows fit), 0 = never
+    // (the streamed tile steps), 1 = insist (an error where the tables do not exist).
+    int sart_resident = -1;
+    bool rs_ok = false;
+    int rs_ntiles = 0, rs_tiles = 0, rs_rpt = 0, rs_groups = 0, rs_cus = 0;
+    RsHdrD *d_rs_hdr = nullptr;
+    uint4 *d_rs_fpc = nullptr, *d_rs_bpc = nullptr;
+    uint16_t *d_rs_rl = nullptr;
+    rs_u64 *rs_pb = nullptr, *rs_rb = nullptr;     // granules {value, tag}: tile sums, residual rows
+    size_t rs_pb_bytes = 0, rs_rb_bytes = 0;
+    int *d_rs_angs = nullptr;                      // angle of every step of the sweep in flight
+    size_t rs_angs_cap = 0;
+    std::vector<int> rs_angs_host;                 // (what d_rs_angs holds: an unchanged sequence is not uploaded again)
+    int *rs_abort = nullptr, *d_rs_abort = nullptr; // pinned host word / device word a workgroup sets when a bounded spin gave up
+    uint32_t rs_epoch = 0;                         // tags handed out so far (a granule's tag is unique per sweep, chunk round and step)
+    uint32_t rs_spin_limit = 1u << 21;
     int art_tile = 1;                              // chained ART sweep as fused tile steps (k_sart_tile ART) instead of k_fp_rows + k_bp_art per angle
     int sart_skip_same = 1;                        // k_sart_tile stores only the 256-byte pieces whose bits changed (in place)
     int sart_nt = -1;                              // tile accesses: -1 streaming form by slab size (slab_streams), 0 plain, 1 streaming
@@ -281,6 +304,16 @@ struct tomo_engine {
 };
 
 static inline double *gnorm_ptr(const tomo_engine *e) { return e->gnorm_override ? e->gnorm_override : e->d_scal + e->gnorm_slot; }
+
+static int rs_gave_up(tomo_engine *e)
+{
+    const int code = *e->rs_abort;
+    *e->rs_abort = 0;
+    if (e->d_rs_abort) (void)hipMemsetAsync(e->d_rs_abort, 0, sizeof(int), e->stream);
+    return fail(TOMO_ERR_STATE, std::string("the resident SART sweep gave up waiting for ") + (code == 1 ? "residual rows" : "tile sums") +
+                " (its workgroups were not all resident at once: another kernel held the device?); the swept volume is invalid -- "
+                "set the option \"sart_resident\" to 0 to use the streamed sweep");
+}
 
 static int dev_alloc(void **p, size_t bytes, bool zero, hipStream_t st)
 {
@@ -1090,6 +1123,41 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         }
         release(t.st_cell); release(t.st_off); release(t.st_w); release(t.st_seg); release(t.st_segid); release(t.st_win);
         lap("build_sart_tiles + upload");
+        {   // tables of the volume-resident sweep (resident.cpp); TOMO_SART_RESIDENT = 0 leaves them out
+            static_assert(Resident::T == RS_T && Resident::WAVES == RS_WAVES && Resident::MAXWIN == RS_MAXWIN && Resident::RL == RS_RL && Resident::USABLE == RS_USABLE &&
+                          sizeof(Resident::Hdr) == sizeof(RsHdrD), "k_sart_resident geometry (resident.h)");
+            bool want = e->n % 8 == 0;
+            if (const char *env = std::getenv("TOMO_SART_RESIDENT")) want = want && std::atoi(env) != 0;
+            e->rs_ok = false;
+            if (want) {
+                hipDeviceProp_t prop;
+                HIPCHK(hipGetDeviceProperties(&prop, e->device));
+                e->rs_cus = prop.multiProcessorCount;
+                Resident R;
+                build_sart_resident(e->n, e->np, t, e->rs_cus, R);
+                if (R.ok) {
+                    e->rs_ntiles = R.ntiles; e->rs_tiles = R.tiles; e->rs_rpt = R.rpt;
+                    e->rs_groups = std::max(1, std::min(e->rs_cus / R.ntiles, e->sxc / 64));
+                    e->rs_pb_bytes = (size_t)e->rs_groups * R.ntiles * RS_MAXWIN * 64 * sizeof(rs_u64);
+                    e->rs_rb_bytes = (size_t)e->rs_groups * e->np * e->n * 64 * sizeof(rs_u64);
+                    if ((rc = dev_alloc((void **)&e->d_rs_hdr, R.hdr.size() * sizeof(RsHdrD), false, e->stream))) return rc;
+                    if ((rc = dev_alloc((void **)&e->d_rs_fpc, R.fpc.size() * 4, false, e->stream))) return rc;
+                    if ((rc = dev_alloc((void **)&e->d_rs_bpc, R.bpc.size() * 4, false, e->stream))) return rc;
+                    if ((rc = dev_alloc((void **)&e->d_rs_rl, R.rl.size() * 2, false, e->stream))) return rc;
+                    if ((rc = dev_alloc((void **)&e->rs_pb, e->rs_pb_bytes, true, e->stream))) return rc;     // tag 0 = never written
+                    if ((rc = dev_alloc((void **)&e->rs_rb, e->rs_rb_bytes, true, e->stream))) return rc;
+                    HIPCHK(hipMemcpy(e->d_rs_hdr, R.hdr.data(), R.hdr.size() * sizeof(RsHdrD), hipMemcpyHostToDevice));
+                    HIPCHK(hipMemcpy(e->d_rs_fpc, R.fpc.data(), R.fpc.size() * 4, hipMemcpyHostToDevice));
+                    HIPCHK(hipMemcpy(e->d_rs_bpc, R.bpc.data(), R.bpc.size() * 4, hipMemcpyHostToDevice));
+                    HIPCHK(hipMemcpy(e->d_rs_rl, R.rl.data(), R.rl.size() * 2, hipMemcpyHostToDevice));
+                    if (!e->rs_abort) { HIPCHK(hipHostMalloc((void **)&e->rs_abort, sizeof(int), hipHostMallocMapped)); *e->rs_abort = 0; }
+                    if ((rc = dev_alloc((void **)&e->d_rs_abort, sizeof(int), true, e->stream))) return rc;
+                    e->rs_epoch = 0;
+                    e->rs_ok = true;
+                }
+            }
+        }
+        lap("build_sart_resident + upload");
         build_bp_tiles(e->n, e->np, FT_TY, FT_TZ, FB_A, FB_MAXR, 256, 2 * FB_A, t);   // the cell ring prefetches up to angle P + 2*FB_A - 2
         static_assert(sizeof(Tables::TileCell) == sizeof(uint4), "tile cell layout");
         e->fb_ok = t.bp_tile_ok && e->np <= FB_MAX_PROJ;
@@ -1305,8 +1373,10 @@ static void free_geometry(tomo_engine *e)
                      (void **)&e->d_fs_items, (void **)&e->d_fs_orient, (void **)&e->d_fs_shift, (void **)&e->d_fs_cnt, (void **)&e->d_fs_gstart,
                      (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_zero, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux,
                      (void **)&e->d_fl_items, (void **)&e->d_fl_orient, (void **)&e->d_fl_shift, (void **)&e->d_fl_ent, (void **)&e->d_fl_ptr, (void **)&e->d_fl_fent, (void **)&e->d_fl_fptr,
-                     (void **)&e->d_fl_rsptr, (void **)&e->d_fl_rsidx, (void **)&e->d_fl_zero, (void **)&e->fl_part, (void **)&e->fl_part_aux};
+                     (void **)&e->d_fl_rsptr, (void **)&e->d_fl_rsidx, (void **)&e->d_fl_zero, (void **)&e->fl_part, (void **)&e->fl_part_aux,
+                     (void **)&e->d_rs_hdr, (void **)&e->d_rs_fpc, (void **)&e->d_rs_bpc, (void **)&e->d_rs_rl, (void **)&e->rs_pb, (void **)&e->rs_rb, (void **)&e->d_rs_angs, (void **)&e->d_rs_abort};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    e->rs_ok = false; e->rs_angs_cap = 0; e->rs_angs_host.clear();
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
     if (e->g_prev) { (void)hipFree(e->g_prev); e->g_prev = nullptr; }
     if (e->g_yk) { (void)hipFree(e->g_yk); e->g_yk = nullptr; }
@@ -1328,6 +1398,7 @@ int tomo_destroy(tomo_engine *e)
     if (e->ev_peer) (void)hipEventDestroy(e->ev_peer);
     if (e->ev_snap) (void)hipEventDestroy(e->ev_snap);
     if (e->h_snap) (void)hipHostFree(e->h_snap);
+    if (e->rs_abort) (void)hipHostFree(e->rs_abort);
     free_geometry(e);
     void *ptrs[] = {e->tv_alt, e->halo_lo_alt, e->halo_hi_alt, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_part, e->cg_coef, e->sart_alt,
                     e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
@@ -1385,7 +1456,7 @@ int tomo_set_stream(tomo_engine *e, void *hip_stream)
     return TOMO_OK;
 }
 
-int tomo_synchronize(tomo_engine *e) { NEED(e); HIPCHK(hipStreamSynchronize(e->stream)); return TOMO_OK; }
+int tomo_synchronize(tomo_engine *e) { NEED(e); HIPCHK(hipStreamSynchronize(e->stream)); RS_CHECK(e); return TOMO_OK; }
 int tomo_get_device(tomo_engine *e, int *device) { if (!e || !device) return fail(TOMO_ERR_ARG, "null"); *device = e->device; return TOMO_OK; }
 int tomo_get_dims(tomo_engine *e, int *nslice, int *nray, int *nproj, int64_t *nnz)
 {
@@ -1428,6 +1499,7 @@ static int download(tomo_engine *e, const float *src, float *host, int64_t m)
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(host, e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    RS_CHECK(e);
     return TOMO_OK;
 }
 
@@ -1599,6 +1671,59 @@ int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter)
     return TOMO_OK;
 }
 
+// ---- the SART sweep as one launch of the volume-resident kernel (sart_resident.hip.h) ----------------------------------------------
+// Every workgroup of the launch must be on the chip at once (they wait for one another's ray sums), and a workgroup fills a CU:
+// two such launches side by side -- two engines on one device, on two streams -- could each get part of the chip and wait for the
+// rest until their spins run out.  So the resident launches of one device form a chain: each waits for the event the one before
+// it (any engine, any stream) recorded.  Other kernels may overlap freely: they finish by themselves.
+static std::mutex g_rs_mu;
+static hipEvent_t g_rs_last[64] = {};
+
+static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t steps, const std::function<int(int64_t)> &angle_at, float *track)
+{
+    if (steps > (int64_t)1 << 24) return fail(TOMO_ERR_ARG, "too many SART steps in one call");
+    const int c0 = e->sub_nc ? e->sub_c0 : 0, nc = e->sub_nc ? e->sub_nc : e->sxc / 64;
+    const int groups = std::max(1, std::min(e->rs_groups, nc)), rounds = (nc + groups - 1) / groups;
+    {   // the angle of every step, on the device (an unchanged sequence stays where it is)
+        std::vector<int> seq((size_t)steps);
+        for (int64_t k = 0; k < steps; ++k) seq[(size_t)k] = angle_at(k);
+        if (seq != e->rs_angs_host) {
+            HIPCHK(hipStreamSynchronize(e->stream));          // (a sweep in flight may still read the old sequence; rare: the first sweep, a new order)
+            if ((size_t)steps > e->rs_angs_cap) {
+                if (e->d_rs_angs) { HIPCHK(hipFree(e->d_rs_angs)); e->d_rs_angs = nullptr; e->rs_angs_cap = 0; }
+                HIPCHK(hipMalloc((void **)&e->d_rs_angs, (size_t)steps * sizeof(int)));
+                e->rs_angs_cap = (size_t)steps;
+            }
+            HIPCHK(hipMemcpy(e->d_rs_angs, seq.data(), (size_t)steps * sizeof(int), hipMemcpyHostToDevice));
+            e->rs_angs_host.swap(seq);
+        }
+    }
+    const uint64_t need = (uint64_t)rounds * (uint64_t)steps;
+    if ((uint64_t)e->rs_epoch + need + 16 > 0xFFFFFFFFull) {     // the tags wrap: back to the state after creation (tag 0 = never written)
+        HIPCHK(hipMemsetAsync(e->rs_pb, 0, e->rs_pb_bytes, e->stream));
+        HIPCHK(hipMemsetAsync(e->rs_rb, 0, e->rs_rb_bytes, e->stream));
+        e->rs_epoch = 0;
+    }
+    RsArgs A{};
+    A.x = x; A.b = e->cur_b; A.rowsum = e->d_rowsum; A.hdr = e->d_rs_hdr; A.fpc = e->d_rs_fpc; A.bpc = e->d_rs_bpc; A.rl = e->d_rs_rl;
+    A.pb = e->rs_pb; A.rb = e->rs_rb; A.angs = e->d_rs_angs; A.track = track; A.part = e->d_part; A.abort_word = e->d_rs_abort; A.abort_host = e->rs_abort;
+    A.n = e->n; A.sx = e->sx; A.np = e->np; A.ntiles = e->rs_ntiles; A.tiles = e->rs_tiles; A.rpt = e->rs_rpt; A.steps = (int)steps; A.chunk0 = c0; A.nchunk = nc;
+    A.epoch0 = e->rs_epoch; A.spin_limit = e->rs_spin_limit; A.beta = beta; A.prof = nullptr;
+    e->rs_epoch += (uint32_t)need;
+    if (e->device < 0 || e->device >= 64) return fail(TOMO_ERR_ARG, "device index");
+    std::lock_guard<std::mutex> lk(g_rs_mu);
+    hipEvent_t &last = g_rs_last[e->device];
+    if (!last) HIPCHK(hipEventCreateWithFlags(&last, hipEventDisableTiming));
+    else HIPCHK(hipStreamWaitEvent(e->stream, last, 0));
+    {
+        ProfScope ps(e, TOMO_K_SART_RESIDENT);
+        hipLaunchKernelGGL(k_sart_resident, dim3((unsigned)(e->rs_ntiles * groups)), dim3(RS_THREADS), 0, e->stream, A);
+        LAUNCHCHK();
+    }
+    HIPCHK(hipEventRecord(last, e->stream));
+    return TOMO_OK;
+}
+
 int tomo_sart(tomo_engine *e, int vol, float beta, int niter, const int32_t *order)
 {
     return tomo_sart_data(e, vol, TOMO_SINO_B, beta, niter, order);
@@ -1645,6 +1770,11 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
     }
     // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
     if (steps <= 0) return TOMO_OK;
+    if (e->sart_resident != 0 && e->rs_ok) {      // the volume-resident sweep: one launch, the slab read and written once
+        if ((rc = launch_sart_resident(e, x, beta, steps, angle_at, track))) return rc;
+        return finish();
+    }
+    if (e->sart_resident == 1) return fail(TOMO_ERR_STATE, "\"sart_resident\" = 1, but this engine has no tables of the resident sweep (N not a multiple of 8, more 32 x 32 tiles than CUs, or a matrix whose ray windows do not fit)");
     if (e->sart_tile && e->st_ok) {   // tile form, in place
         // cooperative chain (k_sart_tile COOP): needs consecutive angles to differ (np >= 2) and whole 64-slice chunks
         const bool coop = e->sart_coop && e->np >= 2 && steps >= 2;
@@ -2183,6 +2313,7 @@ int tomo_read_scalars(tomo_engine *e, double *out, int count)
     { int rc = tomo_async_wait(e); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(out, e->d_scal, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    RS_CHECK(e);
     return TOMO_OK;
 }
 
@@ -2211,6 +2342,7 @@ int tomo_scalars_snapshot_read(tomo_engine *e, double *out, int count)
     HIPCHK(hipEventSynchronize(e->ev_snap));
     std::memcpy(out, e->h_snap, count * sizeof(double));
     e->snap_pending = false;
+    RS_CHECK(e);
     return TOMO_OK;
 }
 
@@ -3059,6 +3191,9 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "bp_list_ready") == 0) { *value = e->bl_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_reuse") == 0) { *value = e->fp_reuse; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { *value = e->sart_tile; return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident") == 0) { *value = e->sart_resident; return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident_ready") == 0) { *value = e->rs_ok ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident_active") == 0) { *value = (e->rs_ok && e->sart_resident != 0) ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "comm_rounds") == 0) { *value = (int)std::min<int64_t>(e->comm_rounds, 0x7FFFFFFF); return TOMO_OK; }
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -3072,6 +3207,8 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "art_chain") == 0) { e->art_chain = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { e->sart_tile = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident") == 0) { e->sart_resident = value < 0 ? -1 : (value ? 1 : 0); return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident_spin") == 0) { e->rs_spin_limit = value <= 0 ? 64u : (uint32_t)value; return TOMO_OK; }   // (tests: a sweep that gives up)
 #ifdef TOMO_WHATIF
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif
