@@ -268,6 +268,36 @@ def roof(name, cnt, tot_ms, alg_bytes, flops=None, lds_bytes=None, busy_ms=None)
     return r
 
 
+def resident_sweep(t):
+    """True when a SART sweep of this engine runs as ONE launch of the volume-resident kernel (k_sart_resident, round 5)."""
+    try:
+        return bool(t.get_option("sart_resident_active"))
+    except Exception:  # noqa: BLE001 -- the numpy slab double of the launcher test has no such option
+        return False
+
+
+def resident_roof(cnt, tot_ms, busy_ms, nslice, n, nproj, tracked):
+    """Roofline record of k_sart_resident: one launch = one whole sweep of the slab.
+    ``achieved`` follows SURVEY.md 8(d): the algorithmic bytes of the work a launch does -- P fused single-angle steps at
+    8V + 12 Nx N each, the figure the streamed kernel k_sart_tile was priced with -- over the launch time.  The kernel does
+    not MOVE those bytes (the volume stays in registers; what it has to move is in ``resident``), so ``frac`` can exceed 1:
+    it says how far the sweep is past what any form that streams the slab once per angle can reach.  What bounds the kernel
+    is the per-angle exchange latency and the vector ALUs (``valu_frac``); see DESIGN.md and profiles/r05_resident_sweep.md."""
+    V = float(nslice) * n * n
+    alg = nproj * (8.0 * V + 12.0 * nslice * n)
+    # 7 vector operations per voxel and angle in the back projection (mul, fma, mul, fma, max: 7 flops), 2 FMAs in the forward one
+    r = roof("k_sart_resident", cnt, tot_ms, alg, flops=11.0 * V * nproj, busy_ms=busy_ms)
+    chunks = (nslice + 63) // 64
+    must = (16.0 if tracked else 8.0) * V + 4.0 * nslice * n * nproj + chunks * nproj * 2 * 16.0 * n * n
+    avg = r["avg_ms"]
+    r["resident"] = {"bytes_the_launch_must_move": must, "what": "slab in + out once (+ snapshot in + out when tracked) + measured rows + "
+                     "two 16-byte cell tables per pixel, angle and 64-slice chunk",
+                     "achieved_on_those_GBs": must / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
+                     "us_per_angle_and_chunk": avg * 1e3 / nproj / chunks if avg > 0 else 0.0}
+    r["frac_note"] = "algorithmic bytes of the streamed form (SURVEY 8d) over the launch time; > 1 = faster than any once-per-angle stream at HBM peak"
+    return r
+
+
 def sart_chains(t):
     """Launch chains a SART sweep of this engine's slab runs as -- asked of the engine (tomo_sart_chain_count: the rule lives in
     tomo_engine.hip: chain_count, under the options in force), not restated here.  A sub-slab group answers per sub-slab engine."""
@@ -367,18 +397,22 @@ def _time_steps(t, fn, steps, warmup=1):
 
 def secondary_configs(nnz_per_pixel_angle=1.22):
     from tomo_tv_amd import pytvlib
-    from tomo_tv_amd._lib import K_BP_TILE, K_FGP_GRAD, K_FGP_OBJ, K_FP_REDUCE, K_FP_TILE, K_SART_FUSED, VOL_YK
+    from tomo_tv_amd._lib import K_BP_TILE, K_FGP_GRAD, K_FGP_OBJ, K_FP_REDUCE, K_FP_TILE, K_SART_FUSED, K_SART_RESIDENT, VOL_YK
     out = {}
     # ---- config 2: 256^3, 60 tilts, SART (beta 1, sequential) + data_distance per iteration
     t = _engine(256, 256, 60)
     t.initialize_SART("sequential")
-    log = KernelLog(t, {"k_sart_tile<true>": K_SART_FUSED})
+    res2 = resident_sweep(t)
+    log = KernelLog(t, {"k_sart_resident": K_SART_RESIDENT} if res2 else {"k_sart_tile<true>": K_SART_FUSED})
     ms = _time_steps(t, lambda: (t.SART(1.0, 1), t.data_distance()), 5)
-    cnt, tot, busy = log.read()["k_sart_tile<true>"]
     V = 256.0 ** 3
-    ns = sart_chains(t)
-    out["config2_sart_256cube_x60tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6,
-                                            "roofline": roof("k_sart_tile<true>", cnt, tot, (8 * V + 12 * 256 * 256) / ns, busy_ms=busy)}
+    if res2:
+        cnt, tot, busy = log.read()["k_sart_resident"]
+        roof2 = resident_roof(cnt, tot, busy, 256, 256, 60, False)
+    else:
+        cnt, tot, busy = log.read()["k_sart_tile<true>"]
+        roof2 = roof("k_sart_tile<true>", cnt, tot, (8 * V + 12 * 256 * 256) / sart_chains(t), busy_ms=busy)
+    out["config2_sart_256cube_x60tilts"] = {"ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": V / ms / 1e6, "roofline": roof2}
     del t
     # ---- config 3: 512^3, 90 tilts: FISTA (lambda 0.1, 10 FGP iterations, cost), then SIRT with the tile projectors' roofs
     t = _engine(512, 512, 90)
@@ -700,7 +734,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import ctypes
-    from tomo_tv_amd._lib import K_BP_ANGLE, K_SART_FUSED, VOL_ORIGINAL
+    from tomo_tv_amd._lib import K_BP_ANGLE, K_SART_FUSED, K_SART_RESIDENT, VOL_ORIGINAL
     from tomo_tv_amd.distributed import slab_partition
     from tomo_tv_amd.phantom import ellipsoids, tilt_angles
 
@@ -778,9 +812,17 @@ def main():
     # (two sub-slab chains: every fused step is timed -- "achieved" is all launches' bytes over the time at least one of them was
     # executing, which needs them all; the pairs cost less there because the other stream's kernel fills the gap: 0.2 ms per step)
     two_chains = sart_chains(t) > 1
-    LOG_STRIDE = {K_FUSED_NAME: 1 if two_chains else 4, K_TVN_NAME: 2, K_TVU_NAME: 2}
-    log = (KernelLog(t, {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}, LOG_STRIDE)
-           if on_gpu and not args.no_kernel_log else None)
+    # round 5: the sweep as ONE launch of the volume-resident kernel (N % 8 == 0, one 32 x 32 tile per CU at most): it replaces the
+    # per-angle fused steps, the first projection and the tracked last back-projection
+    resident = on_gpu and resident_sweep(t)
+    K_RES_NAME = "k_sart_resident"
+    if resident:
+        LOG_STRIDE = {K_TVN_NAME: 2, K_TVU_NAME: 2}
+        log_ids = {K_RES_NAME: K_SART_RESIDENT, K_TVN_NAME: 2, K_TVU_NAME: 3}
+    else:
+        LOG_STRIDE = {K_FUSED_NAME: 1 if two_chains else 4, K_TVN_NAME: 2, K_TVU_NAME: 2}
+        log_ids = {K_FUSED_NAME: K_SART_FUSED, K_BP_NAME: K_BP_ANGLE, K_FP_NAME: 1, K_TVN_NAME: 2, K_TVU_NAME: 3}
+    log = KernelLog(t, log_ids, LOG_STRIDE) if on_gpu and not args.no_kernel_log else None
     sync()
     rounds0 = comm_rounds(t)
     t0 = time.perf_counter()
@@ -792,8 +834,8 @@ def main():
     rounds1 = comm_rounds(t)
     prof = log.read() if log else {}
     iso = None
-    chains = sart_chains(t)          # launch chains per sweep of this rank's slab, as the engine runs them now
-    if on_gpu and getattr(t, "sub_slabs", 1) == 1 and chains > 1:
+    chains = 1 if resident else sart_chains(t)          # launch chains per sweep of this rank's slab, as the engine runs them now
+    if on_gpu and getattr(t, "sub_slabs", 1) == 1 and chains > 1 and not resident:
         # the dominant kernel alone on the chip (one chain, one stream), one untimed step: the kernel's own rate
         t.set_option("sart_streams", 1)
         log1 = KernelLog(t, {K_FUSED_NAME: K_SART_FUSED})
@@ -808,7 +850,7 @@ def main():
     # Transparency: k_sart_tile stores only the 256-byte pieces whose bits changed (voxels held at zero by the positivity
     # clamp, rays with a zero residual -- data-dependent).  The same step with every voxel stored, timed after the timed region:
     el_all = None
-    if on_gpu and tile and not any(o.replace(" ", "").startswith("sart_skip_same=") for o in args.opt):
+    if on_gpu and tile and not resident and not any(o.replace(" ", "").startswith("sart_skip_same=") for o in args.opt):
         t.set_option("sart_skip_same", 0)
         asd_pocs_step(t, st)
         sync()
@@ -824,7 +866,8 @@ def main():
         comm.allreduce_max(tt)
         el = float(tt.item())
         if prof:   # the dominant kernel's mean launch time on every rank
-            mine = prof[K_FUSED_NAME][2] / max(prof[K_FUSED_NAME][0], 1)   # busy time per launch
+            kdom = K_RES_NAME if resident else K_FUSED_NAME
+            mine = prof[kdom][2] / max(prof[kdom][0], 1)   # busy time per launch
             allv = t.be.tensor([mine if r == rank else 0.0 for r in range(world)])
             comm.allreduce_sum(allv)
             per_rank = [float(v) for v in allv.tolist()]
@@ -849,6 +892,13 @@ def main():
         roofs = {}
         nsub = chains * max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)   # launches per angle
         for name, (cnt, tot, busy) in prof.items():
+            if name == K_RES_NAME:      # one launch = one sweep of (this engine's share of) the slab
+                nsl = max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)
+                roofs[name] = resident_roof(cnt, tot, busy, nloc // nsl, n, nproj, True)
+                roofs[name]["launches_per_sweep"] = nsl
+                roofs[name]["sample_stride"] = 1
+                roofs[name]["frac_of_measured_rmw_ceiling"] = roofs[name]["achieved"] / RMW_CEILING_GBS
+                continue
             per = nsub if name in (K_BP_NAME, K_FUSED_NAME, K_FP_NAME) else max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)
             roofs[name] = roof(name, cnt, tot, alg_bytes[name] / per, busy_ms=busy)
             roofs[name]["launches_per_angle"] = per    # sweep chains x sub-slab engines: one launch covers 1/per of the slab
@@ -890,7 +940,9 @@ def main():
                        "sub_slab_engines_per_gpu": getattr(t, "sub_slabs", 1), "sart_chains_per_engine": chains},
             # the data-INDEPENDENT figure (k_sart_tile storing every voxel; the headline skips stores of unchanged 256-byte pieces,
             # which the zero background of the synthetic phantom favours): null when the option was forced on the command line
-            "ms_per_step_every_voxel_stored": None if el_all is None else el_all * 1e3,
+            # (round 5, resident sweep: every voxel is loaded and stored once per sweep whatever the data -- the headline IS that figure)
+            "ms_per_step_every_voxel_stored": (el / args.steps * 1e3 if resident else None) if el_all is None else el_all * 1e3,
+            "sart_sweep_form": "k_sart_resident (one launch per sweep, volume resident in registers)" if resident else "k_sart_tile chain (one fused step per angle)",
             "final_dd": dd, "final_tv": tv,
             "store_skipping": None if el_all is None else {
                 "ms_per_step_with_every_voxel_stored": el_all * 1e3,

@@ -50,10 +50,11 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 30):
     dev.remove_momentum()
     # two-stream SART == one chain (bitwise where the sub-slabs keep the slab's vector width, else an ulp per step)
     v0 = None
+    dev.set_option("sart_resident", 0)
     for ns in (1, 2):
         dev.set_option("sart_streams", ns); dev.restart_recon(); dev.SART(0.7, 1); v = dev.get_volume()
         if v0 is None: v0 = v
-    dev.set_option("sart_streams", 1)
+    dev.set_option("sart_streams", 1); dev.set_option("sart_resident", -1)
     e.append(0.0 if np.array_equal(v0, v) else rel(v, v0))
     # ART (chained, segmented scan) and the Cimmino branch through the ctvlib facade
     print(' art', flush=True)

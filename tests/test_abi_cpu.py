@@ -195,6 +195,24 @@ def test_back_projector_lists_replay_the_matrix(tmp_path):
         assert r.returncode == 0 and r.stdout.rstrip().endswith("ok"), (N, P, amax, r.stdout + r.stderr)
 
 
+def test_resident_sweep_tables_replay_the_matrix(tmp_path):
+    """Host tables of the volume-resident SART sweep (tomo_tv_amd/csrc/resident.cpp: build_sart_resident), replayed on the CPU by
+    tests/native/resident_check.cpp as k_sart_resident uses them: block sums per wave through the fpc cells, tile sums over the
+    waves by window slot, ray sums over the reducer lists = CSR product; the bpc cells = the cell table (rays through the wave's
+    window, weights, the single-precision divisor); windows within the kernel's limits; and the geometries it must refuse."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "rsc")
+    src = [os.path.join(root, "tests", "native", "resident_check.cpp"), os.path.join(root, "tomo_tv_amd", "csrc", "sysmat.cpp"),
+           os.path.join(root, "tomo_tv_amd", "csrc", "resident.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "tomo_tv_amd", "csrc"), *src, "-lpthread", "-o", exe], check=True)
+    for N, P, amax in [(32, 7, 60.0), (64, 16, 70.0), (40, 9, 45.0), (96, 20, 89.0), (128, 31, 70.0), (8, 3, 60.0), (64, 1, 0.0), (256, 60, 70.0)]:
+        r = subprocess.run([exe, str(N), str(P), str(amax)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("OK"), (N, P, amax, r.stdout + r.stderr)
+    r = subprocess.run([exe, "512", "9", "70", "64"], capture_output=True, text=True)         # 256 tiles on a 64-CU device
+    assert r.returncode == 2 and "more tiles than resident workgroups" in r.stdout, r.stdout + r.stderr
+
+
 def test_facades_carry_every_method_of_the_reference_tables(golden):
     """tests/golden/method_tables.json holds the method NAMES of the reference's five pybind11 classes; every one of
     them must exist on the class of the same name here (the drop-in boundary of SURVEY.md section 8b)."""

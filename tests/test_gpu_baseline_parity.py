@@ -68,6 +68,56 @@ def test_config2_sart_sweep_256cube_60(gpu):
     assert close(dev.rmse(), ref.rmse())
 
 
+def test_config3_rank_of_8_64x512sq_x90(gpu):
+    """The slab ONE rank of the BASELINE metric's 8-GPU point owns: slices 192..255 of the 512^3 phantom, 90 tilts (VERDICT r4,
+    "What's missing" 3; the reference splits exactly like this: tomofusion/gpu/utils/multigpuengine.cpp:163-228).  At 64 slices the
+    engine runs forms no other oracle test reaches at N = 512 -- one 64-slice chunk through the resident sweep (round 5; the
+    streamed chain with k_resid_finish<1> / k_bp_angle<1,...> is compared as well), the tile / list projectors on a single
+    chunk -- against the oracle on the same 64 slices: forward projection, a SART sweep, the data distance, five TV steps and
+    two normalised SIRT iterations (arithmetic: tomofusion/cpu/utils/ctvlib.cpp:137-155,272-293,406-462)."""
+    nx_all, first, nx, n, p = 512, 192, 64, 512, 90
+    x = ellipsoids(nx_all, n, first=first, count=nx)
+    dev = tomoengine(nx, n, np.deg2rad(tilt_angles(p)))
+    dev.set_volume(x, VOL_ORIGINAL)
+    dev.create_projections()
+    b = dev.get_projections()
+    ref = make_oracle(nx, n, p)
+    ref.original_volume = x
+    ref.create_projections()
+    assert rel_l2(b, ref.b) < TOL
+    ref.set_tilt_series(b)
+    assert dev.get_option("sart_resident_active") == 1
+    dev.initialize_SART("sequential")
+    dev.SART(0.25, 1)
+    ref.SART(0.25, 1)
+    got = dev.get_volume()
+    e_res = rel_l2(got, ref.recon)
+    assert e_res < TOL, e_res
+    assert close(dev.data_distance(), ref.data_distance(normalize=False))
+    # the streamed chain on the same slab (what the resident form replaced; still the fallback): same bound, and next to the resident result
+    alt = tomoengine(nx, n, np.deg2rad(tilt_angles(p)))
+    alt.set_option("sart_resident", 0)
+    alt.set_tilt_series(b)
+    alt.SART(0.25, 1)
+    e_str = rel_l2(alt.get_volume(), ref.recon)
+    assert e_str < TOL and rel_l2(alt.get_volume(), got) < 2e-6, (e_str, rel_l2(alt.get_volume(), got))
+    del alt
+    start = ref.recon.copy()
+    dPOCS = 0.2 * float(np.linalg.norm(start.astype(np.float64).ravel()))
+    dev.set_volume(start)
+    tv_r, tv_d = ref.tv_gd(5, dPOCS), dev.tv_gd(5, dPOCS)
+    e5 = rel_l2(dev.get_volume(), ref.recon)
+    assert close(tv_d, tv_r) and e5 < 1e-6, e5
+    ref.recon[:] = start
+    dev.set_volume(start)
+    dev.SIRT(2)
+    ref.SIRT_norm(2)
+    e_sirt = rel_l2(dev.get_volume(), ref.recon)
+    assert e_sirt < TOL, e_sirt
+    assert close(dev.data_distance(), ref.data_distance(normalize=False))
+    print(f"rank-of-8 slab 64 x 512^2 x 90: SART resident {e_res:.2e}, streamed {e_str:.2e}; tv_gd(5) {e5:.2e}; SIRT x 2 {e_sirt:.2e}")
+
+
 def ulp_noise(x, seed):
     """x moved by one float32 ulp in a random direction per element: the smallest possible change of an input."""
     rng = np.random.default_rng(seed)

@@ -203,6 +203,7 @@ def test_sart_two_stream_sub_slabs_equal_one_chain(big):
     k_bp_angle writes every rounding out for that."""
     t, x, (nx, n, p), ang = big
     res = {}
+    t.set_option("sart_resident", 0)              # the launch structure of the STREAMED sweep is what this test is about
     for ns in (1, 2):
         t.set_option("sart_streams", ns)
         t.restart_recon()
@@ -211,6 +212,7 @@ def test_sart_two_stream_sub_slabs_equal_one_chain(big):
         t.SART(0.6, 1)
         res[ns] = (dp, t.get_volume())
     t.set_option("sart_streams", 1)
+    t.set_option("sart_resident", -1)
     # fp64 partial sums: atomics in any order, and a sub-slab may run its per-row kernels at another vector width
     assert res[1][0] == res[2][0] or abs(res[1][0] - res[2][0]) <= 1e-10 * res[1][0]
     assert np.array_equal(res[1][1], res[2][1])

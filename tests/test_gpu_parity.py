@@ -970,6 +970,7 @@ def test_tile_sart_step_matches_ray_walk_form_and_oracle(gpu, N, P, Nx):
     vols = {}
     for tile in (0, 1):
         t = tomoengine(Nx, N, ang * np.pi / 180)
+        t.set_option("sart_resident", 0)          # the two STREAMED forms (the resident sweep: tests/test_gpu_sart_resident.py)
         t.set_option("sart_tile", tile)
         t.set_tilt_series(ref.b)
         t.SART(0.7, 2)
@@ -1010,7 +1011,7 @@ def test_matrix_whose_ray_windows_defeat_the_tile_kernels(gpu):
     assert rel_l2(dev.get_volume(), ref.recon) < 1e-5
 
 
-@pytest.mark.parametrize("opts", [{}, {"sart_tile": 0}, {"sart_fused": 0}])
+@pytest.mark.parametrize("opts", [{}, {"sart_resident": 0}, {"sart_resident": 0, "sart_tile": 0}, {"sart_fused": 0}])
 def test_tracked_sart_and_tv_equal_the_separate_calls(gpu, opts):
     """tomo_sart_tracked / tomo_tv_gd_tracked = SART; matrix_2norm; copy_recon and tv_gd; matrix_2norm; copy_recon
     (examples/sim_ASD.py:68-88) with the norm and the snapshot formed inside the last pass: same volumes bit for bit."""

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 def _sweep(ns, n, nproj, opts, order="sequential", niter=2, tracked=False):
     ang = np.deg2rad(tilt_angles(nproj))
     t = tomoengine(ns, n, ang)
+    t.set_option("sart_resident", 0)      # these tests hold the STREAMED sweep's forms to each other (the resident sweep: test_gpu_sart_resident.py)
     for k, v in opts.items():
         t.set_option(k, v)
     vol = ellipsoids(ns, n)
