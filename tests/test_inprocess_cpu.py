@@ -32,7 +32,7 @@ def rel(a, b):
     return float(np.linalg.norm((a.astype(np.float64) - b).ravel()) / np.linalg.norm(b.astype(np.float64).ravel()))
 
 
-@pytest.mark.parametrize("world,Nx", [(2, 6), (3, 7), (1, 4)])
+@pytest.mark.parametrize("world,Nx", [(2, 6), (3, 7), (1, 4), (4, 9), (8, 16)])
 def test_facade_over_threads_equals_single_process_oracle(world, Nx):
     N, P = 16, 5
     ang = np.linspace(-65, 65, P)
@@ -85,3 +85,32 @@ def test_plain_process_config_follows_the_visible_devices(monkeypatch):
     monkeypatch.setattr(reconstructor, "device_count", lambda: [])
     with pytest.raises(ValueError):
         reconstructor.determine_gpu_config(-1)
+
+
+def test_plain_process_never_builds_more_slabs_than_slices(monkeypatch):
+    """``multigpuengine`` / ``multigpufusion`` in a plain process took every visible device, so a volume with fewer slices
+    than GPUs raised 'more ranks than slices' where the single-GPU path (and the reference's per-slice scheduler,
+    multigpuengine.cpp:163-193) works.  The device list is cut to the slice count; one device left = the plain single-GPU class."""
+    from tomo_tv_amd import chemistry, inprocess
+    seen = {}
+
+    class FakeFacade:
+        def __init__(self, make, devs):
+            seen["devs"] = list(devs)
+
+    class FakeSingle:
+        def __init__(self, *a, **k):
+            seen["single"] = k.get("device")
+
+    monkeypatch.setattr(inprocess, "visible_devices", lambda: list(range(8)))
+    monkeypatch.setattr(inprocess, "process_group_world", lambda: 1)
+    monkeypatch.setattr(inprocess, "InProcessMultiGPU", FakeFacade)
+    ang = np.deg2rad(np.linspace(-60, 60, 5))
+    assert isinstance(engine.multigpuengine(3, 16, ang), FakeFacade) and seen["devs"] == [0, 1, 2]
+    assert isinstance(engine.multigpuengine(100, 16, ang), FakeFacade) and seen["devs"] == list(range(8))
+    assert isinstance(engine.multigpuengine(5, 16, ang, devices=[4, 5, 6, 7, 1, 2]), FakeFacade) and seen["devs"] == [4, 5, 6, 7, 1]
+    monkeypatch.setattr(engine, "tomoengine", FakeSingle)
+    assert isinstance(engine.multigpuengine(1, 16, ang), FakeSingle) and seen["single"] == 0
+    assert isinstance(chemistry.multigpufusion(2, 16, 2, ang, ang), FakeFacade) and seen["devs"] == [0, 1]
+    monkeypatch.setattr(chemistry, "multimodal", FakeSingle)
+    assert isinstance(chemistry.multigpufusion(1, 16, 2, ang, ang, devices=[3, 4]), FakeSingle) and seen["single"] == 3

@@ -318,6 +318,9 @@ class multigpufusion(multimodal):
         from . import inprocess
         if group is None and inprocess.process_group_world() <= 1:
             devs = list(devices) if devices is not None else inprocess.visible_devices()
+            devs = devs[:max(1, min(len(devs), int(Nslice)))]        # never more slabs than slices; one device = the plain class
+            if len(devs) == 1:
+                return multimodal(Nslice, Nray, Nelements, haadfAngles, chemAngles, device=devs[0])
             return inprocess.InProcessMultiGPU(
                 lambda comm, dev: multimodal(Nslice, Nray, Nelements, haadfAngles, chemAngles, device=dev, comm=comm), devs)
         return super().__new__(cls)

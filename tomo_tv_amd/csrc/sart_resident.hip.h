@@ -52,8 +52,10 @@ struct RsArgs {
 };
 #ifdef RS_PROF
 #define RS_STAMP(q) { const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); if (wave == 0) tacc[q] += now_ - tprev; tprev = now_; }
+#define RS_TL(q) { if (k == 40 && blockIdx.x == 37 && lane == 0) rs_args()->prof[2048 + wave * 8 + (q)] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #else
 #define RS_STAMP(q)
+#define RS_TL(q)
 #endif
 
 __device__ __forceinline__ rs_u64 rs_gld(const rs_u64 *p)
@@ -83,12 +85,17 @@ __device__ __forceinline__ bool rs_give_up(unsigned &spins, unsigned spin_limit,
 }
 
 // ---- the two static loops over a wave's 64 pixels --------------------------------------------------------------------------------
-// Cells arrive 8 pixels (32 dwords) at a time into two SGPR sets, s[36:67] and s[68:99]: the loads of batch b + 1 go out before the
-// work on batch b (scalar loads return out of order: the wait between two batches is lgkmcnt(0)).  SB = first SGPR of the set,
-// K = pixel inside the batch, Q = pixel of the block.
-#define RS_LD(SB, OFF)                                                                                    \
-    "s_load_dwordx16 s[" #SB ":" #SB "+15], %[cp], " #OFF "\n"                                            \
-    "s_load_dwordx16 s[" #SB "+16:" #SB "+31], %[cp], " #OFF "+0x40\n"
+// Cells arrive 16 pixels (64 dwords = all of s[36:99]) at a time: four s_load_dwordx16, one wait, sixteen pixels of work.  A scalar
+// load is ~0.2 us from the L2 whatever its size and only lgkmcnt(0) is a safe wait (scalar loads return out of order), so what
+// counts is round trips per pass: double-buffered sets of 8 pixels (the first form: 8 round trips, each hidden behind 8 pixels = 0.03
+// to 0.07 us of this wave's own work) took 1.4 us (back projection) and 2.1 us (forward projection) per wave and pass; one set of 16
+// pixels has four, and the other three waves of the SIMD fill them (profiles/r05_resident_sweep.md).
+// SB = first SGPR of the set (36), K = pixel inside the batch, Q = pixel of the block.
+#define RS_LD(OFF)                                                                                        \
+    "s_load_dwordx16 s[36:51], %[cp], " #OFF "\n"                                                         \
+    "s_load_dwordx16 s[52:67], %[cp], " #OFF "+0x40\n"                                                    \
+    "s_load_dwordx16 s[68:83], %[cp], " #OFF "+0x80\n"                                                    \
+    "s_load_dwordx16 s[84:99], %[cp], " #OFF "+0xc0\n"
 // back-projection, cell {slot0 | slot1 << 8, w0, w1, inv}; index mode on SRC1; rows in v[32:47] (v47 = 0: the dummy row)
 #define RS_BP1(SB, K, Q)                                                                                  \
     "s_set_gpr_idx_idx s[" #SB "+4*" #K "]\n"                                                             \
@@ -105,18 +112,12 @@ __device__ __forceinline__ bool rs_give_up(unsigned &spins, unsigned spin_limit,
     "v_fma_f32 v32, s[" #SB "+4*" #K "+1], v[64+" #Q "], v32\n"                                           \
     "s_set_gpr_idx_idx s[" #SB "+4*" #K "+2]\n"                                                           \
     "v_fma_f32 v32, s[" #SB "+4*" #K "+3], v[64+" #Q "], v32\n"
-#define RS_BATCH(OP, SB, B)                                                                               \
-    OP(SB, 0, 8*B+0) OP(SB, 1, 8*B+1) OP(SB, 2, 8*B+2) OP(SB, 3, 8*B+3) OP(SB, 4, 8*B+4) OP(SB, 5, 8*B+5) OP(SB, 6, 8*B+6) OP(SB, 7, 8*B+7)
+#define RS_BATCH(OP, B)                                                                                   \
+    OP(36, 0, 16*B+0) OP(36, 1, 16*B+1) OP(36, 2, 16*B+2) OP(36, 3, 16*B+3) OP(36, 4, 16*B+4) OP(36, 5, 16*B+5) OP(36, 6, 16*B+6) OP(36, 7, 16*B+7) \
+    OP(36, 8, 16*B+8) OP(36, 9, 16*B+9) OP(36, 10, 16*B+10) OP(36, 11, 16*B+11) OP(36, 12, 16*B+12) OP(36, 13, 16*B+13) OP(36, 14, 16*B+14) OP(36, 15, 16*B+15)
 #define RS_WAIT "s_waitcnt lgkmcnt(0)\n"
 #define RS_SWEEP(OP)                                                                                      \
-    RS_LD(68, 0x080) RS_BATCH(OP, 36, 0) RS_WAIT                                                          \
-    RS_LD(36, 0x100) RS_BATCH(OP, 68, 1) RS_WAIT                                                          \
-    RS_LD(68, 0x180) RS_BATCH(OP, 36, 2) RS_WAIT                                                          \
-    RS_LD(36, 0x200) RS_BATCH(OP, 68, 3) RS_WAIT                                                          \
-    RS_LD(68, 0x280) RS_BATCH(OP, 36, 4) RS_WAIT                                                          \
-    RS_LD(36, 0x300) RS_BATCH(OP, 68, 5) RS_WAIT                                                          \
-    RS_LD(68, 0x380) RS_BATCH(OP, 36, 6) RS_WAIT                                                          \
-    RS_BATCH(OP, 68, 7)
+    RS_BATCH(OP, 0) RS_LD(0x100) RS_WAIT RS_BATCH(OP, 1) RS_LD(0x200) RS_WAIT RS_BATCH(OP, 2) RS_LD(0x300) RS_WAIT RS_BATCH(OP, 3)
 #define RS_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define RS_CLOBBERS                                                                                       \
     RS_CLOB4(s, 36, 37, 38, 39), RS_CLOB4(s, 40, 41, 42, 43), RS_CLOB4(s, 44, 45, 46, 47), RS_CLOB4(s, 48, 49, 50, 51),      \
@@ -285,6 +286,7 @@ void k_sart_resident(const RsArgs unused_by_name)
                     if (i2 < nr) rs_rbuf[i2][lane] = __uint_as_float((uint32_t)g2);
                 }
                 RS_STAMP(0)
+                RS_TL(0)
                 __syncthreads();
 #pragma unroll
                 for (int s = 0; s < 16; ++s) rr[s] = (s < RS_USABLE && dwv + s < nr) ? rs_rbuf[dwv + s][lane] : 0.f;
@@ -292,8 +294,9 @@ void k_sart_resident(const RsArgs unused_by_name)
                 const float beta = A->beta;
                 rs_touch(A, tile, wave, lane, k + 2 < steps ? rs_angle(A, k + 2) : -1, k + 1 < steps ? rs_angle(A, k + 1) : -1, rs_dump[wave]);
                 RS_STAMP(1)
+                RS_TL(1)
                 asm volatile("s_mov_b32 s33, m0\n"
-                             RS_LD(36, 0x000)
+                             RS_LD(0x000)
                              RS_WAIT
                              "s_set_gpr_idx_on s36, gpr_idx(SRC1)\n"
                              RS_SWEEP(RS_BP1)
@@ -303,6 +306,7 @@ void k_sart_resident(const RsArgs unused_by_name)
                              : [cp] "s"(cp), [beta] "s"(beta)
                              : RS_CLOBBERS);
                 RS_STAMP(2)
+                RS_TL(2)
             }
             if (k + 1 < steps) {
                 // ---- forward projection of the next angle, the workgroup's sums per window ray, the reducers' rows
@@ -320,7 +324,7 @@ void k_sart_resident(const RsArgs unused_by_name)
                 for (int s = 0; s < 16; ++s) rr[s] = 0.f;
                 const uint4 *cp = A->fpc + (((size_t)a * A->ntiles + tile) * RS_WAVES + wave) * 64;
                 asm volatile("s_mov_b32 s33, m0\n"
-                             RS_LD(36, 0x000)
+                             RS_LD(0x000)
                              RS_WAIT
                              "s_set_gpr_idx_on s36, gpr_idx(SRC2,DST)\n"
                              RS_SWEEP(RS_FP1)
@@ -330,21 +334,30 @@ void k_sart_resident(const RsArgs unused_by_name)
                              : [cp] "s"(cp)
                              : RS_CLOBBERS);
                 RS_STAMP(3)
+                RS_TL(3)
 #pragma unroll
                 for (int s = 0; s < 16; ++s) rs_pbuf[wave][s][lane] = rr[s];
                 __syncthreads();
                 rs_u64 *pb = A->pb + ((size_t)grp * A->ntiles + tile) * RS_MAXWIN * 64 + lane;
                 for (int i = wave; i < nr; i += RS_WAVES) {
-                    float acc = 0.f;
+                    // (sixteen independent LDS reads, then the additions in wave order: as a chain of "if in the window, read and add" every
+                    // read waited for the one before -- 1.5 to 2.5 us between the last wave's projection and the published sums)
+                    float v[RS_WAVES];
+                    bool in[RS_WAVES];
 #pragma unroll
                     for (int w = 0; w < RS_WAVES; ++w) {
                         const uint32_t dq = w < 4 ? dw0 : w < 8 ? dw1 : w < 12 ? dw2 : dw3;
                         const int s = i - (int)((dq >> ((w & 3) * 8)) & 255u);
-                        if ((unsigned)s < (unsigned)RS_USABLE) acc += rs_pbuf[w][s][lane];
+                        in[w] = (unsigned)s < (unsigned)RS_USABLE;
+                        v[w] = rs_pbuf[w][in[w] ? s : 0][lane];
                     }
+                    float acc = 0.f;
+#pragma unroll
+                    for (int w = 0; w < RS_WAVES; ++w) acc = in[w] ? acc + v[w] : acc;
                     rs_gst(pb + (size_t)i * 64, acc, ep);
                 }
                 RS_STAMP(4)
+                RS_TL(4)
                 const rs_u64 *pg = A->pb + (size_t)grp * A->ntiles * RS_MAXWIN * 64 + lane;
                 for (int r0 = 0; r0 < rpt; r0 += rpt2) {
                     const int jr = r0 + jr0, j = tile * rpt + jr;
@@ -377,6 +390,7 @@ void k_sart_resident(const RsArgs unused_by_name)
                         rs_sbuf[wave][lane] = acc;
                     }
                     RS_STAMP(5)
+                    RS_TL(5)
                     __syncthreads();
                     if (active && sub == 0) {
                         float tot = rs_sbuf[wave][lane];
@@ -389,6 +403,7 @@ void k_sart_resident(const RsArgs unused_by_name)
                     if (r0 + rpt2 < rpt) __syncthreads();
                 }
                 RS_STAMP(6)
+                RS_TL(6)
             }
         }
         {   // ---- the chunk goes back (and, tracked, into the snapshot volume with the squared step in part[])

@@ -1080,6 +1080,11 @@ class multigpuengine(tomoengine):
         from . import inprocess
         if group is None and not force_collectives and inprocess.process_group_world() <= 1:
             devs = list(devices) if devices is not None else inprocess.visible_devices()
+            # never more slabs than slices (the reference's per-slice scheduler simply leaves the surplus devices idle,
+            # multigpuengine.cpp:163-193); one device left = the plain single-GPU engine
+            devs = devs[:max(1, min(len(devs), int(Nslice)))]
+            if len(devs) == 1:
+                return tomoengine(Nslice, Nray, pyAngles, device=devs[0])
             return inprocess.InProcessMultiGPU(lambda comm, dev: tomoengine(Nslice, Nray, pyAngles, device=dev, comm=comm), devs)
         return super().__new__(cls)
 

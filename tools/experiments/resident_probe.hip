@@ -64,7 +64,7 @@ int main(int argc, char **argv)
     A.spin_limit = 1u << 20; A.beta = beta;
     std::vector<int> hang(steps); for (int k = 0; k < steps; ++k) hang[k] = k % P;
     int *dang; CK(hipMalloc(&dang, steps * 4)); CK(hipMemcpy(dang, hang.data(), steps * 4, hipMemcpyHostToDevice)); A.angs = dang;
-    long long *dprof; CK(hipMalloc(&dprof, 256 * 8 * 8)); CK(hipMemset(dprof, 0, 256 * 8 * 8)); A.prof = dprof;
+    long long *dprof; CK(hipMalloc(&dprof, (2048 + 128) * 8)); CK(hipMemset(dprof, 0, (2048 + 128) * 8)); A.prof = dprof;
     std::vector<float> tk0;
     float *dtk = nullptr;
     if (tracked) {
@@ -100,6 +100,12 @@ int main(int argc, char **argv)
         const int nwg = ntiles * ngrp; const double per = 0.01 / nwg / steps / ((nchunk + ngrp - 1) / ngrp);
         double av[8] = {0};
         for (int w = 0; w < nwg; ++w) for (int q = 0; q < 8; ++q) av[q] += hp[w * 8 + q] * per;
+        if (steps > 41 && ntiles * ngrp > 37) {
+            std::vector<long long> tl(128); CK(hipMemcpy(tl.data(), dprof + 2048, 128 * 8, hipMemcpyDeviceToHost));
+            long long t0 = tl[0]; for (int w = 0; w < 16; ++w) t0 = std::min(t0, tl[w * 8]);
+            printf("TIMELINE step 40, workgroup 37, us after the first wave had its rows (per wave: rows in | BP starts | BP done | FP done | sums published | reducer polled | final done)\n");
+            for (int w = 0; w < 16; ++w) { printf("  wave %2d:", w); for (int q = 0; q < 7; ++q) printf(" %6.2f", (tl[w * 8 + q] - t0) * 0.01); printf("\n"); }
+        }
         printf("PROF us per angle (wave 0, mean over workgroups): wait rows %.2f | barrier+rows->regs %.2f | BP %.2f | FP %.2f | block sums->LDS, barrier, tile sums, publish %.2f | reducer poll %.2f | barrier, final, publish %.2f | loop head %.2f\n",
                av[0], av[1], av[2], av[3], av[4], av[5], av[6], av[7]);
     }
