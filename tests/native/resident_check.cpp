@@ -1,10 +1,12 @@
 // Host-only check of the tables of the volume-resident SART sweep (tomo_tv_amd/csrc/resident.cpp: build_sart_resident).
 // Replays what k_sart_resident does with them, in double precision on one slice:
-//   forward projection  -- per (tile, wave) the block sums acc[slot] += w x[pixel] from the fpc cells, per tile the sums of its window
-//                          rays over the waves (slot = window index - dw[wave], slots 0..13 only), per ray the tile sums named by
-//                          its reducer list -- must equal the CSR product A x, every nonzero weight used exactly once;
-//   back projection     -- the bpc cell of every pixel must name the rays / weights of the cell table through the wave's window
-//                          (jbase + dw + slot) and carry 1 / (w0 + w1) as the single-precision quotient;
+//   forward projection  -- per (tile, wave) the block sums acc[s0] += w0 x[pixel], acc[s0 + 1] += w1 x[pixel] from the cells, per tile
+//                          the sums of its window rays from the block sums the ts lists name (wave << 4 | slot, ascending wave, padded
+//                          with a row that must stay zero), per ray the tile sums named by its reducer list -- must equal the CSR
+//                          product A x, every nonzero weight used exactly once;
+//   back projection     -- the cell of every pixel must name the rays / weights of the cell table through the wave's window
+//                          (jbase + dw + s0, and the NEXT ray for the second weight) and carry 1 / (w0 + w1) as the single-precision
+//                          quotient;
 //   windows             -- a tile's window holds <= MAXWIN rays, a wave's <= USABLE, every list <= RL entries, ascending tile.
 // Usage: resident_check N P max_abs_angle_deg [max_tiles=256] [quiet]
 #include <cmath>
@@ -36,7 +38,7 @@ int main(int argc, char **argv)
     const int64_t npix = (int64_t)N * N;
     REQUIRE(R.tiles == (N + T - 1) / T && ntiles == R.tiles * R.tiles && ntiles <= max_tiles, "tile counts");
     REQUIRE(R.rpt * ntiles >= N, "every ray needs a reducer");
-    REQUIRE(R.hdr.size() == (size_t)P * ntiles && R.fpc.size() == (size_t)P * ntiles * W * Q * 4 && R.bpc.size() == R.fpc.size() && R.rl.size() == (size_t)P * N * Resident::RL, "table sizes");
+    REQUIRE(R.hdr.size() == (size_t)P * ntiles && R.cell.size() == (size_t)P * ntiles * W * Q * 4 && R.ts.size() == (size_t)P * ntiles * Resident::MAXWIN * Resident::TSN && R.rl.size() == (size_t)P * N * Resident::RL, "table sizes");
     std::mt19937 rng(7); std::uniform_real_distribution<double> U(0.1, 1.0);
     std::vector<double> x(npix);
     for (auto &v : x) v = U(rng);
@@ -52,38 +54,51 @@ int main(int argc, char **argv)
             const int y0 = (k / R.tiles) * T, z0 = (k % R.tiles) * T;
             std::vector<double> pbuf((size_t)W * 16, 0.0);
             for (int w = 0; w < W; ++w) {
-                const uint32_t *fc = R.fpc.data() + (((size_t)i * ntiles + k) * W + w) * Q * 4;
-                const uint32_t *bc = R.bpc.data() + (((size_t)i * ntiles + k) * W + w) * Q * 4;
+                const uint32_t *cc = R.cell.data() + (((size_t)i * ntiles + k) * W + w) * Q * 4;
                 int top = -1;
                 for (int q = 0; q < Q; ++q) {
                     int ly, lz; Resident::pixel(w, q, ly, lz);
                     const int y = y0 + ly, z = z0 + lz;
-                    const uint32_t s0 = fc[q * 4], s1 = fc[q * 4 + 2];
-                    const float w0 = bitsf(fc[q * 4 + 1]), w1 = bitsf(fc[q * 4 + 3]);
-                    REQUIRE(s0 < 16 && s1 < 16, "slot range");
-                    REQUIRE((w0 != 0.f) == (s0 < (uint32_t)Resident::USABLE) && (w1 != 0.f) == (s1 < (uint32_t)Resident::USABLE) && (w0 != 0.f || s0 == Resident::DUMMY) && (w1 != 0.f || s1 == Resident::DUMMY),
-                            "a zero weight must aim at the dummy slot and a real one at slots 0..13 (tile %d wave %d pixel %d angle %d)", k, w, q, i);
-                    REQUIRE(bc[q * 4] == (s0 | (s1 << 8)) && bc[q * 4 + 1] == fc[q * 4 + 1] && bc[q * 4 + 2] == fc[q * 4 + 3], "bpc cell differs from fpc cell");
+                    const uint32_t s0 = cc[q * 4];
+                    const float w0 = bitsf(cc[q * 4 + 1]), w1 = bitsf(cc[q * 4 + 2]);
+                    REQUIRE(s0 <= (uint32_t)Resident::SINK, "slot range");
+                    REQUIRE((w0 != 0.f) == (s0 < (uint32_t)Resident::USABLE) && (w1 == 0.f || (w0 != 0.f && s0 + 1 < (uint32_t)Resident::USABLE)),
+                            "a pixel without rays must aim at the sink, a real first ray at slots 0..13, a second ray needs a first (tile %d wave %d pixel %d angle %d)", k, w, q, i);
                     const float cs = w0 + w1, inv = 1.0f / (cs > 0.f ? cs : 1.0f);
-                    REQUIRE(bitsf(bc[q * 4 + 3]) == inv, "divisor");
+                    REQUIRE(bitsf(cc[q * 4 + 3]) == inv, "divisor");
                     if (y >= N || z >= N) { REQUIRE(w0 == 0.f && w1 == 0.f, "weight outside the image"); continue; }
                     const Cell &c = ci[(int64_t)y * N + z];
                     const int base = h.jbase + h.dw[w];
                     if (c.w0 != 0.f) { REQUIRE(w0 == c.w0 && base + (int)s0 == (int)c.r0, "first ray of pixel (%d,%d) angle %d", y, z, i); ++nz_cells; }
                     else REQUIRE(w0 == 0.f, "phantom first weight");
-                    if (c.w1 != 0.f) { REQUIRE(w1 == c.w1 && base + (int)s1 == (int)c.r1, "second ray of pixel (%d,%d) angle %d", y, z, i); ++nz_cells; }
+                    if (c.w1 != 0.f) { REQUIRE(w1 == c.w1 && base + (int)s0 + 1 == (int)c.r1, "second ray of pixel (%d,%d) angle %d", y, z, i); ++nz_cells; }
                     else REQUIRE(w1 == 0.f, "phantom second weight");
                     pbuf[(size_t)w * 16 + s0] += (double)w0 * x[(int64_t)y * N + z];
-                    pbuf[(size_t)w * 16 + s1] += (double)w1 * x[(int64_t)y * N + z];
+                    pbuf[(size_t)w * 16 + s0 + 1] += (double)w1 * x[(int64_t)y * N + z];
                     if (w0 != 0.f) top = std::max(top, (int)s0);
-                    if (w1 != 0.f) top = std::max(top, (int)s1);
+                    if (w1 != 0.f) top = std::max(top, (int)s0 + 1);
                 }
                 REQUIRE(top < 0 || h.dw[w] + top < h.nrays, "a wave's window reaches beyond the tile's");
+                REQUIRE(pbuf[(size_t)w * 16 + 14] == 0.0 && pbuf[(size_t)w * 16 + 15] == 0.0, "the sink rows must stay zero");
                 max_wwin = std::max(max_wwin, top + 1);
             }
             for (int r = 0; r < h.nrays; ++r) {
+                const uint8_t *e = R.ts.data() + (((size_t)i * ntiles + k) * Resident::MAXWIN + r) * Resident::TSN;
                 double acc = 0.0;
-                for (int w = 0; w < W; ++w) { const int s = r - h.dw[w]; if ((unsigned)s < (unsigned)Resident::USABLE) acc += pbuf[(size_t)w * 16 + s]; }
+                int prev = -1;
+                bool padded = false;
+                for (int c = 0; c < Resident::TSN; ++c) {
+                    if (e[c] == Resident::TS_PAD) { padded = true; continue; }
+                    REQUIRE(!padded, "entry behind the padding");
+                    const int w = e[c] >> 4, sl = e[c] & 15;
+                    REQUIRE(w > prev && sl < Resident::USABLE && h.dw[w] + sl == r, "tile-sum entry %d of ray %d tile %d angle %d", c, r, k, i);
+                    acc += pbuf[(size_t)w * 16 + sl];
+                    prev = w;
+                }
+                // every block sum that carries weight on this ray is in the list (the others are exact zeros)
+                double all = 0.0;
+                for (int w = 0; w < W; ++w) { const int sl = r - h.dw[w]; if ((unsigned)sl < (unsigned)Resident::USABLE) all += pbuf[(size_t)w * 16 + sl]; }
+                REQUIRE(acc == all, "tile sum of ray %d tile %d angle %d misses a block", r, k, i);
                 tsum[(size_t)k * Resident::MAXWIN + r] = acc;
             }
         }

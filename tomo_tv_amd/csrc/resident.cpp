@@ -31,12 +31,13 @@ void build_sart_resident(int N, int P, const Tables &t, int max_tiles, Resident 
     r.ntiles = r.tiles * r.tiles;
     if (r.ntiles > max_tiles) { r.why = "more tiles than resident workgroups"; return; }
     if (t.cell.size() != (size_t)P * N * N) { r.why = "no cell table"; return; }
+    if (!t.art_chain_ok) { r.why = "a pixel's two rays of an angle are not neighbours"; return; }
     r.rpt = (N + r.ntiles - 1) / r.ntiles;
     const int64_t npix = (int64_t)N * N;
     const int ntiles = r.ntiles;
     r.hdr.assign((size_t)P * ntiles, Resident::Hdr{});
-    r.fpc.assign((size_t)P * ntiles * W * Q * 4, 0u);
-    r.bpc.assign((size_t)P * ntiles * W * Q * 4, 0u);
+    r.cell.assign((size_t)P * ntiles * W * Q * 4, 0u);
+    r.ts.assign((size_t)P * ntiles * Resident::MAXWIN * Resident::TSN, (uint8_t)Resident::TS_PAD);
     r.rl.assign((size_t)P * N * Resident::RL, (uint16_t)0xFFFFu);
     const int nth = (int)std::max(1u, std::min<unsigned>(resident_threads(), (unsigned)P));
     std::vector<std::string> bad(nth);
@@ -69,26 +70,39 @@ void build_sart_resident(int N, int P, const Tables &t, int max_tiles, Resident 
                 if (nr > (uint32_t)Resident::MAXWIN) { if (bad[th].empty()) bad[th] = "a tile's ray window exceeds " + std::to_string(Resident::MAXWIN) + " rays at angle " + std::to_string(i); continue; }
                 if (!bad[th].empty()) continue;
                 h.jbase = (uint16_t)tlo; h.nrays = (uint16_t)nr;
+                uint8_t *ts = r.ts.data() + ((size_t)i * ntiles + k) * Resident::MAXWIN * Resident::TSN;
+                int tsn[Resident::MAXWIN] = {0};
                 for (int w = 0; w < W; ++w) {
                     const uint32_t base = wlo[w] == 0xFFFFFFFFu ? tlo : wlo[w];
                     h.dw[w] = (uint8_t)(base - tlo);
-                    uint32_t *fp = r.fpc.data() + (((size_t)i * ntiles + k) * W + w) * Q * 4;
-                    uint32_t *bp = r.bpc.data() + (((size_t)i * ntiles + k) * W + w) * Q * 4;
+                    uint32_t *cp = r.cell.data() + (((size_t)i * ntiles + k) * W + w) * Q * 4;
+                    bool used[Resident::USABLE] = {false};
                     for (int q = 0; q < Q; ++q) {
                         int ly, lz; Resident::pixel(w, q, ly, lz);
                         const int y = y0 + ly, z = z0 + lz;
-                        uint32_t s0 = Resident::DUMMY, s1 = Resident::DUMMY;
+                        uint32_t s0 = Resident::SINK;
                         float w0 = 0.f, w1 = 0.f;
                         if (y < N && z < N) {
                             const Cell &c = ci[(int64_t)y * N + z];
-                            if (c.w0 != 0.f) { s0 = c.r0 - base; w0 = c.w0; }
-                            if (c.w1 != 0.f) { s1 = c.r1 - base; w1 = c.w1; }
+                            if (c.w0 != 0.f) { s0 = c.r0 - base; w0 = c.w0; if (s0 < (uint32_t)Resident::USABLE) used[s0] = true; }
+                            if (c.w1 != 0.f) {
+                                // (the neighbour property: the second ray is the next one; a first ray with weight 0 cannot have a second)
+                                if ((c.w0 == 0.f || c.r1 != c.r0 + 1 || s0 + 1 >= (uint32_t)Resident::USABLE) && bad[th].empty()) bad[th] = "second ray of a pixel is not the next ray of its block window";
+                                w1 = c.w1;
+                                if (s0 + 1 < (uint32_t)Resident::USABLE) used[s0 + 1] = true;
+                            }
                         }
                         // the divisor of k_bp_angle / k_sart_tile: 1 / (w0 + w1), 1 where no ray crosses the pixel (IEEE single division)
                         const float cs = w0 + w1;
                         const float inv = 1.0f / (cs > 0.f ? cs : 1.0f);
-                        fp[q * 4 + 0] = s0; fp[q * 4 + 1] = fbits(w0); fp[q * 4 + 2] = s1; fp[q * 4 + 3] = fbits(w1);
-                        bp[q * 4 + 0] = s0 | (s1 << 8); bp[q * 4 + 1] = fbits(w0); bp[q * 4 + 2] = fbits(w1); bp[q * 4 + 3] = fbits(inv);
+                        cp[q * 4 + 0] = s0; cp[q * 4 + 1] = fbits(w0); cp[q * 4 + 2] = fbits(w1); cp[q * 4 + 3] = fbits(inv);
+                    }
+                    // this wave's block sums, by window ray of the tile (waves ascend, so every list is in wave order)
+                    for (int sl = 0; sl < Resident::USABLE; ++sl) {
+                        if (!used[sl]) continue;
+                        const int row = (int)(base - tlo) + sl;
+                        if (tsn[row] >= Resident::TSN) { if (bad[th].empty()) bad[th] = "more than " + std::to_string(Resident::TSN) + " blocks of a tile on one ray"; continue; }
+                        ts[row * Resident::TSN + tsn[row]++] = (uint8_t)(w << 4 | sl);
                     }
                 }
             }
@@ -110,7 +124,7 @@ void build_sart_resident(int N, int P, const Tables &t, int max_tiles, Resident 
     for (int th = 1; th < nth; ++th) thr.emplace_back(work, th);
     work(0);
     for (auto &x : thr) x.join();
-    for (auto &b : bad) if (!b.empty()) { r.why = b; r.hdr.clear(); r.fpc.clear(); r.bpc.clear(); r.rl.clear(); r.hdr.shrink_to_fit(); r.fpc.shrink_to_fit(); r.bpc.shrink_to_fit(); r.rl.shrink_to_fit(); return; }
+    for (auto &b : bad) if (!b.empty()) { r.why = b; r.hdr.clear(); r.cell.clear(); r.ts.clear(); r.rl.clear(); r.hdr.shrink_to_fit(); r.cell.shrink_to_fit(); r.ts.shrink_to_fit(); r.rl.shrink_to_fit(); return; }
     r.ok = true;
 }
 

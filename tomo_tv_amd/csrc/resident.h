@@ -8,9 +8,12 @@
 // What the kernel needs from the host, per angle i and tile k:
 //   hdr[i*ntiles + k]   jbase = first ray of the tile's window, nrays = its length (<= MAXWIN), dw[w] = first ray of wave w's block
 //                       window minus jbase
-//   fpc / bpc           per (i, k, wave, pixel q of the block, row-major) one 16-byte cell, read by SCALAR loads:
-//                         fpc {slot0, w0, slot1, w1}               slot = ray - first ray of the wave's window, DUMMY for "no ray"
-//                         bpc {slot0 | slot1 << 8, w0, w1, 1/(w0+w1)}   (1 where the pixel has no ray: the update adds 0)
+//   cell                per (i, k, wave, pixel q of the block, row-major) one 16-byte cell {slot0, w0, w1, 1/(w0+w1)}, read by SCALAR
+//                       loads in both passes: slot0 = the pixel's first ray - first ray of the wave's window; its second ray is ALWAYS
+//                       the next one (slot0 + 1: the neighbour property build_tables checks as art_chain_ok -- one register index per
+//                       pixel picks both); a pixel no ray crosses: slot0 = SINK, weights 0, divisor 1
+//   ts[(i*ntiles+k)*MAXWIN + r]  the block sums that make up the tile's sum of window ray r: up to TSN bytes wave << 4 | slot,
+//                       ascending wave, padded with TS_PAD (a block-sum row that is always zero)
 //   rl[(i*N + j)*RL ..] the tiles whose window holds ray j, ascending, as row ids tile * MAXWIN + (j - jbase); 0xFFFF ends the list
 #pragma once
 #include <cstdint>
@@ -22,7 +25,7 @@
 namespace tomo {
 
 struct Resident {
-    static constexpr int T = 32, B = 8, WAVES = 16, PPW = 64, NSLOT = 16, USABLE = 14, DUMMY = 15, MAXWIN = 48, RL = 32;
+    static constexpr int T = 32, B = 8, WAVES = 16, PPW = 64, NSLOT = 16, USABLE = 14, SINK = 14, MAXWIN = 48, RL = 32, TSN = 8, TS_PAD = 0x0E;
     struct Hdr { uint16_t jbase, nrays; uint8_t dw[WAVES]; uint8_t pad[12]; };
     static_assert(sizeof(Hdr) == 32, "header layout");
     bool ok = false;
@@ -30,7 +33,8 @@ struct Resident {
     int tiles = 0, ntiles = 0;      // tiles per image side, tiles of the image
     int rpt = 0;                    // rays of an angle a tile reduces: [tile * rpt, tile * rpt + rpt)
     std::vector<Hdr> hdr;           // [P * ntiles]
-    std::vector<uint32_t> fpc, bpc; // [P * ntiles * WAVES * PPW * 4]
+    std::vector<uint32_t> cell;     // [P * ntiles * WAVES * PPW * 4]
+    std::vector<uint8_t> ts;        // [P * ntiles * MAXWIN * TSN]
     std::vector<uint16_t> rl;       // [P * N * RL]
     // pixel q of wave w inside its tile
     static void pixel(int w, int q, int &ly, int &lz) { ly = (w >> 2) * B + (q >> 3); lz = (w & 3) * B + (q & 7); }

@@ -5,12 +5,13 @@
 // tomoengine.cpp:162-179: one forward projection, one residual, one clamped back-projection per angle, angles in sequence):
 //   * one workgroup of 16 waves per 32 x 32-pixel tile, one workgroup per CU (N <= 512: at most 256 tiles); wave w holds the
 //     8 x 8 block (w / 4, w % 4) of the tile in v[64:127], one register per pixel, lane = slice;
-//   * back-projection of angle a:  x[q] = max(0, x[q] + beta * ((w0 r[s0] + w1 r[s1]) * inv))   -- the expression of k_bp_angle,
+//   * back-projection of angle a:  x[q] = max(0, x[q] + beta * ((w0 r[s0] + w1 r[s0+1]) * inv))   -- the expression of k_bp_angle,
 //     rounding for rounding; the (at most 14) residual rows that cross the block sit in v[32:45], picked through the VGPR index
-//     mode (s_set_gpr_idx: M0[7:0] is added to the register number of the operands the mode names), the cell {slots, w0, w1, inv}
-//     is SCALAR data (s_load_dwordx16: four pixels per load);
-//   * forward projection of angle a+1:  acc[s0] += w0 x[q]; acc[s1] += w1 x[q]  with the pixel STATIC in the instruction and the
-//     ray's accumulator (v[32:45] again) picked through the index mode -- no LDS image, no lane moves;
+//     mode (s_set_gpr_idx: M0[7:0] is added to the register number of the operands the mode names), the cell {s0, w0, w1, inv}
+//     is SCALAR data (s_load_dwordx16: four pixels per load).  A pixel's two rays of an angle are neighbours, so ONE index per
+//     pixel serves both: the second operand is written one register higher;
+//   * forward projection of angle a+1:  acc[s0] += w0 x[q]; acc[s0+1] += w1 x[q]  with the pixel STATIC in the instruction and the
+//     ray's accumulator (v[32:45] again) picked through the index mode -- no LDS image, no lane moves; the SAME cells;
 //   * exchange, per angle: the workgroup adds its waves' block sums per ray of the tile's window (LDS, fixed order) and publishes
 //     them; a ray's reducer (16 / rpt waves of tile j / rpt) adds the tile sums in ascending tile order, forms
 //     r = (b - sum) / rowsum (k_resid_finish's expression) and publishes the row; every workgroup picks up the <= 48 rows of its window.
@@ -38,7 +39,8 @@ struct RsArgs {
     float *x;                       // the swept volume [pixel][sx]
     const float *b, *rowsum;        // measured rows [row][sx]; row sums
     const RsHdrD *hdr;
-    const uint4 *fpc, *bpc;
+    const uint4 *cell;              // [angle][tile][wave][pixel] {s0, w0, w1, inv}
+    const uint2 *ts;                // [angle][tile][window ray] eight block sums wave << 4 | slot
     const uint16_t *rl;
     rs_u64 *pb, *rb;                // granules: tile sums [group][tile][RS_MAXWIN][64], residual rows [group][angle][ray][64]
     const int *angs;                // angle of step k (steps entries)
@@ -96,35 +98,45 @@ __device__ __forceinline__ bool rs_give_up(unsigned &spins, unsigned spin_limit,
     "s_load_dwordx16 s[52:67], %[cp], " #OFF "+0x40\n"                                                    \
     "s_load_dwordx16 s[68:83], %[cp], " #OFF "+0x80\n"                                                    \
     "s_load_dwordx16 s[84:99], %[cp], " #OFF "+0xc0\n"
-// back-projection, cell {slot0 | slot1 << 8, w0, w1, inv}; index mode on SRC1; rows in v[32:47] (v47 = 0: the dummy row)
+#ifndef RS_WHATIF
+#define RS_WHATIF 0            // measurement builds only (results are WRONG): 1 no index changes, 2 no cell loads after the first batch
+#endif
+#if RS_WHATIF & 1
+#define RS_IDX(SB, K)
+#else
+#define RS_IDX(SB, K) "s_set_gpr_idx_idx s[" #SB "+4*" #K "]\n"
+#endif
+// back-projection, cell {s0, w0, w1, inv}; index mode on SRC1; rows in v[32:47] (v46 = v47 = 0: where a pixel without rays points)
 #define RS_BP1(SB, K, Q)                                                                                  \
-    "s_set_gpr_idx_idx s[" #SB "+4*" #K "]\n"                                                             \
+    RS_IDX(SB, K)                                                                                         \
     "v_mul_f32 v48, s[" #SB "+4*" #K "+1], v32\n"                                                         \
-    "s_lshr_b32 s34, s[" #SB "+4*" #K "], 8\n"                                                            \
-    "s_set_gpr_idx_idx s34\n"                                                                             \
-    "v_fma_f32 v48, s[" #SB "+4*" #K "+2], v32, v48\n"                                                    \
+    "v_fma_f32 v48, s[" #SB "+4*" #K "+2], v33, v48\n"                                                    \
     "v_mul_f32 v48, v48, s[" #SB "+4*" #K "+3]\n"                                                         \
     "v_fma_f32 v[64+" #Q "], v48, %[beta], v[64+" #Q "]\n"                                                \
     "v_max_f32 v[64+" #Q "], v[64+" #Q "], 0\n"
-// forward projection, cell {slot0, w0, slot1, w1}; index mode on SRC2 and DST; ray sums in v[32:47] (v47 = the sink of "no ray")
+// forward projection, the same cell; index mode on SRC2 and DST; ray sums in v[32:47] (v46, v47: the sink of pixels without rays,
+// which only ever receives 0 * x)
 #define RS_FP1(SB, K, Q)                                                                                  \
-    "s_set_gpr_idx_idx s[" #SB "+4*" #K "]\n"                                                             \
+    RS_IDX(SB, K)                                                                                         \
     "v_fma_f32 v32, s[" #SB "+4*" #K "+1], v[64+" #Q "], v32\n"                                           \
-    "s_set_gpr_idx_idx s[" #SB "+4*" #K "+2]\n"                                                           \
-    "v_fma_f32 v32, s[" #SB "+4*" #K "+3], v[64+" #Q "], v32\n"
+    "v_fma_f32 v33, s[" #SB "+4*" #K "+2], v[64+" #Q "], v33\n"
 #define RS_BATCH(OP, B)                                                                                   \
     OP(36, 0, 16*B+0) OP(36, 1, 16*B+1) OP(36, 2, 16*B+2) OP(36, 3, 16*B+3) OP(36, 4, 16*B+4) OP(36, 5, 16*B+5) OP(36, 6, 16*B+6) OP(36, 7, 16*B+7) \
     OP(36, 8, 16*B+8) OP(36, 9, 16*B+9) OP(36, 10, 16*B+10) OP(36, 11, 16*B+11) OP(36, 12, 16*B+12) OP(36, 13, 16*B+13) OP(36, 14, 16*B+14) OP(36, 15, 16*B+15)
 #define RS_WAIT "s_waitcnt lgkmcnt(0)\n"
+#if RS_WHATIF & 2
+#define RS_SWEEP(OP) RS_BATCH(OP, 0) RS_BATCH(OP, 1) RS_BATCH(OP, 2) RS_BATCH(OP, 3)
+#else
 #define RS_SWEEP(OP)                                                                                      \
     RS_BATCH(OP, 0) RS_LD(0x100) RS_WAIT RS_BATCH(OP, 1) RS_LD(0x200) RS_WAIT RS_BATCH(OP, 2) RS_LD(0x300) RS_WAIT RS_BATCH(OP, 3)
+#endif
 #define RS_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define RS_CLOBBERS                                                                                       \
     RS_CLOB4(s, 36, 37, 38, 39), RS_CLOB4(s, 40, 41, 42, 43), RS_CLOB4(s, 44, 45, 46, 47), RS_CLOB4(s, 48, 49, 50, 51),      \
     RS_CLOB4(s, 52, 53, 54, 55), RS_CLOB4(s, 56, 57, 58, 59), RS_CLOB4(s, 60, 61, 62, 63), RS_CLOB4(s, 64, 65, 66, 67),      \
     RS_CLOB4(s, 68, 69, 70, 71), RS_CLOB4(s, 72, 73, 74, 75), RS_CLOB4(s, 76, 77, 78, 79), RS_CLOB4(s, 80, 81, 82, 83),      \
     RS_CLOB4(s, 84, 85, 86, 87), RS_CLOB4(s, 88, 89, 90, 91), RS_CLOB4(s, 92, 93, 94, 95), RS_CLOB4(s, 96, 97, 98, 99),      \
-    "s33", "s34", "v48", "scc", "memory"
+    "s33", "v48", "memory"
 
 // the chunk in and out: a running scalar pointer to the pixel's row of slices + the lane's byte offset; 8 pixels of a block row are
 // RS_PS bytes apart, the next block row follows after RS_RS more
@@ -171,20 +183,15 @@ __device__ __forceinline__ int rs_angle(RsArgsP A, int k)
     return ((const RS_K int *)A->angs)[k];
 }
 
-// The cells stream from HBM once per chunk and angle, and a scalar load has nothing to hide a miss behind: a step ahead of their use
-// every wave pulls the lines of its 1-KB cell block into the L2 with one LDS-DMA load per 128-byte line (no register to wait for:
-// the data goes to a dump row of the LDS that nobody reads; lanes 0-7 the fpc block of angle af, lanes 8-15 the bpc block of angle ab)
-__device__ __forceinline__ void rs_touch(RsArgsP A, int tile, int wave, int lane, int af, int ab, float *dump)
+// The cells stream from HBM once per chunk and angle, and a scalar load has nothing to hide a miss behind: a step ahead of their first
+// use (the forward projection; the back projection a step later finds them in the L2) every wave pulls the lines of its 1-KB cell
+// block into the L2 with one LDS-DMA load per 128-byte line (no register to wait for: the data goes to a dump row of the LDS that
+// nobody reads)
+__device__ __forceinline__ void rs_touch(RsArgsP A, int tile, int wave, int lane, int an, float *dump)
 {
-    if (lane < 16) {
-        const int an = lane < 8 ? af : ab;
-        if (an >= 0) {
-            const size_t cb = (((size_t)an * A->ntiles + tile) * RS_WAVES + wave) * 64;
-            const uint4 *fb = A->fpc, *bb = A->bpc;
-            asm volatile("" : "+s"(fb), "+s"(bb));     // (two scalar loads, then a select: not one vector load through a selected address)
-            const uint32_t *tp = reinterpret_cast<const uint32_t *>((lane < 8 ? fb : bb) + cb) + (lane & 7) * 32;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)tp, (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
-        }
+    if (lane < 8 && an >= 0) {
+        const uint32_t *tp = reinterpret_cast<const uint32_t *>(A->cell + (((size_t)an * A->ntiles + tile) * RS_WAVES + wave) * 64) + lane * 32;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)tp, (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
     }
 }
 
@@ -201,6 +208,7 @@ void k_sart_resident(const RsArgs unused_by_name)
     v16f rr;
 #ifdef RS_PROF
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)__builtin_amdgcn_s_memrealtime();
+    const long long clk0 = (long long)__builtin_amdgcn_s_memtime(), rt0 = tprev;
 #endif
     int tile, grp, ngrp, chunk, chunk_end, steps;
     {
@@ -212,8 +220,8 @@ void k_sart_resident(const RsArgs unused_by_name)
         const uint32_t voff = (uint32_t)(chunk * 64 + lane) * 4u;
         {   // ---- the chunk comes in (a block outside the image holds zeros: its cells carry no weights)
             RsArgsP A = rs_args();
-            rs_touch(A, tile, wave, lane, rs_angle(A, 0), rs_angle(A, 0), rs_dump[wave]);
-            if (steps > 1) rs_touch(A, tile, wave, lane, rs_angle(A, 1), -1, rs_dump[wave]);
+            rs_touch(A, tile, wave, lane, rs_angle(A, 0), rs_dump[wave]);
+            if (steps > 1) rs_touch(A, tile, wave, lane, rs_angle(A, 1), rs_dump[wave]);
             const int n = A->n, sx = A->sx;
             const int ty = tile / A->tiles, tz = tile - ty * A->tiles;
             const int y0 = ty * RS_T + (wave >> 2) * 8, z0 = tz * RS_T + (wave & 3) * 8;
@@ -240,7 +248,8 @@ void k_sart_resident(const RsArgs unused_by_name)
             // wait for the residual rows, so that none of these (cold) loads sits on the path from the rows to the published sums.
             // reducer duty: rays [tile * rpt, tile * rpt + rpt) of every angle; a ray's list is shared by wpr waves
             int f_nr = 0, f_jbase = 0, f_rpt = 1, f_rpt2 = 1, f_wpr = RS_WAVES, f_cpw = RS_RL / RS_WAVES, f_jr0 = 0, f_sub = 0;
-            uint32_t f_dw0 = 0, f_dw1 = 0, f_dw2 = 0, f_dw3 = 0;
+            uint32_t f_dwv = 0;
+            rs_u2 f_ts0 = {0u, 0u}, f_ts1 = {0u, 0u}, f_ts2 = {0u, 0u};
             rs_u2 f_ids0 = {0xFFFFFFFFu, 0xFFFFFFFFu};
             float f_rs0 = 0.f, f_bv0 = 0.f;
             if (k + 1 < steps) {
@@ -249,7 +258,11 @@ void k_sart_resident(const RsArgs unused_by_name)
                 const int a = rs_angle(A, k + 1);
                 const RS_K RsHdrD *h = (const RS_K RsHdrD *)A->hdr + (size_t)a * A->ntiles + tile;
                 f_nr = h->nrays; f_jbase = h->jbase;
-                f_dw0 = h->dw[0]; f_dw1 = h->dw[1]; f_dw2 = h->dw[2]; f_dw3 = h->dw[3];
+                f_dwv = (h->dw[wave >> 2] >> ((wave & 3) * 8)) & 255u;
+                {   // the block sums behind this wave's (at most three) window rays
+                    const RS_K rs_u2 *tsp = (const RS_K rs_u2 *)A->ts + ((size_t)a * A->ntiles + tile) * RS_MAXWIN;
+                    f_ts0 = tsp[wave]; f_ts1 = tsp[wave + 16]; f_ts2 = tsp[wave + 32];
+                }
                 f_rpt = A->rpt;
                 while (f_rpt2 < f_rpt && f_rpt2 < RS_WAVES) f_rpt2 *= 2;
                 f_wpr = RS_WAVES / f_rpt2; f_cpw = RS_RL / f_wpr;
@@ -290,9 +303,9 @@ void k_sart_resident(const RsArgs unused_by_name)
                 __syncthreads();
 #pragma unroll
                 for (int s = 0; s < 16; ++s) rr[s] = (s < RS_USABLE && dwv + s < nr) ? rs_rbuf[dwv + s][lane] : 0.f;
-                const uint4 *cp = A->bpc + (((size_t)a * A->ntiles + tile) * RS_WAVES + wave) * 64;
+                const uint4 *cp = A->cell + (((size_t)a * A->ntiles + tile) * RS_WAVES + wave) * 64;
                 const float beta = A->beta;
-                rs_touch(A, tile, wave, lane, k + 2 < steps ? rs_angle(A, k + 2) : -1, k + 1 < steps ? rs_angle(A, k + 1) : -1, rs_dump[wave]);
+                rs_touch(A, tile, wave, lane, k + 2 < steps ? rs_angle(A, k + 2) : -1, rs_dump[wave]);
                 RS_STAMP(1)
                 RS_TL(1)
                 asm volatile("s_mov_b32 s33, m0\n"
@@ -315,14 +328,13 @@ void k_sart_resident(const RsArgs unused_by_name)
                 const int a = rs_angle(A, k + 1);
                 const unsigned ep = A->epoch0 + (unsigned)it * (unsigned)steps + (unsigned)k + 2u;
                 const int nr = f_nr, rpt = f_rpt, rpt2 = f_rpt2, wpr = f_wpr, cpw = f_cpw, jr0 = f_jr0, sub = f_sub;
-                const uint32_t dw0 = f_dw0, dw1 = f_dw1, dw2 = f_dw2, dw3 = f_dw3;
                 const rs_u2 ids0 = f_ids0;
                 const float rs0 = f_rs0, bv0 = f_bv0;
                 c_jbase = f_jbase; c_nr = nr;
-                c_dwv = (int)(((wave < 4 ? dw0 : wave < 8 ? dw1 : wave < 12 ? dw2 : dw3) >> ((wave & 3) * 8)) & 255u);
+                c_dwv = (int)f_dwv;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) rr[s] = 0.f;
-                const uint4 *cp = A->fpc + (((size_t)a * A->ntiles + tile) * RS_WAVES + wave) * 64;
+                const uint4 *cp = A->cell + (((size_t)a * A->ntiles + tile) * RS_WAVES + wave) * 64;
                 asm volatile("s_mov_b32 s33, m0\n"
                              RS_LD(0x000)
                              RS_WAIT
@@ -339,22 +351,23 @@ void k_sart_resident(const RsArgs unused_by_name)
                 for (int s = 0; s < 16; ++s) rs_pbuf[wave][s][lane] = rr[s];
                 __syncthreads();
                 rs_u64 *pb = A->pb + ((size_t)grp * A->ntiles + tile) * RS_MAXWIN * 64 + lane;
-                for (int i = wave; i < nr; i += RS_WAVES) {
-                    // (sixteen independent LDS reads, then the additions in wave order: as a chain of "if in the window, read and add" every
-                    // read waited for the one before -- 1.5 to 2.5 us between the last wave's projection and the published sums)
-                    float v[RS_WAVES];
-                    bool in[RS_WAVES];
+                // the tile's sum of window ray i = the block sums its list names (bytes wave << 4 | slot = row of rs_pbuf), in wave order;
+                // the list is padded to eight with a row that is always zero.  (The first form asked all sixteen waves "is ray i in
+                // your window": 350 instructions per wave -- 2.6 us between the last projection and the last published sum.)
 #pragma unroll
-                    for (int w = 0; w < RS_WAVES; ++w) {
-                        const uint32_t dq = w < 4 ? dw0 : w < 8 ? dw1 : w < 12 ? dw2 : dw3;
-                        const int s = i - (int)((dq >> ((w & 3) * 8)) & 255u);
-                        in[w] = (unsigned)s < (unsigned)RS_USABLE;
-                        v[w] = rs_pbuf[w][in[w] ? s : 0][lane];
+                for (int r3 = 0; r3 < 3; ++r3) {
+                    const int i = wave + 16 * r3;
+                    if (i < nr) {
+                        const rs_u2 e = r3 == 0 ? f_ts0 : r3 == 1 ? f_ts1 : f_ts2;
+                        const float *pr = &rs_pbuf[0][0][0] + lane;
+                        float v[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = pr[(((c < 4 ? e.x : e.y) >> ((c & 3) * 8)) & 255u) * 64];
+                        float acc = v[0];
+#pragma unroll
+                        for (int c = 1; c < 8; ++c) acc += v[c];
+                        rs_gst(pb + (size_t)i * 64, acc, ep);
                     }
-                    float acc = 0.f;
-#pragma unroll
-                    for (int w = 0; w < RS_WAVES; ++w) acc = in[w] ? acc + v[w] : acc;
-                    rs_gst(pb + (size_t)i * 64, acc, ep);
                 }
                 RS_STAMP(4)
                 RS_TL(4)
@@ -455,7 +468,11 @@ void k_sart_resident(const RsArgs unused_by_name)
         }
     }
 #ifdef RS_PROF
-    if (threadIdx.x == 0) { RsArgsP A = rs_args(); for (int q = 0; q < 8; ++q) A->prof[blockIdx.x * 8 + q] = tacc[q]; }
+    if (threadIdx.x == 0) {
+        RsArgsP A = rs_args();
+        for (int q = 0; q < 8; ++q) A->prof[blockIdx.x * 8 + q] = tacc[q];
+        if (blockIdx.x == 0) { A->prof[2048 + 126] = (long long)__builtin_amdgcn_s_memtime() - clk0; A->prof[2048 + 127] = (long long)__builtin_amdgcn_s_memrealtime() - rt0; }
+    }
 #endif
 }
 #undef RS_K
@@ -474,6 +491,7 @@ void k_sart_resident(const RsArgs unused_by_name)
 #undef RS_WAIT
 #undef RS_BATCH
 #undef RS_FP1
+#undef RS_IDX
 #undef RS_BP1
 #undef RS_LD
 

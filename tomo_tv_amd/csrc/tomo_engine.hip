@@ -223,7 +223,8 @@ struct tomo_engine {
     bool rs_ok = false;
     int rs_ntiles = 0, rs_tiles = 0, rs_rpt = 0, rs_groups = 0, rs_cus = 0;
     RsHdrD *d_rs_hdr = nullptr;
-    uint4 *d_rs_fpc = nullptr, *d_rs_bpc = nullptr;
+    uint4 *d_rs_cell = nullptr;
+    uint2 *d_rs_ts = nullptr;
     uint16_t *d_rs_rl = nullptr;
     rs_u64 *rs_pb = nullptr, *rs_rb = nullptr;     // granules {value, tag}: tile sums, residual rows
     size_t rs_pb_bytes = 0, rs_rb_bytes = 0;
@@ -1125,7 +1126,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
         lap("build_sart_tiles + upload");
         {   // tables of the volume-resident sweep (resident.cpp); TOMO_SART_RESIDENT = 0 leaves them out
             static_assert(Resident::T == RS_T && Resident::WAVES == RS_WAVES && Resident::MAXWIN == RS_MAXWIN && Resident::RL == RS_RL && Resident::USABLE == RS_USABLE &&
-                          sizeof(Resident::Hdr) == sizeof(RsHdrD), "k_sart_resident geometry (resident.h)");
+                          Resident::TSN == 8 && Resident::SINK == 14 && sizeof(Resident::Hdr) == sizeof(RsHdrD), "k_sart_resident geometry (resident.h)");
             bool want = e->n % 8 == 0;
             if (const char *env = std::getenv("TOMO_SART_RESIDENT")) want = want && std::atoi(env) != 0;
             e->rs_ok = false;
@@ -1141,14 +1142,14 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
                     e->rs_pb_bytes = (size_t)e->rs_groups * R.ntiles * RS_MAXWIN * 64 * sizeof(rs_u64);
                     e->rs_rb_bytes = (size_t)e->rs_groups * e->np * e->n * 64 * sizeof(rs_u64);
                     if ((rc = dev_alloc((void **)&e->d_rs_hdr, R.hdr.size() * sizeof(RsHdrD), false, e->stream))) return rc;
-                    if ((rc = dev_alloc((void **)&e->d_rs_fpc, R.fpc.size() * 4, false, e->stream))) return rc;
-                    if ((rc = dev_alloc((void **)&e->d_rs_bpc, R.bpc.size() * 4, false, e->stream))) return rc;
+                    if ((rc = dev_alloc((void **)&e->d_rs_cell, R.cell.size() * 4, false, e->stream))) return rc;
+                    if ((rc = dev_alloc((void **)&e->d_rs_ts, R.ts.size(), false, e->stream))) return rc;
                     if ((rc = dev_alloc((void **)&e->d_rs_rl, R.rl.size() * 2, false, e->stream))) return rc;
                     if ((rc = dev_alloc((void **)&e->rs_pb, e->rs_pb_bytes, true, e->stream))) return rc;     // tag 0 = never written
                     if ((rc = dev_alloc((void **)&e->rs_rb, e->rs_rb_bytes, true, e->stream))) return rc;
                     HIPCHK(hipMemcpy(e->d_rs_hdr, R.hdr.data(), R.hdr.size() * sizeof(RsHdrD), hipMemcpyHostToDevice));
-                    HIPCHK(hipMemcpy(e->d_rs_fpc, R.fpc.data(), R.fpc.size() * 4, hipMemcpyHostToDevice));
-                    HIPCHK(hipMemcpy(e->d_rs_bpc, R.bpc.data(), R.bpc.size() * 4, hipMemcpyHostToDevice));
+                    HIPCHK(hipMemcpy(e->d_rs_cell, R.cell.data(), R.cell.size() * 4, hipMemcpyHostToDevice));
+                    HIPCHK(hipMemcpy(e->d_rs_ts, R.ts.data(), R.ts.size(), hipMemcpyHostToDevice));
                     HIPCHK(hipMemcpy(e->d_rs_rl, R.rl.data(), R.rl.size() * 2, hipMemcpyHostToDevice));
                     if (!e->rs_abort) { HIPCHK(hipHostMalloc((void **)&e->rs_abort, sizeof(int), hipHostMallocMapped)); *e->rs_abort = 0; }
                     if ((rc = dev_alloc((void **)&e->d_rs_abort, sizeof(int), true, e->stream))) return rc;
@@ -1374,7 +1375,7 @@ static void free_geometry(tomo_engine *e)
                      (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_zero, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux,
                      (void **)&e->d_fl_items, (void **)&e->d_fl_orient, (void **)&e->d_fl_shift, (void **)&e->d_fl_ent, (void **)&e->d_fl_ptr, (void **)&e->d_fl_fent, (void **)&e->d_fl_fptr,
                      (void **)&e->d_fl_rsptr, (void **)&e->d_fl_rsidx, (void **)&e->d_fl_zero, (void **)&e->fl_part, (void **)&e->fl_part_aux,
-                     (void **)&e->d_rs_hdr, (void **)&e->d_rs_fpc, (void **)&e->d_rs_bpc, (void **)&e->d_rs_rl, (void **)&e->rs_pb, (void **)&e->rs_rb, (void **)&e->d_rs_angs, (void **)&e->d_rs_abort};
+                     (void **)&e->d_rs_hdr, (void **)&e->d_rs_cell, (void **)&e->d_rs_ts, (void **)&e->d_rs_rl, (void **)&e->rs_pb, (void **)&e->rs_rb, (void **)&e->d_rs_angs, (void **)&e->d_rs_abort};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     e->rs_ok = false; e->rs_angs_cap = 0; e->rs_angs_host.clear();
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
@@ -1705,7 +1706,7 @@ static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t st
         e->rs_epoch = 0;
     }
     RsArgs A{};
-    A.x = x; A.b = e->cur_b; A.rowsum = e->d_rowsum; A.hdr = e->d_rs_hdr; A.fpc = e->d_rs_fpc; A.bpc = e->d_rs_bpc; A.rl = e->d_rs_rl;
+    A.x = x; A.b = e->cur_b; A.rowsum = e->d_rowsum; A.hdr = e->d_rs_hdr; A.cell = e->d_rs_cell; A.ts = e->d_rs_ts; A.rl = e->d_rs_rl;
     A.pb = e->rs_pb; A.rb = e->rs_rb; A.angs = e->d_rs_angs; A.track = track; A.part = e->d_part; A.abort_word = e->d_rs_abort; A.abort_host = e->rs_abort;
     A.n = e->n; A.sx = e->sx; A.np = e->np; A.ntiles = e->rs_ntiles; A.tiles = e->rs_tiles; A.rpt = e->rs_rpt; A.steps = (int)steps; A.chunk0 = c0; A.nchunk = nc;
     A.epoch0 = e->rs_epoch; A.spin_limit = e->rs_spin_limit; A.beta = beta; A.prof = nullptr;

@@ -43,23 +43,23 @@ int main(int argc, char **argv)
     if (!R.ok) { printf("resident tables: %s\n", R.why.c_str()); return 1; }
     const int ntiles = R.ntiles;
     int ngrp = std::max(1, std::min(prop.multiProcessorCount / ntiles, nchunk));
-    printf("tiles %d, rpt %d, groups %d; tables %.1f MB\n", ntiles, R.rpt, ngrp, (R.fpc.size() + R.bpc.size()) * 4 / 1e6);
+    printf("tiles %d, rpt %d, groups %d; cell table %.1f MB\n", ntiles, R.rpt, ngrp, R.cell.size() * 4 / 1e6);
     const size_t npix = (size_t)N * N, nrows = (size_t)N * P;
     std::vector<float> x0(npix * sx), b(nrows * sx);
     for (size_t i = 0; i < x0.size(); ++i) x0[i] = ((int)(i % sx) < nx) ? hashf(i, 1) : 0.f;
     for (size_t r = 0; r < nrows; ++r)
         for (int s = 0; s < sx; ++s) b[r * sx + s] = s < nx ? t.rowsum[r] * (0.3f + 0.4f * hashf(r * sx + s, 2)) : 0.f;
-    float *dx, *db, *drs; RsHdrD *dh; uint4 *dfp, *dbp; uint16_t *drl; rs_u64 *dpb, *drb; int *dab; double *dpart;
+    float *dx, *db, *drs; RsHdrD *dh; uint4 *dcell; uint2 *dts; uint16_t *drl; rs_u64 *dpb, *drb; int *dab; double *dpart;
     CK(hipMalloc(&dx, x0.size() * 4)); CK(hipMalloc(&db, b.size() * 4)); CK(hipMalloc(&drs, nrows * 4));
-    CK(hipMalloc(&dh, R.hdr.size() * 32)); CK(hipMalloc(&dfp, R.fpc.size() * 4)); CK(hipMalloc(&dbp, R.bpc.size() * 4)); CK(hipMalloc(&drl, R.rl.size() * 2));
+    CK(hipMalloc(&dh, R.hdr.size() * 32)); CK(hipMalloc(&dcell, R.cell.size() * 4)); CK(hipMalloc(&dts, R.ts.size())); CK(hipMalloc(&drl, R.rl.size() * 2));
     const size_t pbn = (size_t)ngrp * ntiles * RS_MAXWIN * 64, rbn = (size_t)ngrp * P * N * 64;
     CK(hipMalloc(&dpb, pbn * 8)); CK(hipMalloc(&drb, rbn * 8)); CK(hipMalloc(&dab, 4)); CK(hipMalloc(&dpart, NPART * 8));
     CK(hipMemset(dpb, 0, pbn * 8)); CK(hipMemset(drb, 0, rbn * 8)); CK(hipMemset(dab, 0, 4)); CK(hipMemset(dpart, 0, NPART * 8));
     CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(drs, t.rowsum.data(), nrows * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dh, R.hdr.data(), R.hdr.size() * 32, hipMemcpyHostToDevice)); CK(hipMemcpy(dfp, R.fpc.data(), R.fpc.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dbp, R.bpc.data(), R.bpc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(drl, R.rl.data(), R.rl.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dh, R.hdr.data(), R.hdr.size() * 32, hipMemcpyHostToDevice)); CK(hipMemcpy(dcell, R.cell.data(), R.cell.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dts, R.ts.data(), R.ts.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(drl, R.rl.data(), R.rl.size() * 2, hipMemcpyHostToDevice));
     RsArgs A{};
-    A.x = dx; A.b = db; A.rowsum = drs; A.hdr = dh; A.fpc = dfp; A.bpc = dbp; A.rl = drl; A.pb = dpb; A.rb = drb; A.angs = nullptr; A.track = nullptr; A.part = dpart;
+    A.x = dx; A.b = db; A.rowsum = drs; A.hdr = dh; A.cell = dcell; A.ts = dts; A.rl = drl; A.pb = dpb; A.rb = drb; A.angs = nullptr; A.track = nullptr; A.part = dpart;
     A.abort_word = dab; A.n = N; A.sx = sx; A.np = P; A.ntiles = ntiles; A.tiles = R.tiles; A.rpt = R.rpt; A.steps = steps; A.chunk0 = 0; A.nchunk = nchunk;
     A.spin_limit = 1u << 20; A.beta = beta;
     std::vector<int> hang(steps); for (int k = 0; k < steps; ++k) hang[k] = k % P;
@@ -106,6 +106,8 @@ int main(int argc, char **argv)
             printf("TIMELINE step 40, workgroup 37, us after the first wave had its rows (per wave: rows in | BP starts | BP done | FP done | sums published | reducer polled | final done)\n");
             for (int w = 0; w < 16; ++w) { printf("  wave %2d:", w); for (int q = 0; q < 7; ++q) printf(" %6.2f", (tl[w * 8 + q] - t0) * 0.01); printf("\n"); }
         }
+        { std::vector<long long> ck(2); CK(hipMemcpy(ck.data(), dprof + 2048 + 126, 16, hipMemcpyDeviceToHost));
+          printf("CLOCK s_memtime %lld ticks over %.1f us = %.0f MHz\n", ck[0], ck[1] * 0.01, ck[0] / (ck[1] * 0.01)); }
         printf("PROF us per angle (wave 0, mean over workgroups): wait rows %.2f | barrier+rows->regs %.2f | BP %.2f | FP %.2f | block sums->LDS, barrier, tile sums, publish %.2f | reducer poll %.2f | barrier, final, publish %.2f | loop head %.2f\n",
                av[0], av[1], av[2], av[3], av[4], av[5], av[6], av[7]);
     }
@@ -135,21 +137,22 @@ int main(int argc, char **argv)
         auto fp = [&](int a) {
             for (int k = 0; k < ntiles; ++k) for (int w = 0; w < 16; ++w) {
                 float sl[16] = {0};
-                const uint32_t *c = R.fpc.data() + (((size_t)a * ntiles + k) * 16 + w) * 256;
+                const uint32_t *c = R.cell.data() + (((size_t)a * ntiles + k) * 16 + w) * 256;
                 for (int q = 0; q < 64; ++q) {
                     int ly, lz; Resident::pixel(w, q, ly, lz);
                     const int y = (k / R.tiles) * 32 + ly, z = (k % R.tiles) * 32 + lz;
                     const float xv = (y < N && z < N) ? x[(size_t)y * N + z] : 0.f;
                     sl[c[q * 4]] = fmaf(bitsf(c[q * 4 + 1]), xv, sl[c[q * 4]]);
-                    sl[c[q * 4 + 2]] = fmaf(bitsf(c[q * 4 + 3]), xv, sl[c[q * 4 + 2]]);
+                    sl[c[q * 4] + 1] = fmaf(bitsf(c[q * 4 + 2]), xv, sl[c[q * 4] + 1]);
                 }
                 std::memcpy(&pbuf[((size_t)k * 16 + w) * 16], sl, 64);
             }
             for (int k = 0; k < ntiles; ++k) {
                 const Resident::Hdr &h = R.hdr[(size_t)a * ntiles + k];
                 for (int i = 0; i < h.nrays; ++i) {
-                    float acc = 0.f;
-                    for (int w = 0; w < 16; ++w) { int sl = i - h.dw[w]; if ((unsigned)sl < 14u) acc += pbuf[((size_t)k * 16 + w) * 16 + sl]; }
+                    const uint8_t *e = R.ts.data() + (((size_t)a * ntiles + k) * 48 + i) * 8;
+                    float acc = pbuf[(size_t)k * 256 + e[0]];
+                    for (int c8 = 1; c8 < 8; ++c8) acc += pbuf[(size_t)k * 256 + e[c8]];
                     tsum[(size_t)k * 48 + i] = acc;
                 }
             }
@@ -172,13 +175,13 @@ int main(int argc, char **argv)
                 for (int w = 0; w < 16; ++w) {
                     float rr[16];
                     for (int sl = 0; sl < 16; ++sl) rr[sl] = (sl < 14 && h.dw[w] + sl < h.nrays) ? r[h.jbase + h.dw[w] + sl] : 0.f;
-                    const uint32_t *c = R.bpc.data() + (((size_t)a * ntiles + k) * 16 + w) * 256;
+                    const uint32_t *c = R.cell.data() + (((size_t)a * ntiles + k) * 16 + w) * 256;
                     for (int q = 0; q < 64; ++q) {
                         int ly, lz; Resident::pixel(w, q, ly, lz);
                         const int y = (k / R.tiles) * 32 + ly, z = (k % R.tiles) * 32 + lz;
                         if (y >= N || z >= N) continue;
-                        float tt = bitsf(c[q * 4 + 1]) * rr[c[q * 4] & 255];
-                        tt = fmaf(bitsf(c[q * 4 + 2]), rr[(c[q * 4] >> 8) & 255], tt);
+                        float tt = bitsf(c[q * 4 + 1]) * rr[c[q * 4]];
+                        tt = fmaf(bitsf(c[q * 4 + 2]), rr[c[q * 4] + 1], tt);
                         tt = tt * bitsf(c[q * 4 + 3]);
                         float v = fmaf(tt, beta, x[(size_t)y * N + z]);
                         x[(size_t)y * N + z] = v > 0.f ? v : 0.f;
