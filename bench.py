@@ -316,7 +316,7 @@ def attach_traffic(roofs, shape):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, separate runs, FETCH_SIZE x2), null if the
     profile is absent or was taken at another shape.  Measured outside this run by construction (the counters need the
     profiler); the file names the command."""
-    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         try:
             doc = json.load(open(path))
