@@ -482,7 +482,9 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
                                 flops=(2 * nnz if bp_list else 4.0 * n * n * P) * nx,
                                 lds_bytes=(4 * nnz if bp_list else 8.0 * n * n * P) * nx, busy_ms=pr["k_bp_tile"][2]),
         "back_projector": bp_kernel}
-    del t
+    del t, log          # (the kernel log holds the engine's handle: without this the 512^3 engine stays alive under the next configs)
+    import gc
+    gc.collect()
     # ---- ASD-POCS in the CPU reference's form (cpu/sim_ASD.py:64-96: ART sweep + tv + 10 TV-GD steps + 3 norms) at 512^3 x 90
     from tomo_tv_amd.engine import ctvlib
     from tomo_tv_amd.phantom import ellipsoids, tilt_angles
@@ -609,6 +611,20 @@ def sharded_run_record(t, comm, rank, world, nglobal, n, nproj, ang, args, round
     if args.no_validate:
         rec["parity"] = None
         return rec
+    # the check builds a second engine that holds the WHOLE volume on rank 0's device while the other ranks wait: skipped when
+    # that engine would not fit beside this rank's slab (~14 volumes + ~16 GB of tables at 1024^2 x 120) -- ADVICE r4
+    try:
+        import torch
+        free_b = float(torch.cuda.mem_get_info()[0])
+    except Exception:  # noqa: BLE001
+        free_b = None
+    need_b = 14.0 * 4.0 * nglobal * n * n + 16e9 * (n / 1024.0) ** 2 * (nproj / 120.0)
+    skip = free_b is not None and need_b > 0.8 * free_b
+    flag = t.be.tensor([1.0 if (skip and rank == 0) else 0.0])
+    comm.allreduce_sum(flag)
+    if float(flag.item()) > 0:
+        rec["parity"] = {"skipped": f"a whole-volume engine needs ~{need_b / 1e9:.0f} GB, {0 if free_b is None else free_b / 1e9:.0f} GB are free on rank 0's device"}
+        return rec
     # one iteration from zero, sharded
     b_full = t._sino(0, dst=0)                                    # the tilt series assembled on rank 0 (gather)
     t.restart_recon()
@@ -647,11 +663,28 @@ def _free_port():
 
 def visible_gpu_count():
     """GPUs this process could use, WITHOUT initialising one (the launcher must stay GPU-free: its children are the ranks)."""
+    # from the kernel driver's topology (a node with SIMDs is a GPU), cut by the visibility lists: no runtime is loaded for it
+    # (torch.cuda.device_count() can bring HIP / HSA up in this parent on ROCm -- ADVICE r4)
     try:
-        import torch
-        return int(torch.cuda.device_count())
-    except Exception:  # noqa: BLE001 -- no torch: let the ranks find out
-        return 1 << 30
+        import glob
+        n = 0
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            props = dict(ln.split(None, 1) for ln in open(f).read().splitlines() if " " in ln)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        if n == 0:
+            raise OSError("no GPU node in the kfd topology")
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v is not None:
+                n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+        return n
+    except Exception:  # noqa: BLE001 -- no kfd topology to read: ask torch in a short-lived child, never in this process
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+            return int(out.stdout.strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001 -- let the ranks find out
+            return 1 << 30
 
 
 def spawn_ranks(n, argv):

@@ -172,10 +172,38 @@ def tv_descent_stage(t, ref, start, dPOCS, label, seed=0, tol5=1e-6):
     ref.recon[:] = base
     print(f"{label}: tv_gd(5) {e5:.2e}; tv_gd(10): HIP vs fp64 {e_dev:.2e}, oracle vs fp64 {e_ref:.2e}, HIP vs oracle {e10:.2e}, "
           f"oracle vs itself from a +-1 ulp start {spread:.2e}")
-    assert e_dev <= max(TOL, 2 * e_ref), (label, e_dev, e_ref)
+    # one draw of a ratio whose upper tail over slabs is 2.6 (see the docstring): a loose guard here, the statistical bound is
+    # tv_ratio_over_slabs (geometric mean over four slabs <= 1.5)
+    assert e_dev <= max(TOL, 4 * e_ref), (label, e_dev, e_ref)
     assert close(dg_d, dg_host, 1e-6)
     assert abs(dg_d - dg_r) <= e10 * float(np.linalg.norm(ref.recon.astype(np.float64).ravel())) + TOL * dg_r
     return e_dev, e_ref
+
+
+def tv_ratio_over_slabs(start, dPOCS_of, label, firsts=(0, 128, 256, 384), width=64):
+    """The ten-step TV descent on FOUR disjoint 64-slice slabs of a 512^3 state: per slab the ratio "HIP's distance to the binary64
+    trajectory / the oracle's" (a draw from the chaotic amplification: 0.62 ... 2.59 over eight slabs, profiles/r04_tv_arith_variants.md),
+    and the bound on their GEOMETRIC MEAN (1.5; measured 1.22) that replaces round 4's bound of 2 on one draw.
+    Each slab is its own periodic volume on both sides (ctvlib.cpp:406-462)."""
+    n = start.shape[1]
+    ratios = []
+    for f in firsts:
+        sl = np.ascontiguousarray(start[f:f + width])
+        dev = tomoengine(width, n, np.deg2rad(tilt_angles(3)))
+        ref = oracle.ctvlib(width, n, 3)
+        ref.tv_eps = dev.tv_eps = 1e-6
+        dP = dPOCS_of(sl)
+        dev.set_volume(sl)
+        dev.tv_gd(10, dP)
+        ref.recon[:] = sl
+        ref.tv_gd(10, dP)
+        exact = ref.tv_gd_f64(10, dP, start=sl)
+        ratios.append(rel_l2(dev.get_volume(), exact) / max(rel_l2(ref.recon, exact), 1e-30))
+        del dev, ref
+    gm = float(np.exp(np.mean(np.log(ratios))))
+    print(f"{label}: HIP / oracle distance to binary64 after ten TV steps on slabs {firsts}: {[round(r, 2) for r in ratios]}, geometric mean {gm:.2f}")
+    assert gm <= 1.5, (label, ratios)
+    return ratios
 
 
 def test_config3_asd_pocs_and_fista_iterations_512cube_90(gpu):
@@ -207,7 +235,7 @@ def test_config3_asd_pocs_and_fista_iterations_512cube_90(gpu):
     base = ref.recon.copy()
     e_free = rel_l2(got, base)
     spread = []
-    for seed in (0, 1):
+    for seed in (0, 1, 2, 3):                                  # four one-ulp seeds, like the config-4 shard (two until round 4)
         ref.set_tilt_series(ulp_noise(b, seed))
         ref.recon[:] = 0
         oracle_asd_iteration(ref, 0.25, 0.0, 10, 0.2, True)
@@ -236,6 +264,8 @@ def test_config3_asd_pocs_and_fista_iterations_512cube_90(gpu):
     assert close(t.data_distance(), ref.data_distance(normalize=False))
     start = ref.recon.copy()
     tv_descent_stage(t, ref, start, 0.2 * dp, "config 3 TV descent after sweep 1")
+    # (a slab's share of the whole volume's step length: the descent moves every voxel by dPOCS / |g| of the volume it runs on)
+    tv_ratio_over_slabs(start, lambda sl: 0.2 * dp * float(np.sqrt(sl.shape[0] / float(nx))), "config 3 TV descent, four 64-slice slabs")
 
     # ---- iteration 2 from the oracle's state: the sweep and the descent on a dense, TV-processed volume ----
     start = ref.recon.copy()

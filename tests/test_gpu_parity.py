@@ -906,10 +906,9 @@ def test_wave_uniform_back_projector_is_bit_identical(gpu, N, P, Nx):
         t.SIRT(2)
         vols[form] = t.get_volume()
     assert np.array_equal(vols["wave"], vols["tile"])
-    if ((Nx + 63) // 64) % 2 == 0:      # (k_bp_all's one-float-per-lane build, what odd chunk counts run, rounds its epilogue differently: 1 ulp)
-        assert np.array_equal(vols["tile"], vols["pixel"])
-    else:
-        assert rel_l2(vols["tile"], vols["pixel"]) < 1e-6
+    # (round 5: also k_bp_all's one-float-per-lane build, what odd chunk counts run: its accumulation is two written-out FMAs now --
+    # the compiler had packed one of them into v_pk_mul_f32 + v_pk_add_f32, the 1-ulp exception this test carried in round 4)
+    assert np.array_equal(vols["tile"], vols["pixel"])
 
 
 @pytest.mark.parametrize("N,P,Nx,amax", [(40, 7, 70, 70), (96, 13, 128, 68), (33, 5, 256, 60), (16, 1, 64, 0), (64, 16, 64, 89), (128, 31, 64, 70),

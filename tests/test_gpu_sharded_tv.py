@@ -341,6 +341,56 @@ def test_sharded_chemicaltomo_on_real_kernels(gpu, world):
     assert rel_l2(got[1], want[1]) < 2e-5 and rel_l2(got[2], want[2]) < 1e-6
 
 
+def test_sharded_chemicaltomo_at_config5_image_size_vs_oracle(gpu):
+    """Config 5 at its OWN image size (N = 512, 70 tilts, 2 elements + HAADF), slab-sharded: two 8-slice slabs through the thread
+    ring against oracle/multimodal.py on the 16 slices (until now the sharded class met the oracle at N = 32
+    only).  One poisson_ml step, the rescalings (per-projection max over ranks), one sirt_data_fusion step and the 4-D FGP with its
+    halo exchange (multimodal.cpp:277-304,312-328,425-491; the reference's sharded class: multigpufusion.cpp:160-228)."""
+    import oracle
+    from oracle.multimodal import multimodal as ref_multimodal
+    from tomo_tv_amd.chemistry import create_weighted_summation_weights, multimodal
+    from tomo_tv_amd.phantom import tilt_angles
+    nx, n, p, nel, gamma = 16, 512, 70, 2, 1.6
+    oracle.set_num_threads(oracle.usable_cpus())
+    ang = tilt_angles(p)
+    gt = np.stack([ellipsoids(nx, n, seed=5 + e) * np.float32(0.5 + 0.3 * e) for e in range(nel)])
+    w = create_weighted_summation_weights([30, 8], 1.6, 3)
+    ref = ref_multimodal(nx, n, nel, ang, ang)
+    ref.w, ref.gamma = w.copy(), np.float32(gamma)
+    for e in range(nel):
+        ref.bChem[e] = ref._fp(ref.C, gt[e])
+    ref.recon = gt.copy()
+    ref.bh = ref._fp(ref.H, ref.model())
+    ref.bh /= ref.bh.max()
+    ref.bChem /= ref.bChem.max()
+    ref.recon = np.zeros_like(gt)
+    bh, bc = ref.bh.copy(), np.concatenate([ref.bChem[e] for e in range(nel)], axis=1)
+
+    def script(comm):
+        mm = multimodal(nx, n, nel, np.deg2rad(ang), np.deg2rad(ang), device=0, comm=comm)
+        mm.set_gamma(gamma); mm.set_weights(w)
+        mm.set_haadf_tilt_series(bh); mm.set_chem_tilt_series(bc)
+        mm.set_measureChem(True); mm.set_measureHaadf(True); mm.estimate_lipschitz()
+        out = [mm.poisson_ml(0.05)]
+        v0 = mm.get_volume()
+        mm.rescale_tomograms(10); mm.rescale_projections()
+        hp = mm.get_haadf_projections()
+        out += list(mm.sirt_data_fusion(10, 0.05, 5))
+        out.append(mm.tv_fgp_4D(5, 1e-4))
+        return np.array(out), v0, hp, mm.get_volume()
+    got = ThreadRing(2).run(script)[0]
+    c0 = ref.poisson_ml(0.05)
+    v0 = ref.recon.copy()
+    ref.rescale_tomograms(10); ref.rescale_projections()
+    h_ref, c_ref = ref.data_fusion(10, 0.05, 5)
+    tv_ref = ref.tv_fgp_4D(5, 1e-4)
+    want = np.array([c0, h_ref, c_ref, tv_ref])
+    assert np.allclose(got[0], want, rtol=2e-5), (got[0], want)
+    e0, eh, e1 = rel_l2(got[1], v0), rel_l2(got[2], ref.bh), rel_l2(got[3], ref.recon)
+    print(f"sharded config 5 at N = 512 (2 x 8 slices) vs oracle: poisson_ml {e0:.2e}, rescaled HAADF series {eh:.2e}, fusion + FGP step {e1:.2e}")
+    assert e0 < 1e-5 and eh < 1e-5 and e1 < 1e-5
+
+
 # ---- the facade a plain process gets when several GPUs are visible (tomo_tv_amd/inprocess.py) ------------------------------------
 def _drive(t, b):
     """A short run through the reference's driver calls (gpu/reconstructor.py:75-192) on any engine object."""

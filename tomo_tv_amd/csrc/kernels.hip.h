@@ -919,6 +919,11 @@ __device__ __forceinline__ V bp_axpby(float alpha, V x, float beta, V a)
     return __builtin_elementwise_fma((V)alpha, x, t);
 }
 
+template <typename V>
+__device__ __forceinline__ V bp_fma(float w, V a, V acc) { return __builtin_elementwise_fma((V)w, a, acc); }
+template <>
+__device__ __forceinline__ float bp_fma<float>(float w, float a, float acc) { return __builtin_fmaf(w, a, acc); }
+
 template <int VEC, int PPW>
 __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const CellD *__restrict__ cell,
                                                  const float *__restrict__ r, const float *__restrict__ colsum,
@@ -946,8 +951,11 @@ __global__ __launch_bounds__(256) void k_bp_all(float *__restrict__ x, const Cel
             CellD c = ci[p];
             V a0 = *reinterpret_cast<const V *>(ri + (size_t)c.r0 * sx);
             V a1 = *reinterpret_cast<const V *>(ri + (size_t)c.r1 * sx);
-            acc[q] += c.w0 * a0;
-            acc[q] += c.w1 * a1;
+            // two FMAs, written out (round 5): left to the compiler, the one-float-per-lane build packed the four pixels' products
+            // and sums of one of the two statements into v_pk_mul_f32 + v_pk_add_f32 (two roundings) where every other build and
+            // every other back-projector contracts to an FMA -- the 1-ulp difference of k_bp_all<1> that round 4 could not place
+            acc[q] = bp_fma(c.w0, a0, acc[q]);
+            acc[q] = bp_fma(c.w1, a1, acc[q]);
         }
     }
 #pragma unroll

@@ -1229,11 +1229,10 @@ static tomo_engine *new_engine(int nslice, int nray, int nproj, int device)
     e->vec = (e->sxc % 256 == 0) ? 4 : (e->sxc % 128 == 0) ? 2 : 1;
     // Row pitch = computed width.  A pixel's row of slices that is a multiple of 4 KB (1024 slices) makes two sweep chains striding over
     // alternate halves of the rows alias the memory channels (round 2: 51.3 against 40.6 ms per sweep at 1024 slices), so such a slab
-    // runs ONE chain (chain_count).  Round 4 tried 64 slices of padding on the pitch so that it can run two (TOMO_PITCH_PAD = slices;
-    // no kernel computes on the padding: chunk counts come from the computed width): 1024^3 x 120 ASD-POCS step 208.7 ms with two
-    // chains on the padded pitch against 206.6 ms with one chain on the plain one -- not kept as the default.
+    // runs ONE chain (chain_count).  Round 4 measured 64 slices of padding on the pitch so that it can run two: 1024^3 x 120 ASD-POCS
+    // step 208.7 ms against 206.6 ms with one chain on the plain pitch -- no gain; the environment hook of that experiment is gone
+    // (round 5, ADVICE r4: several launches size their work from the pitch, so a padded pitch was not safe to ship).
     e->sx = e->sxc;
-    if (const char *env = std::getenv("TOMO_PITCH_PAD")) { int v = std::atoi(env); if (v >= 0 && v % 4 == 0) e->sx = e->sxc + v; }
     e->npix = (int64_t)nray * nray;
     e->nrows = (int64_t)nray * nproj;
     return e;

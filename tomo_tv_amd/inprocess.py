@@ -43,13 +43,29 @@ class InProcWorld:
                 self._done.put((rank, None, e))
 
     def run(self, fn):
-        """``fn(rank)`` on every worker at once; the list of results; the first real exception is re-raised."""
+        """``fn(rank)`` on every worker at once; the list of results; the first real exception is re-raised.
+
+        Once one rank has failed the others get ``TOMO_INPROC_GRACE`` seconds (default 60) to come back: a rank that sits in a native
+        RCCL group or a stream synchronisation waiting for the failed one is not freed by the Python barrier's abort, and a facade
+        call must not hang on it forever.  If they do not return, the world is marked dead (every later call raises at once) and
+        the original error is raised with a note: the process should end (its worker threads are daemons)."""
+        if getattr(self, "dead", None):
+            raise RuntimeError(f"in-process multi-GPU world is dead: {self.dead}")
         for q in self._jobs:
             q.put(fn)
         out, err = [None] * self.world, [None] * self.world
-        for _ in range(self.world):
-            r, v, e = self._done.get()
+        got, failed = 0, False
+        grace = float(os.environ.get("TOMO_INPROC_GRACE", "60"))
+        while got < self.world:
+            try:
+                r, v, e = self._done.get(timeout=grace if failed else None)
+            except queue.Empty:
+                first = [x for x in err if x is not None][0]
+                self.dead = f"rank(s) {[i for i in range(self.world) if err[i] is None and out[i] is None]} did not return within {grace:.0f} s after: {first!r}"
+                raise RuntimeError(f"in-process multi-GPU call failed and left ranks waiting ({self.dead}); the world cannot be used any more") from first
             out[r], err[r] = v, e
+            failed = failed or e is not None
+            got += 1
         if any(e is not None for e in err):
             self.bar.reset()
             real = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)]
@@ -60,6 +76,9 @@ class InProcWorld:
         return InProcComm(self, rank)
 
     def close(self):
+        if getattr(self, "closed", False):
+            return
+        self.closed = True
         for q in self._jobs:
             q.put(None)
 
@@ -186,6 +205,8 @@ class InProcessMultiGPU:
         object.__setattr__(self, "_world", InProcWorld(len(devices)))
         self._world.shared_device = len(set(devices)) < len(devices)
         object.__setattr__(self, "_engines", self._world.run(lambda r: make(self._world.comm(r), devices[r])))
+        import weakref
+        weakref.finalize(self, InProcWorld.close, self._world)       # the worker threads end with the facade (and at interpreter exit)
 
     def __getattr__(self, name):
         engines = object.__getattribute__(self, "_engines")
