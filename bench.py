@@ -288,10 +288,10 @@ def resident_roof(cnt, tot_ms, busy_ms, nslice, n, nproj, tracked):
     # 7 vector operations per voxel and angle in the back projection (mul, fma, mul, fma, max: 7 flops), 2 FMAs in the forward one
     r = roof("k_sart_resident", cnt, tot_ms, alg, flops=11.0 * V * nproj, busy_ms=busy_ms)
     chunks = (nslice + 63) // 64
-    must = (16.0 if tracked else 8.0) * V + 4.0 * nslice * n * nproj + chunks * nproj * 2 * 16.0 * n * n
+    must = (16.0 if tracked else 8.0) * V + 4.0 * nslice * n * nproj + chunks * nproj * 16.0 * n * n
     avg = r["avg_ms"]
     r["resident"] = {"bytes_the_launch_must_move": must, "what": "slab in + out once (+ snapshot in + out when tracked) + measured rows + "
-                     "two 16-byte cell tables per pixel, angle and 64-slice chunk",
+                     "one 16-byte cell per pixel, angle and 64-slice chunk (read by both loops; the exchange's granules are traffic, not in here)",
                      "achieved_on_those_GBs": must / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
                      "us_per_angle_and_chunk": avg * 1e3 / nproj / chunks if avg > 0 else 0.0}
     r["frac_note"] = "algorithmic bytes of the streamed form (SURVEY 8d) over the launch time; > 1 = faster than any once-per-angle stream at HBM peak"
