@@ -298,6 +298,28 @@ def resident_roof(cnt, tot_ms, busy_ms, nslice, n, nproj, tracked):
     return r
 
 
+def facade_overhead(world):
+    """Host cost of the single-process multi-GPU facade (tomo_tv_amd/inprocess.py): every method call on ``InProcessMultiGPU`` is
+    forwarded to ``world`` persistent worker threads through a job queue each and one result queue.  Measured here on the host
+    alone (no GPU work): the wall time of an EMPTY forwarded call, and what the ~7 calls of an ASD-POCS step of TomoGPU.asd_pocs
+    (copy_recon, SART_tracked, data_distance_begin, tv_gd_tracked, its deferred read, the two option / state reads) add to a step."""
+    from tomo_tv_amd.inprocess import InProcWorld
+    w = InProcWorld(max(1, int(world)))
+    try:
+        for _ in range(50):
+            w.run(lambda r: None)
+        t0 = time.perf_counter()
+        n = 400
+        for _ in range(n):
+            w.run(lambda r: None)
+        us = (time.perf_counter() - t0) / n * 1e6
+    finally:
+        w.close()
+    calls = 7
+    return {"world": int(world), "empty_forwarded_call_us": us, "calls_per_asd_pocs_step": calls, "host_overhead_ms_per_step": us * calls * 1e-3,
+            "what": "InProcWorld.run(lambda r: None): queue hand-off to one host thread per device and back; host only"}
+
+
 def sart_chains(t):
     """Launch chains a SART sweep of this engine's slab runs as -- asked of the engine (tomo_sart_chain_count: the rule lives in
     tomo_engine.hip: chain_count, under the options in force), not restated here.  A sub-slab group answers per sub-slab engine."""
@@ -983,6 +1005,8 @@ def main():
                         "gain depends on the data (zero background of the synthetic phantom); --opt sart_skip_same=0 times the other form"},
             # N > 1 (and --force-dist): what the run itself can prove about its communication
             "comm": comm_record,
+            # the plain-process multi-GPU facade's host cost per step, at this run's GPU count and at 8 (host-only)
+            "inprocess_facade": [facade_overhead(max(2, world)), facade_overhead(8)],
             "roofline": dominant,
             "roofline_bp_angle": roofs.get(K_BP_NAME),
             "roofline_fp_angle": roofs.get(K_FP_NAME),

@@ -193,6 +193,8 @@ def tv_ratio_over_slabs(start, dPOCS_of, label, firsts=(0, 64, 128, 192, 256, 32
     ratios = []
     for f in firsts:
         sl = np.ascontiguousarray(start[f:f + width])
+        if not np.any(sl):                                   # (the phantom's last slices are empty: nothing to descend on)
+            continue
         dev = tomoengine(width, n, np.deg2rad(tilt_angles(3)))
         ref = oracle.ctvlib(width, n, 3)
         ref.tv_eps = dev.tv_eps = 1e-6

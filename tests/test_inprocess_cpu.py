@@ -114,3 +114,50 @@ def test_plain_process_never_builds_more_slabs_than_slices(monkeypatch):
     assert isinstance(chemistry.multigpufusion(2, 16, 2, ang, ang), FakeFacade) and seen["devs"] == [0, 1]
     monkeypatch.setattr(chemistry, "multimodal", FakeSingle)
     assert isinstance(chemistry.multigpufusion(1, 16, 2, ang, ang, devices=[3, 4]), FakeSingle) and seen["single"] == 3
+
+
+def test_driver_loops_run_on_the_rank_threads(monkeypatch):
+    """``TomoGPU.asd_pocs`` / ``.sart`` over the in-process facade: the loop runs ON the rank threads (one crossing of the facade per
+    driver call instead of ~7 per iteration: reconstructor.py ``_on_rank_threads``) and gives what the same driver gives over one
+    engine that holds everything (gpu/reconstructor.py:75-192 drives ``self.tomo`` the same way whatever class it is)."""
+    from tomo_tv_amd import reconstructor
+    from tomo_tv_amd.inprocess import InProcWorld
+    N, P, Nx = 16, 5, 7
+    ang = np.linspace(-65, 65, P)
+    x = ellipsoids(Nx, N, seed=23)
+    full = oracle.ctvlib(Nx, N, P)
+    full.load_A(oracle.parallel_ray(N, ang))
+    full.original_volume = x.copy()
+    full.create_projections()
+    series = full.b.reshape(Nx, P, N).transpose(0, 2, 1)            # (Nslice, Nray, Nangles), what TomoGPU takes
+
+    def driver(tomo):
+        rec = reconstructor.TomoGPU.__new__(reconstructor.TomoGPU)   # (the constructor insists on a HIP device)
+        rec.tomo, rec.verbose, rec.recon, rec.cost = tomo, False, None, None
+        rec.set_tilt_series(series)
+        return rec
+
+    t1 = InProcessMultiGPU(lambda comm, dev: ShardedEngine(Nx, N, ang * np.pi / 180, device=dev, comm=comm), [0])   # (one slab: == oracle, test above)
+    try:
+        one = driver(t1)
+        dd1, tv1 = one.asd_pocs(Niter=3)
+        v1 = t1.get_volume()
+        c1 = one.sart(Niter=2).copy()
+    finally:
+        t1.close()
+    crossings = []
+    real_run = InProcWorld.run
+    monkeypatch.setattr(InProcWorld, "run", lambda self, fn: (crossings.append(1), real_run(self, fn))[1])
+    t = InProcessMultiGPU(lambda comm, dev: ShardedEngine(Nx, N, ang * np.pi / 180, device=dev, comm=comm), [0, 0, 0])
+    try:
+        many = driver(t)
+        n0 = len(crossings)
+        dd3, tv3 = many.asd_pocs(Niter=3)
+        used = len(crossings) - n0
+        assert used <= 4, used                                        # initialize_algorithm's two calls + ONE for the whole loop
+        assert np.allclose(dd3, dd1, rtol=1e-5) and np.allclose(tv3, tv1, rtol=1e-5)
+        assert rel(t.get_volume(), v1) < 1e-5
+        c3 = many.sart(Niter=2)
+        assert np.allclose(c3, c1, rtol=1e-5) and many.cost is not None
+    finally:
+        t.close()

@@ -319,7 +319,7 @@ class multigpufusion(multimodal):
         if group is None and inprocess.process_group_world() <= 1:
             devs = list(devices) if devices is not None else inprocess.visible_devices()
             devs = devs[:max(1, min(len(devs), int(Nslice)))]        # never more slabs than slices; one device = the plain class
-            if len(devs) == 1:
+            if len(devs) == 1 and not inprocess.process_group_initialized():
                 return multimodal(Nslice, Nray, Nelements, haadfAngles, chemAngles, device=devs[0])
             return inprocess.InProcessMultiGPU(
                 lambda comm, dev: multimodal(Nslice, Nray, Nelements, haadfAngles, chemAngles, device=dev, comm=comm), devs)

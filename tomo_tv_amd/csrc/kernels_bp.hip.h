@@ -338,12 +338,16 @@ __device__ __forceinline__ int bl_lz(int w, int q) { return (w & 3) * 4 + (q & 3
 __global__ __launch_bounds__(BL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_bp_list(float *__restrict__ x, const uint4 *__restrict__ lent, const uint32_t *__restrict__ lptr, const uint32_t *__restrict__ win,
                const float *__restrict__ r, const float *__restrict__ colsum, float alpha, float beta, int clamp,
-               int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2)
+               int nproj, int n, int sx, int tiles_z, int ntiles, int nchunk2, int band)
 {
     typedef VecOf<4>::T V;
     extern __shared__ V bl_lds[];
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-    const int tile = (l / nchunk2) * 8 + xcd, c2 = l % nchunk2;
+    // band = 0: consecutive tiles go round the eight XCDs (rounds 4: a tile's neighbours sit on seven other L2s);
+    // band = 1 (round 5): an XCD owns a contiguous band of tiles, so the tiles that share residual rows -- a ray
+    // crosses neighbouring tiles -- find them in ONE L2
+    const int tpx = (ntiles + 7) >> 3;
+    const int tile = band ? xcd * tpx + l / nchunk2 : (l / nchunk2) * 8 + xcd, c2 = l % nchunk2;
     if (tile >= ntiles) return;
     const int ty = tile / tiles_z, tz = tile - ty * tiles_z;
     const int t = threadIdx.x, lane = t & 63;

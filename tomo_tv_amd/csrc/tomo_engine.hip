@@ -240,6 +240,7 @@ struct tomo_engine {
     int bp_tile = 1;                              // tile-stationary all-angle BP (k_bp_tile) when the geometry allows it
     int bp_list = 1;                              // ... in its entry-list form (k_bp_list) when the slab is whole pairs of 64-slice chunks
     bool attr_bp2 = false, bl_ok = false;
+    int bp_list_band = 0;                         // k_bp_list: 1 = an XCD owns a contiguous band of tiles (see the kernel)
     uint4 *d_bl_ent = nullptr;                    // k_bp_list: entry batches and the first batch of every (tile, stage, wave) list
     uint32_t *d_bl_ptr = nullptr, *d_bl_win = nullptr;
     int bl_tiles_z = 0, bl_ntiles = 0;
@@ -904,7 +905,7 @@ static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *
         ProfScope ps(e, TOMO_K_BP_TILE);
         dim3 grid((unsigned)(8 * ((e->bl_ntiles + 7) / 8) * nchunk2)), block(BL_THREADS);
         hipLaunchKernelGGL(k_bp_list, grid, block, BL_LDS_BYTES, e->stream, x, e->d_bl_ent, e->d_bl_ptr, e->d_bl_win, r, colsum, alpha, beta, clamp,
-                           e->np, e->n, e->sx, e->bl_tiles_z, e->bl_ntiles, nchunk2);
+                           e->np, e->n, e->sx, e->bl_tiles_z, e->bl_ntiles, nchunk2, e->bp_list_band);
         LAUNCHCHK();
         return TOMO_OK;
     }
@@ -3222,6 +3223,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_coop_spin") == 0) { e->sart_coop_spin = value < 0 ? -1 : value; return TOMO_OK; }
     if (std::strcmp(name, "bp_tile") == 0) { e->bp_tile = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "bp_list") == 0) { e->bp_list = value ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "bp_list_band") == 0) { e->bp_list_band = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "fp_list") == 0) { e->fp_list = value ? 1 : 0; return TOMO_OK; }
     // all-angle FP form: "fp_strip" = 1 (default) sheared strips; asking for "fp_tile" = 1 / 0 explicitly selects the tile-stationary /
     // the ray-driven form (and takes the strips out of the way until "fp_strip" = 1 is set again)

@@ -1083,7 +1083,7 @@ class multigpuengine(tomoengine):
             # never more slabs than slices (the reference's per-slice scheduler simply leaves the surplus devices idle,
             # multigpuengine.cpp:163-193); one device left = the plain single-GPU engine
             devs = devs[:max(1, min(len(devs), int(Nslice)))]
-            if len(devs) == 1:
+            if len(devs) == 1 and not inprocess.process_group_initialized():
                 return tomoengine(Nslice, Nray, pyAngles, device=devs[0])
             return inprocess.InProcessMultiGPU(lambda comm, dev: tomoengine(Nslice, Nray, pyAngles, device=dev, comm=comm), devs)
         return super().__new__(cls)

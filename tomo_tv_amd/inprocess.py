@@ -189,6 +189,15 @@ def process_group_world():
     return 1
 
 
+def process_group_initialized():
+    """True inside a ``torch.distributed`` job of any size (a one-rank job still wants the sharded class with its collectives)."""
+    try:
+        import torch.distributed as dist
+        return bool(dist.is_available() and dist.is_initialized())
+    except ImportError:
+        return False
+
+
 class InProcessMultiGPU:
     """K slab engines on K devices behind the method table of ONE engine.
 
