@@ -2535,6 +2535,9 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv, float *g_first 
                 const bool edge = e->nx % 64 != 0 || e->n % 8 != 0;      // lanes without a voxel exist: the predicated form
 #define TV4_NORM(WTV, EDGE, PTV) hipLaunchKernelGGL((k_tv_march4<8, WTV, TVM_NORM, EDGE>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, PTV, gp)
                 if (with_tv) { if (edge) TV4_NORM(true, true, e->d_part_tv); else TV4_NORM(true, false, e->d_part_tv); }
+#ifdef TV4_WHATIF_FUSED
+                else if (std::getenv("TOMO_WHATIF_SKIP_NORM")) { /* what-if: iteration i's update pass did this pass's arithmetic */ }
+#endif
                 else { if (edge) TV4_NORM(false, true, (double *)nullptr); else TV4_NORM(false, false, (double *)nullptr); }
 #undef TV4_NORM
             }
