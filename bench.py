@@ -299,10 +299,11 @@ def resident_roof(cnt, tot_ms, busy_ms, nslice, n, nproj, tracked):
 
 
 def facade_overhead(world):
-    """Host cost of the single-process multi-GPU facade (tomo_tv_amd/inprocess.py): every method call on ``InProcessMultiGPU`` is
+    """Host cost of the single-process multi-GPU facade (tomo_tv_amd/inprocess.py): a method call on ``InProcessMultiGPU`` is
     forwarded to ``world`` persistent worker threads through a job queue each and one result queue.  Measured here on the host
-    alone (no GPU work): the wall time of an EMPTY forwarded call, and what the ~7 calls of an ASD-POCS step of TomoGPU.asd_pocs
-    (copy_recon, SART_tracked, data_distance_begin, tv_gd_tracked, its deferred read, the two option / state reads) add to a step."""
+    alone (no GPU work): the wall time of an EMPTY forwarded call.  A loop written against the engine's methods pays it per call
+    (~7 per ASD-POCS iteration: copy_recon, SART_tracked, data_distance_begin, tv_gd_tracked, its deferred read, two state reads);
+    TomoGPU's driver loops run ON the rank threads (reconstructor._on_rank_threads) and pay it once per driver call."""
     from tomo_tv_amd.inprocess import InProcWorld
     w = InProcWorld(max(1, int(world)))
     try:
@@ -316,7 +317,9 @@ def facade_overhead(world):
     finally:
         w.close()
     calls = 7
-    return {"world": int(world), "empty_forwarded_call_us": us, "calls_per_asd_pocs_step": calls, "host_overhead_ms_per_step": us * calls * 1e-3,
+    return {"world": int(world), "empty_forwarded_call_us": us, "calls_per_asd_pocs_iteration_of_a_host_written_loop": calls,
+            "host_overhead_ms_per_iteration_of_a_host_written_loop": us * calls * 1e-3,
+            "crossings_per_TomoGPU_driver_call": 1,
             "what": "InProcWorld.run(lambda r: None): queue hand-off to one host thread per device and back; host only"}
 
 
@@ -630,6 +633,10 @@ def sharded_run_record(t, comm, rank, world, nglobal, n, nproj, ang, args, round
     rec["device_of_rank"] = [int(d) for d in t.get_gpu_ids()]
     if rounds0 is not None and rounds1 is not None:
         rec["rccl_rounds_per_step"] = (rounds1 - rounds0) / max(1, args.steps)
+    try:
+        rec["rccl_version"] = t.get_option("rccl_version")      # ncclGetVersion's code as the library read it (22707 = 2.27.7)
+    except Exception:  # noqa: BLE001 -- the numpy slab double of the launcher test
+        pass
     if args.no_validate:
         rec["parity"] = None
         return rec

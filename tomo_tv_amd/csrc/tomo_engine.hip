@@ -2950,6 +2950,7 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    int version = 0;            // ncclGetVersion's code: major * 10000 + minor * 100 + patch (2.9 and later)
 };
 static RcclApi g_rccl;
 static std::mutex g_rccl_mu;
@@ -2969,6 +2970,10 @@ static int rccl_load()
     RCCL_SYM(AllReduce, "ncclAllReduce"); RCCL_SYM(Send, "ncclSend"); RCCL_SYM(Recv, "ncclRecv");
     RCCL_SYM(GroupStart, "ncclGroupStart"); RCCL_SYM(GroupEnd, "ncclGroupEnd"); RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
+    // a round here is ONE group of an all-reduce with point-to-point sends / receives: grouped ncclSend / ncclRecv exist since 2.7
+    // (codes below 10000 are the old major * 1000 + minor * 100 scheme, i.e. older than 2.9; built and verified against 2.27.7, ROCm 7.2.0)
+    if (auto getv = (ncclResult_t (*)(int *))dlsym(h, "ncclGetVersion")) { int v = 0; if (getv(&v) == ncclSuccess) g_rccl.version = v; }
+    if (g_rccl.version && g_rccl.version < 2700) return fail(TOMO_ERR_STATE, "librccl is older than 2.7 (no grouped send / receive): version code " + std::to_string(g_rccl.version));
     g_rccl.lib = h;
     return TOMO_OK;
 }
@@ -3198,6 +3203,7 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "sart_resident") == 0) { *value = e->sart_resident; return TOMO_OK; }
     if (std::strcmp(name, "sart_resident_ready") == 0) { *value = e->rs_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_resident_active") == 0) { *value = (e->rs_ok && e->sart_resident != 0) ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "rccl_version") == 0) { *value = g_rccl.version; return TOMO_OK; }     // 0 until a communicator has been opened
     if (std::strcmp(name, "comm_rounds") == 0) { *value = (int)std::min<int64_t>(e->comm_rounds, 0x7FFFFFFF); return TOMO_OK; }
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
 }
