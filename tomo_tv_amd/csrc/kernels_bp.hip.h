@@ -326,6 +326,9 @@ __device__ __forceinline__ int bl_lz(int w, int q) { return (w & 3) * 4 + (q & 3
 #define BL_FMAS(SB)                                                                                       \
     BL_WFMA(SB, 0, 7) BL_WFMA(SB, 1, 6) BL_WFMA(SB, 2, 5) BL_WFMA(SB, 3, 4) BL_WFMA(SB, 4, 3) BL_WFMA(SB, 5, 2) BL_WFMA(SB, 6, 1) BL_WFMA(SB, 7, 0) \
     "s_set_gpr_idx_off\n"
+// Register assumptions of the asm block below (v[32:127] and s[33], s[36:99] bound by NUMBER, amdgpu_waves_per_eu(4, 4)): written against and
+// verified on ROCm 7.2.0 (hipcc = AMD clang 20, gfx950).  A compiler that needs one of these registers for a kernel argument or a
+// live value fails to BUILD (constraint conflict) rather than miscompile; tests/test_gpu_parity.py holds the kernel bit-identical to k_bp_all.
 #define BL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define BL_CLOBBERS                                                                                       \
     BL_CLOB4(s, 68, 69, 70, 71), BL_CLOB4(s, 72, 73, 74, 75), BL_CLOB4(s, 76, 77, 78, 79), BL_CLOB4(s, 80, 81, 82, 83),      \

@@ -591,6 +591,8 @@ struct FlItemD { int pass, v0; uint32_t tile0, ntiles, lp0, work, pad0, pad1; };
     FL_FMA(SB, 0, 15) FL_FMA(SB, 1, 14) FL_FMA(SB, 2, 13) FL_FMA(SB, 3, 12) FL_FMA(SB, 4, 11) FL_FMA(SB, 5, 10) FL_FMA(SB, 6, 9) FL_FMA(SB, 7, 8) \
     FL_FMA(SB, 8, 7) FL_FMA(SB, 9, 6) FL_FMA(SB, 10, 5) FL_FMA(SB, 11, 4) FL_FMA(SB, 12, 3) FL_FMA(SB, 13, 2) FL_FMA(SB, 14, 1) FL_FMA(SB, 15, 0) \
     "s_set_gpr_idx_off\n"
+// (register assumptions as for BL_CLOBBERS, kernels_bp.hip.h: bound by number, verified on ROCm 7.2.0 / clang 20 / gfx950; the bit-identity
+// tests against k_fp_strip / k_fp_tile are the check for another toolchain)
 #define FL_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define FL_CLOBBERS                                                                                       \
     FL_CLOB4(s, 68, 69, 70, 71), FL_CLOB4(s, 72, 73, 74, 75), FL_CLOB4(s, 76, 77, 78, 79), FL_CLOB4(s, 80, 81, 82, 83),      \

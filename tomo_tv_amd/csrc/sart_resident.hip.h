@@ -130,6 +130,10 @@ __device__ __forceinline__ bool rs_give_up(unsigned &spins, unsigned spin_limit,
 #define RS_SWEEP(OP)                                                                                      \
     RS_BATCH(OP, 0) RS_LD(0x100) RS_WAIT RS_BATCH(OP, 1) RS_LD(0x200) RS_WAIT RS_BATCH(OP, 2) RS_LD(0x300) RS_WAIT RS_BATCH(OP, 3)
 #endif
+// Register assumptions of the asm blocks (x in v[64:127], rows / sums in v[32:47], v[48:59] scratch, s[33], s[36:99] cells; 128 VGPRs at
+// amdgpu_waves_per_eu(4, 4)): written against and verified on ROCm 7.2.0 (hipcc = AMD clang 20, gfx950).  Another toolchain: a register the
+// compiler needs elsewhere is a BUILD error (constraint conflict); tools/experiments/resident_probe.hip replays the kernel bit for bit against a
+// CPU loop in its order of operations, tests/test_gpu_sart_resident.py holds it to the streamed chain and the oracle.
 #define RS_CLOB4(P, A, B, C, D) #P #A, #P #B, #P #C, #P #D
 #define RS_CLOBBERS                                                                                       \
     RS_CLOB4(s, 36, 37, 38, 39), RS_CLOB4(s, 40, 41, 42, 43), RS_CLOB4(s, 44, 45, 46, 47), RS_CLOB4(s, 48, 49, 50, 51),      \
