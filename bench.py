@@ -323,6 +323,16 @@ def facade_overhead(world):
             "what": "InProcWorld.run(lambda r: None): queue hand-off to one host thread per device and back; host only"}
 
 
+def engine_forms(t):
+    """Which kernel family the engine runs its all-angle forward projection, its all-angle back projection and its SART sweep as
+    (tomo_get_option "form_fp" / "form_bp" / "form_sart": the engine's own selection function answers, nothing is restated here)."""
+    from tomo_tv_amd import _lib
+    try:
+        return {"fp": _lib.FORM_FP[t.get_option("form_fp")], "bp": _lib.FORM_BP[t.get_option("form_bp")], "sart": _lib.FORM_SART[t.get_option("form_sart")]}
+    except Exception:  # noqa: BLE001 -- the numpy slab double of the launcher test
+        return None
+
+
 def sart_chains(t):
     """Launch chains a SART sweep of this engine's slab runs as -- asked of the engine (tomo_sart_chain_count: the rule lives in
     tomo_engine.hip: chain_count, under the options in force), not restated here.  A sub-slab group answers per sub-slab engine."""
@@ -999,7 +1009,8 @@ def main():
                                    + f", {nloc} slices on rank 0",
                        "volume": shape, "slices_per_gpu": nloc, "nray": n, "nproj": nproj,
                        "sharding": f"tilt-axis slabs x{world} ({args.scaling} scaling)",
-                       "sub_slab_engines_per_gpu": getattr(t, "sub_slabs", 1), "sart_chains_per_engine": chains},
+                       "sub_slab_engines_per_gpu": getattr(t, "sub_slabs", 1), "sart_chains_per_engine": chains,
+                       "forms": engine_forms(t)},
             # the data-INDEPENDENT figure (k_sart_tile storing every voxel; the headline skips stores of unchanged 256-byte pieces,
             # which the zero background of the synthetic phantom favours): null when the option was forced on the command line
             # (round 5, resident sweep: every voxel is loaded and stored once per sweep whatever the data -- the headline IS that figure)

@@ -311,7 +311,15 @@ int tomo_set_option(tomo_engine *e, const char *name, int value);
  * "bp_list_ready" (1: the entry lists of k_bp_list were built: every tile's ray windows fit and there are at most 192 angles),
  * "fp_strip_ready" (1: the sheared-strip tables were built at creation -- by the slab-size rule or TOMO_FP_STRIP=1 -- so
  * "fp_strip" = 1 takes effect), "fp_strip_slots" (accumulator slots per lane group the strip kernel runs with),
- * "comm_rounds" (RCCL rounds -- one ncclGroup or one lone collective each -- this engine has enqueued since creation) */
+ * "comm_rounds" (RCCL rounds -- one ncclGroup or one lone collective each -- this engine has enqueued since creation),
+ * "rccl_version" (ncclGetVersion's code of the librccl the library opened, e.g. 22707; 0 before the first communicator),
+ * "sart_resident", "sart_resident_ready" (the tables of the volume-resident SART sweep were built), "sart_resident_active",
+ * "form_fp" / "form_bp" / "form_sart": which kernel family the all-angle forward projection, the all-angle back projection and the
+ * SART sweep of THIS engine run as under the options in force (tomo_form; one function of the engine decides it for the launchers
+ * and for this query: tomo_engine.hip select_forms) */
+typedef enum { TOMO_FORM_FP_ROWS = 0, TOMO_FORM_FP_TILE = 1, TOMO_FORM_FP_STRIP = 2, TOMO_FORM_FP_LIST = 3,
+               TOMO_FORM_BP_ALL = 0, TOMO_FORM_BP_TILE = 1, TOMO_FORM_BP_LIST = 2,
+               TOMO_FORM_SART_ANGLE = 0, TOMO_FORM_SART_TILE = 1, TOMO_FORM_SART_RESIDENT = 2 } tomo_form;
 int tomo_get_option(tomo_engine *e, const char *name, int *value);
 /* ---- native communicator: the slab-sharded path over RCCL on the engine's own stream ---------------------------------------
  * Replaces, for a C / C++ host as for the Python one, the MPI calls of the reference's sharded CPU engine (mpi_ctvlib.cpp:400-422

@@ -107,3 +107,28 @@ def test_resident_form_is_refused_where_it_cannot_run(gpu):
     t.set_option("sart_resident", -1)
     t.SART(0.5, 1)                    # automatic: the streamed form
     assert np.isfinite(t.get_volume(VOL_RECON)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,n,nproj,want", [
+    (512, 512, 90, ("list", "list", "resident")),     # BASELINE config 3: whole 128-slice pieces, tables by the slab-size rule
+    (64, 512, 90, ("tile", "tile", "resident")),      # the slab of an 8-GPU rank
+    (64, 36, 7, ("tile", "tile", "tile")),            # N not a multiple of 8: the streamed chain
+])
+def test_the_engine_says_which_forms_it_runs(gpu, ns, n, nproj, want):
+    """tomo_get_option "form_fp" / "form_bp" / "form_sart" answer from the one selection function the launchers use
+    (tomo_engine.hip: select_forms); the options move the answer the way include/tomo_hip.h says."""
+    from tomo_tv_amd import _lib
+    t = tomoengine(ns, n, np.deg2rad(tilt_angles(nproj)))
+    got = (_lib.FORM_FP[t.get_option("form_fp")], _lib.FORM_BP[t.get_option("form_bp")], _lib.FORM_SART[t.get_option("form_sart")])
+    assert got == want
+    t.set_option("sart_resident", 0)
+    assert _lib.FORM_SART[t.get_option("form_sart")] == "tile"
+    t.set_option("sart_fused", 0)
+    assert _lib.FORM_SART[t.get_option("form_sart")] == "angle"
+    t.set_option("bp_list", 0)
+    assert _lib.FORM_BP[t.get_option("form_bp")] == "tile"
+    t.set_option("bp_tile", 0)
+    assert _lib.FORM_BP[t.get_option("form_bp")] == "all"
+    t.set_option("fp_tile", 0)                              # also takes the strips / lists out of the way (tomo_hip.h)
+    assert _lib.FORM_FP[t.get_option("form_fp")] == "rows"

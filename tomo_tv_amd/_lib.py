@@ -16,6 +16,10 @@ VOL_USER0 = 5
 S_DD, S_DIFF, S_TV, S_GNORM, S_RMSE, S_COST, S_L1, S_DIFF2, S_GNORM_ALL, S_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 16
 FIELD_FGP_D, FIELD_FGP_P1 = 100, 101
 K_BP_ANGLE, K_FP_ANGLE, K_TV_GRAD, K_TV_UPDATE, K_FGP_OBJ, K_FGP_GRAD, K_SART_FUSED, K_FP_TILE, K_BP_TILE, K_FP_REDUCE, K_SART_RESIDENT = range(11)
+# tomo_form (tomo_get_option "form_fp" / "form_bp" / "form_sart"): the kernel family an operation of an engine runs as
+FORM_FP = ("rows", "tile", "strip", "list")
+FORM_BP = ("all", "tile", "list")
+FORM_SART = ("angle", "tile", "resident")
 
 _i, _i64, _f, _p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 _pp = ctypes.POINTER(ctypes.c_void_p)

@@ -609,13 +609,45 @@ static int launch_fp_list(tomo_engine *e, const float *x, const float *b, float 
     return TOMO_OK;
 }
 
+// ---- which form runs ---------------------------------------------------------------------------------------------------------
+// ONE place decides which kernel family an operation of this engine uses, from what finish_create_impl could build for the geometry
+// (the *_ok flags), the slab's shape and the options in force; the launchers below ask it, and so can a host
+// (tomo_get_option "form_fp" / "form_bp" / "form_sart": the TOMO_FORM_* codes of include/tomo_hip.h).
+//   all-angle forward projection   LIST   the sheared strips as wave-uniform entry lists (k_fp_list): slab = whole 128-slice pieces,
+//                                         tables built (N >= 384 and >= 3000 strip workgroups, or TOMO_FP_LIST = 1), balance >= 0.8
+//                                  STRIP  k_fp_strip: the same geometry rule where the slab is no multiple of 128 slices or the lists
+//                                         could not be balanced
+//                                  TILE   k_fp_tile + k_fp_tile_reduce: small images and thin slabs (the default there), user matrices
+//                                         whose rays are no lines
+//                                  ROWS   ray-driven k_fp_rows / k_fp_rows_g: "fp_tile" = 0 only
+//   all-angle back projection      LIST   k_bp_list: whole 128-slice pieces, P <= 192;  TILE  k_bp_tile: other slabs, P <= FB_MAX_PROJ;
+//                                  ALL    voxel-driven k_bp_all: the fallback
+//   SART sweep                     RESIDENT  k_sart_resident: N a multiple of 8, one 32 x 32 tile per CU, ray windows fit (resident.cpp)
+//                                  TILE      k_sart_tile chain + k_resid_finish: N = 1024, fallbacks, "sart_resident" = 0
+//                                  ANGLE     one FP + one BP launch per angle: "sart_fused" = 0 or no tile tables
+struct Forms { int fp, bp, sart; };
+static Forms select_forms(const tomo_engine *e)
+{
+    Forms f;
+    f.fp = (e->fp_strip && e->fp_list && e->fl_ok && e->sxc % 128 == 0) ? TOMO_FORM_FP_LIST
+         : (e->fp_strip && e->fs_ok) ? TOMO_FORM_FP_STRIP
+         : e->fp_tile ? TOMO_FORM_FP_TILE : TOMO_FORM_FP_ROWS;
+    f.bp = (e->bp_tile && e->bl_ok && e->bp_list && e->sxc % 128 == 0) ? TOMO_FORM_BP_LIST
+         : (e->bp_tile && e->fb_ok) ? TOMO_FORM_BP_TILE : TOMO_FORM_BP_ALL;
+    f.sart = !e->sart_fused ? TOMO_FORM_SART_ANGLE
+           : (e->sart_resident != 0 && e->rs_ok) ? TOMO_FORM_SART_RESIDENT
+           : (e->sart_tile && e->st_ok) ? TOMO_FORM_SART_TILE : TOMO_FORM_SART_ANGLE;
+    return f;
+}
+
 // all-angle FP: sheared-strip form, else the tile-stationary form (k_fp_tile + k_fp_tile_reduce) unless switched off, else the ray-driven form
 template <int MODE>
 static int launch_fp_all(tomo_engine *e, const float *x, const float *b, float *out)
 {
-    if (e->fp_strip && e->fp_list && e->fl_ok && e->sxc % 128 == 0) return launch_fp_list<MODE>(e, x, b, out);
-    if (e->fp_strip && e->fs_ok) return launch_fp_strip<MODE>(e, x, b, out);
-    if (!e->fp_tile) return launch_fp<MODE>(e, x, 0, (int)e->nrows, b, out, e->fp_all_lpr);
+    const int form = select_forms(e).fp;
+    if (form == TOMO_FORM_FP_LIST) return launch_fp_list<MODE>(e, x, b, out);
+    if (form == TOMO_FORM_FP_STRIP) return launch_fp_strip<MODE>(e, x, b, out);
+    if (form == TOMO_FORM_FP_ROWS) return launch_fp<MODE>(e, x, 0, (int)e->nrows, b, out, e->fp_all_lpr);
     const int nchunk = e->sxc / 64;
     if (!e->ft_ncp) {
         size_t per_chunk = (size_t)std::max<uint32_t>(1, e->ft_nseg) * 64 * sizeof(float);
@@ -896,7 +928,8 @@ static int launch_sart_coop(tomo_engine *e, const Sub &sb, float *x, int prev, i
 
 static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *colsum, float alpha, float beta, int clamp)
 {
-    if (e->bp_tile && e->bl_ok && e->bp_list && e->sxc % 128 == 0) {     // entry lists: whole pairs of 64-slice chunks
+    const int form = select_forms(e).bp;
+    if (form == TOMO_FORM_BP_LIST) {     // entry lists: whole pairs of 64-slice chunks
         if (!e->attr_bp2) {
             HIPCHK(hipFuncSetAttribute((const void *)k_bp_list, hipFuncAttributeMaxDynamicSharedMemorySize, BL_LDS_BYTES));
             e->attr_bp2 = true;
@@ -909,7 +942,7 @@ static int launch_bp_all(tomo_engine *e, float *x, const float *r, const float *
         LAUNCHCHK();
         return TOMO_OK;
     }
-    if (e->bp_tile && e->fb_ok) {
+    if (form == TOMO_FORM_BP_TILE) {
         if (!e->attr_bp) {
             HIPCHK(hipFuncSetAttribute((const void *)k_bp_tile, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_BYTES + FB_MAX_PROJ * 4));
             e->attr_bp = true;
@@ -1771,12 +1804,13 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
     }
     // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
     if (steps <= 0) return TOMO_OK;
-    if (e->sart_resident != 0 && e->rs_ok) {      // the volume-resident sweep: one launch, the slab read and written once
+    const int form = select_forms(e).sart;
+    if (form == TOMO_FORM_SART_RESIDENT) {      // the volume-resident sweep: one launch, the slab read and written once
         if ((rc = launch_sart_resident(e, x, beta, steps, angle_at, track))) return rc;
         return finish();
     }
     if (e->sart_resident == 1) return fail(TOMO_ERR_STATE, "\"sart_resident\" = 1, but this engine has no tables of the resident sweep (N not a multiple of 8, more 32 x 32 tiles than CUs, or a matrix whose ray windows do not fit)");
-    if (e->sart_tile && e->st_ok) {   // tile form, in place
+    if (form == TOMO_FORM_SART_TILE) {   // tile form, in place
         // cooperative chain (k_sart_tile COOP): needs consecutive angles to differ (np >= 2) and whole 64-slice chunks
         const bool coop = e->sart_coop && e->np >= 2 && steps >= 2;
         if ((rc = sart_tile_prepare(e, coop))) return rc;
@@ -3203,6 +3237,9 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "sart_resident") == 0) { *value = e->sart_resident; return TOMO_OK; }
     if (std::strcmp(name, "sart_resident_ready") == 0) { *value = e->rs_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_resident_active") == 0) { *value = (e->rs_ok && e->sart_resident != 0) ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "form_fp") == 0) { *value = select_forms(e).fp; return TOMO_OK; }
+    if (std::strcmp(name, "form_bp") == 0) { *value = select_forms(e).bp; return TOMO_OK; }
+    if (std::strcmp(name, "form_sart") == 0) { *value = select_forms(e).sart; return TOMO_OK; }
     if (std::strcmp(name, "rccl_version") == 0) { *value = g_rccl.version; return TOMO_OK; }     // 0 until a communicator has been opened
     if (std::strcmp(name, "comm_rounds") == 0) { *value = (int)std::min<int64_t>(e->comm_rounds, 0x7FFFFFFF); return TOMO_OK; }
     return fail(TOMO_ERR_ARG, std::string("unknown option ") + name);
