@@ -132,3 +132,20 @@ def test_the_engine_says_which_forms_it_runs(gpu, ns, n, nproj, want):
     assert _lib.FORM_BP[t.get_option("form_bp")] == "all"
     t.set_option("fp_tile", 0)                              # also takes the strips / lists out of the way (tomo_hip.h)
     assert _lib.FORM_FP[t.get_option("form_fp")] == "rows"
+
+
+@pytest.mark.parametrize("ns,n,nproj,sweeps", [(64, 512, 90, 40), (256, 256, 60, 40), (130, 96, 12, 300)])
+def test_resident_sweep_is_bit_reproducible_over_many_launches(gpu, ns, n, nproj, sweeps):
+    """The exchange of the resident sweep is flag-free (the data is the flag) and every sum has a fixed order: two runs of the same
+    long sequence of sweeps -- full chip at 512^2, four chunks side by side at 256^2, ragged chunks at 96^2 -- must agree in every
+    bit.  A race (a stale granule accepted, a row read before its tag) would show up as a difference sooner or later."""
+    out = []
+    for _ in range(2):
+        t = _engine(ns, n, nproj, 1, noisy=True)
+        assert t.get_option("sart_resident_active") == 1
+        for _k in range(sweeps // 4):
+            t.SART(0.3, 4)                                # four sweeps per launch, many launches back to back
+        out.append(t.get_volume(VOL_RECON))
+        del t
+    assert np.isfinite(out[0]).all()
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
