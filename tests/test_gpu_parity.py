@@ -1061,6 +1061,44 @@ def test_tile_forward_projection_in_chunk_passes(gpu, ncp):
     assert abs(a.data_distance() - b.data_distance()) <= 1e-12 * a.data_distance()
 
 
+@pytest.mark.parametrize("form", ["strip", "list"])
+@pytest.mark.parametrize("Nx,ncp", [(384, 1), (384, 2), (384, 3), (640, 5), (640, 3), (320, 2)])
+def test_strip_and_list_forward_projection_in_chunk_passes(gpu, monkeypatch, form, Nx, ncp):
+    """The multi-pass path of the strip and the list projector (launch_fp_strip / launch_fp_list with a first chunk c0 > 0 and a
+    ragged last pass): the scratch cap splits the chunks only on large slabs (1024^3), so the tables are forced at a small image
+    (TOMO_FP_STRIP = 1 / TOMO_FP_LIST = 1) and the chunks per pass set by hand.  The list form works on PAIRS of chunks (an odd
+    chunks-per-pass is made even; a slab of an odd number of chunks -- 320 slices -- keeps the strips).  Every grouping gives the
+    single-pass sinogram bit for bit."""
+    from tomo_tv_amd import _lib
+    monkeypatch.setenv("TOMO_FP_STRIP", "1")
+    monkeypatch.setenv("TOMO_FP_LIST", "1" if form == "list" else "0")
+    N, P = 48, 7
+    ang = np.linspace(-70, 65, P) * np.pi / 180
+    x = ellipsoids(Nx, N, seed=6)
+    a, b = tomoengine(Nx, N, ang), tomoengine(Nx, N, ang)
+    want = "list" if (form == "list" and Nx % 128 == 0) else "strip"
+    assert _lib.FORM_FP[a.get_option("form_fp")] == want
+    b.set_option("fp_tile_chunks_per_pass", ncp)
+    for t in (a, b):
+        t.set_volume(x, VOL_ORIGINAL)
+        t.create_projections()
+    pa, pb = a.get_projections(), b.get_projections()
+    assert np.isfinite(pa).all() and pa.max() > 0
+    assert np.array_equal(pa, pb)
+    a.SIRT(2); b.SIRT(2)
+    assert np.array_equal(a.get_volume(), b.get_volume())
+    assert abs(a.data_distance() - b.data_distance()) <= 1e-12 * a.data_distance()
+    # ... and the tile form of the same slab agrees to rounding (another order of the partial sums)
+    monkeypatch.setenv("TOMO_FP_STRIP", "0")
+    monkeypatch.setenv("TOMO_FP_LIST", "0")
+    c = tomoengine(Nx, N, ang)
+    assert _lib.FORM_FP[c.get_option("form_fp")] == "tile"
+    c.set_volume(x, VOL_ORIGINAL)
+    c.create_projections()
+    pc = c.get_projections()
+    assert rel_l2(pc, pa) < 1e-6
+
+
 @pytest.mark.parametrize("N,Nx", [(40, 70), (64, 64), (33, 130), (100, 300), (7, 5), (3, 1)])
 def test_tv_gradient_kernels_are_bit_identical(gpu, N, Nx):
     """Register march without row rotation (k_tv_march4, default), register march (k_tv_grad_reg), LDS march (k_tv_grad_lds)
