@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-shape parity sweep of the volume-resident SART sweep on the GPU (not a pytest file): fuzz_resident.py SEED CASES.
+"""Random-shape parity sweep of the volume-resident SART sweep on the GPU (not a pytest file): fuzz_resident.py SEED CASES [NMAX].
 Image sides that are multiples of 8 up to 256 (1 ... 64 tiles: several chunk groups side by side down to the full chip), 1 ... 40
 angles over random ranges, ragged slice counts, sequential and random angle order, one to three sweeps per call, tracked or not --
 against the oracle (<= 2e-6) and against the streamed chain of the same engine (<= 1e-6)."""
@@ -17,9 +17,10 @@ def rel(a, b):
 
 
 rng0 = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2025)
+NMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 256          # largest image side (512: up to the full chip, one tile per CU)
 bad = 0
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-    N = 8 * int(rng0.integers(1, 33)); P = int(rng0.integers(1, 41)); Nx = int(rng0.integers(1, 300)); seed = int(rng0.integers(0, 10**6))
+    N = 8 * int(rng0.integers(1, NMAX // 8 + 1)); P = int(rng0.integers(1, 41)); Nx = int(rng0.integers(1, 300 if N <= 256 else 100)); seed = int(rng0.integers(0, 10**6))
     niter = int(rng0.integers(1, 4)); beta = float(rng0.uniform(0.1, 1.0)); order = "random" if rng0.random() < 0.4 else "sequential"
     amax = float(rng0.uniform(20, 89.9))
     rng = np.random.default_rng(seed)
