@@ -268,33 +268,75 @@ def roof(name, cnt, tot_ms, alg_bytes, flops=None, lds_bytes=None, busy_ms=None)
     return r
 
 
+def fracs_above_one(doc, path=""):
+    """Every key named ``frac`` / ``*_frac`` / ``frac_*`` of the record whose value exceeds 1 (none may)."""
+    bad = []
+    if isinstance(doc, dict):
+        for k, v in doc.items():
+            here = f"{path}.{k}" if path else str(k)
+            if isinstance(v, (int, float)) and not isinstance(v, bool) and (k == "frac" or k.endswith("_frac") or k.startswith("frac_")) and v > 1.0:
+                bad.append({"key": here, "value": v})
+            else:
+                bad += fracs_above_one(v, here)
+    elif isinstance(doc, list):
+        for i, v in enumerate(doc):
+            bad += fracs_above_one(v, f"{path}[{i}]")
+    return bad
+
+
 def resident_sweep(t):
-    """True when a SART sweep of this engine runs as ONE launch of the volume-resident kernel (k_sart_resident, round 5)."""
+    """True when a SART sweep of this engine runs as ONE launch of the volume-resident kernel (k_sart_resident) -- the engine's own
+    selection (tomo_engine.hip: select_forms) answers, under the options in force (not "sart_resident_active", which
+    ignores "sart_fused")."""
     try:
-        return bool(t.get_option("sart_resident_active"))
+        return t.get_option("form_sart") == 2
     except Exception:  # noqa: BLE001 -- the numpy slab double of the launcher test has no such option
         return False
 
 
 def resident_roof(cnt, tot_ms, busy_ms, nslice, n, nproj, tracked):
-    """Roofline record of k_sart_resident: one launch = one whole sweep of the slab.
-    ``achieved`` follows SURVEY.md 8(d): the algorithmic bytes of the work a launch does -- P fused single-angle steps at
-    8V + 12 Nx N each, the figure the streamed kernel k_sart_tile was priced with -- over the launch time.  The kernel does
-    not MOVE those bytes (the volume stays in registers; what it has to move is in ``resident``), so ``frac`` can exceed 1:
-    it says how far the sweep is past what any form that streams the slab once per angle can reach.  What bounds the kernel
-    is the per-angle exchange latency and the vector ALUs (``valu_frac``); see DESIGN.md and profiles/r05_resident_sweep.md."""
+    """Roofline record of k_sart_resident: one launch = one whole sweep of the slab, the volume resident in registers.
+
+    The kernel sits on NEITHER roof: a step (one angle of one 64-slice chunk) is two latency-bound loops and two hand-offs of ray
+    sums between the workgroups -- ``bound`` says "exchange latency" and ``frac`` is the LARGER of its two roof fractions, both of
+    them honest and small:
+      hbm   the bytes a launch MUST move -- slab in + out once (snapshot in + out too when tracked), the measured rows, one 16-byte
+            cell per pixel, angle and chunk -- over the launch time, against 8 TB/s.  Strictly algorithmic (16V + 4S, SURVEY 8d
+            without the tables) is given beside it.
+      valu  11 flops per voxel and angle (7 in the back projection: mul, fma, mul, fma, max; 2 FMAs forward) against the fp32 peak.
+    ``vs_streamed_form`` is what round 5 mistakenly reported as ``frac``: the bytes the STREAMED form would move for the same work
+    (P x (8V + 12 Nx N)) over this launch's time, relative to the HBM peak -- a speed-up over another algorithm form, not a roofline
+    fraction.  The phase timeline behind "exchange latency" is profiles/r06_resident_phases.txt (tools/resident_phases.sh)."""
     V = float(nslice) * n * n
-    alg = nproj * (8.0 * V + 12.0 * nslice * n)
-    # 7 vector operations per voxel and angle in the back projection (mul, fma, mul, fma, max: 7 flops), 2 FMAs in the forward one
-    r = roof("k_sart_resident", cnt, tot_ms, alg, flops=11.0 * V * nproj, busy_ms=busy_ms)
+    S = float(nslice) * n * nproj
     chunks = (nslice + 63) // 64
-    must = (16.0 if tracked else 8.0) * V + 4.0 * nslice * n * nproj + chunks * nproj * 16.0 * n * n
-    avg = r["avg_ms"]
-    r["resident"] = {"bytes_the_launch_must_move": must, "what": "slab in + out once (+ snapshot in + out when tracked) + measured rows + "
-                     "one 16-byte cell per pixel, angle and 64-slice chunk (read by both loops; the exchange's granules are traffic, not in here)",
-                     "achieved_on_those_GBs": must / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
-                     "us_per_angle_and_chunk": avg * 1e3 / nproj / chunks if avg > 0 else 0.0}
-    r["frac_note"] = "algorithmic bytes of the streamed form (SURVEY 8d) over the launch time; > 1 = faster than any once-per-angle stream at HBM peak"
+    avg_ms = tot_ms / cnt if cnt else 0.0
+    sec = avg_ms * 1e-3
+    slab = (16.0 if tracked else 8.0) * V + 4.0 * S
+    cells = chunks * nproj * 16.0 * n * n
+    must = slab + cells
+    flops = 11.0 * V * nproj
+    hbm_gbs = must / sec / 1e9 if sec > 0 else 0.0
+    valu_tf = flops / sec / 1e12 if sec > 0 else 0.0
+    hbm_frac, valu_frac = hbm_gbs / HBM_PEAK_GBS, valu_tf / VALU_PEAK_TFLOPS
+    streamed = nproj * (8.0 * V + 12.0 * nslice * n)
+    by_valu = valu_frac >= hbm_frac
+    r = {"kernel": "k_sart_resident", "bound": "exchange latency",
+         "achieved": valu_tf if by_valu else hbm_gbs, "peak": VALU_PEAK_TFLOPS if by_valu else HBM_PEAK_GBS,
+         "unit": "TFLOP/s" if by_valu else "GB/s", "frac": max(hbm_frac, valu_frac),
+         "frac_is": "the larger of the kernel's two roof fractions (%s); it is on neither roof: 'bound' names what binds" % ("fp32 VALU" if by_valu else "HBM on the bytes it must move"),
+         "traffic": None, "launches": cnt, "avg_ms": avg_ms, "total_ms": tot_ms, "busy_ms": busy_ms if busy_ms else tot_ms,
+         "launches_in_flight": 1.0,
+         "us_per_angle_and_chunk": avg_ms * 1e3 / nproj / chunks if avg_ms > 0 else 0.0,
+         "hbm": {"bytes_the_launch_must_move": must, "of_which_cells": cells, "achieved_GBs": hbm_gbs, "peak_GBs": HBM_PEAK_GBS, "frac": hbm_frac,
+                 "strictly_algorithmic_bytes": slab, "frac_on_strictly_algorithmic_bytes": slab / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+                 "what": "slab in + out once (+ snapshot in + out when tracked) + measured rows + one 16-byte cell per pixel, angle and "
+                         "64-slice chunk; the exchange's granules are traffic, not in here"},
+         "valu": {"flops_per_launch": flops, "achieved_TFLOPs": valu_tf, "peak_TFLOPs": VALU_PEAK_TFLOPS, "frac": valu_frac},
+         "vs_streamed_form": streamed / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+         "vs_streamed_form_is": "bytes the streamed form (k_sart_tile, SURVEY 8d: P x (8V + 12 Nx N)) would move for this work, over this launch's "
+                                "time, relative to the HBM peak: a speed-up over another algorithm form, NOT a roofline fraction",
+         "phase_profile": "profiles/r06_resident_phases.txt (tools/resident_phases.sh: RS_PROF build of the kernel)"}
     return r
 
 
@@ -321,6 +363,15 @@ def facade_overhead(world):
             "host_overhead_ms_per_iteration_of_a_host_written_loop": us * calls * 1e-3,
             "crossings_per_TomoGPU_driver_call": 1,
             "what": "InProcWorld.run(lambda r: None): queue hand-off to one host thread per device and back; host only"}
+
+
+def engine_facts(t):
+    """What creating this engine cost: device bytes of the tables it built (every kernel family's, eagerly) and the wall clock of
+    the creation (tomo_get_option "table_kib" / "create_ms"; VERDICT r5 'what is missing' 6)."""
+    try:
+        return {"table_MiB": t.get_option("table_kib") / 1024.0, "create_ms": t.get_option("create_ms")}
+    except Exception:  # noqa: BLE001 -- the numpy slab double of the launcher test
+        return None
 
 
 def engine_forms(t):
@@ -351,7 +402,7 @@ def attach_traffic(roofs, shape):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, separate runs, FETCH_SIZE x2), null if the
     profile is absent or was taken at another shape.  Measured outside this run by construction (the counters need the
     profiler); the file names the command."""
-    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         try:
             doc = json.load(open(path))
@@ -374,6 +425,18 @@ def attach_traffic(roofs, shape):
             if hit and r.get("traffic") is None:
                 r["traffic"] = hit[0]["hbm_bytes_per_launch"]
                 r["traffic_source"] = f"profiles/{fn} (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+                raw = hit[0].get("fetch_kib_raw")
+                if r["kernel"] == "k_sart_resident" and raw is not None:
+                    # The guide's x2 is calibrated for 16-byte-per-lane streaming reads only.  This kernel reads by scalar loads (cells),
+                    # 8-byte-per-lane polls (granules) and 4-byte-per-lane loads (the chunk): which factor applies to those widths is
+                    # measured by tools/micro/fetch_calib.hip (profiles/r06_fetch_calibration.md); both readings are given.
+                    wr = hit[0].get("write_kib", 0.0) * 1024.0
+                    r["traffic_fetch_raw_plus_write"] = raw * 1024.0 + wr
+                    r["traffic_fetch_x2_plus_write"] = 2.0 * raw * 1024.0 + wr
+                    must = r["hbm"]["bytes_the_launch_must_move"]
+                    r["traffic_over_must_move"] = {"fetch_x2": r["traffic_fetch_x2_plus_write"] / must, "fetch_raw": r["traffic_fetch_raw_plus_write"] / must}
+                    r["traffic_note"] = ("FETCH_SIZE x2 is the guide's correction for 16-B-per-lane streaming reads; this kernel's reads are scalar "
+                                         "loads, 8-B polls and 4-B lane loads -- see profiles/r06_fetch_calibration.md for the factor measured on those widths")
         return
 
 
@@ -436,6 +499,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     out = {}
     # ---- config 2: 256^3, 60 tilts, SART (beta 1, sequential) + data_distance per iteration
     t = _engine(256, 256, 60)
+    facts = {"256x256x256_x60": engine_facts(t)}
     t.initialize_SART("sequential")
     res2 = resident_sweep(t)
     log = KernelLog(t, {"k_sart_resident": K_SART_RESIDENT} if res2 else {"k_sart_tile<true>": K_SART_FUSED})
@@ -451,6 +515,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     del t
     # ---- config 3: 512^3, 90 tilts: FISTA (lambda 0.1, 10 FGP iterations, cost), then SIRT with the tile projectors' roofs
     t = _engine(512, 512, 90)
+    facts["512x512x512_x90"] = engine_facts(t)
     V, S, nx, n, P = 512.0 ** 3, 512.0 * 512 * 90, 512, 512, 90
     pytvlib.initialize_algorithm(t, "fista")
     st = {"t0": 1.0}
@@ -550,6 +615,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     del c
     # ---- one GPU's shard of config 4: 128 x 1024^2, 120 tilts, ASD-POCS
     t = _engine(128, 1024, 120)
+    facts["128x1024x1024_x120"] = engine_facts(t)
     t.initialize_SART("sequential")
     st4 = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
     asd_pocs_step(t, st4)
@@ -564,6 +630,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     del t
     # ---- config 4 WHOLE on one GPU: 1024^3, 120 tilts -- the N = 1 anchor of the config-4 scaling curve (multigpuengine.cpp:163-193)
     t = _engine(1024, 1024, 120)
+    facts["1024x1024x1024_x120"] = engine_facts(t)
     t.initialize_SART("sequential")
     st4 = {"beta": 0.25, "i": 0, "dPOCS": 0.0, "norm": float(t.Nslice_ * t.Nrow)}
     asd_pocs_step(t, st4)
@@ -611,7 +678,11 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     out["config5_chemicaltomo_fusion_512cube_x70tilts_1gpu"] = {
         "ms_per_step": ms, "iters_per_s": 1e3 / ms, "gvoxel_updates_per_s": 2 * 512.0 ** 3 / ms / 1e6,
         "form": "multimodal.sirt_data_fusion(10, 0.05, 5) + tv_fgp_4D(5, 1e-4), 2 elements + HAADF, whole volume on one GPU"}
+    facts["config5_chemical_engine_512x512x512_x70"] = engine_facts(mm.ce)
+    facts["config5_haadf_engine_512x512x512_x70"] = engine_facts(mm.he)
     del mm
+    # what the engines of these configs cost to create: device tables (all kernel families, built eagerly) and wall clock
+    out["engine_creation"] = facts
     return out
 
 
@@ -969,7 +1040,6 @@ def main():
                 roofs[name] = resident_roof(cnt, tot, busy, nloc // nsl, n, nproj, True)
                 roofs[name]["launches_per_sweep"] = nsl
                 roofs[name]["sample_stride"] = 1
-                roofs[name]["frac_of_measured_rmw_ceiling"] = roofs[name]["achieved"] / RMW_CEILING_GBS
                 continue
             per = nsub if name in (K_BP_NAME, K_FUSED_NAME, K_FP_NAME) else max(1, getattr(t, "sub_slabs", 1) if t is not None else 1)
             roofs[name] = roof(name, cnt, tot, alg_bytes[name] / per, busy_ms=busy)
@@ -1010,7 +1080,7 @@ def main():
                        "volume": shape, "slices_per_gpu": nloc, "nray": n, "nproj": nproj,
                        "sharding": f"tilt-axis slabs x{world} ({args.scaling} scaling)",
                        "sub_slab_engines_per_gpu": getattr(t, "sub_slabs", 1), "sart_chains_per_engine": chains,
-                       "forms": engine_forms(t)},
+                       "forms": engine_forms(t), "engine": engine_facts(t)},
             # the data-INDEPENDENT figure (k_sart_tile storing every voxel; the headline skips stores of unchanged 256-byte pieces,
             # which the zero background of the synthetic phantom favours): null when the option was forced on the command line
             # (round 5, resident sweep: every voxel is loaded and stored once per sweep whatever the data -- the headline IS that figure)
@@ -1037,8 +1107,13 @@ def main():
             del t, log
             t = log = None
             out["secondary"] = secondary_configs()
+            # north_star's ">= 60 % of the HBM roofline on the back-projection kernel": the single-angle voxel update that streams the
+            # slab (k_sart_tile<true> = BP(a_k) + FP(a_k+1) in one pass; the sweep form of N = 1024, where the volume cannot be resident)
+            shard4 = out["secondary"].get("config4_shard_asd_pocs_128x1024sq_x120tilts", {})
+            out["roofline_back_projection_update"] = dict(shard4.get("roofline") or {}, measured_on="config 4 shard: 128 x 1024^2 x 120, ASD-POCS step")
             if not args.no_cpu_baseline:
                 out["cpu_baseline"], out["cpu_baseline_configs"] = cpu_baselines(n, nproj)
+        out["frac_above_one"] = fracs_above_one(out)       # must be empty: a roofline fraction above 1 is not a roofline fraction
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:

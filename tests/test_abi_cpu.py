@@ -240,3 +240,12 @@ def test_cpu_harness_signatures_match_the_reference():
     assert sig(H.create_projections) == [("tomo", E), ("original_volume", E), ("SNR", 0)]
     assert sig(H.load_exp_tilt_series) == [("tomo", E), ("tiltSeries", E)]
     assert sig(H.parallelRay)[0][0] == "Nside"
+
+
+def test_table_builders_are_clean_under_asan_and_ubsan():
+    """sysmat.cpp and resident.cpp are index arithmetic end to end and ship inside libtomo_hip.so: the five table replays of
+    tests/native, built with -fsanitize=address,undefined (no recovery), on two geometries each (tests/native/Makefile: san)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "tests", "native"), "-s", "san"], capture_output=True, text=True)
+    assert r.returncode == 0 and "san: clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -149,3 +149,134 @@ def test_resident_sweep_is_bit_reproducible_over_many_launches(gpu, ns, n, nproj
         del t
     assert np.isfinite(out[0]).all()
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
+# ---- a sweep that cannot finish leaves the volume as it found it, and the streamed chain sweeps what is left (round 6) -----------------
+# Reference behaviour: tomofusion/gpu/utils/tomoengine.cpp:162-179 -- a sweep either happens or errors before touching `recon`.
+
+def _pin_lib():
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "libpin_cus.so")
+    if not os.path.exists(path):
+        pytest.fail("tests/native/libpin_cus.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (make -C tests/native)")
+    L = ctypes.CDLL(path)
+    L.pin_start.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]
+    L.pin_wait.argtypes = [ctypes.c_void_p]
+    L.pin_running.argtypes = [ctypes.c_void_p]
+    return L
+
+
+def _streamed(ns, n, nproj, tracked, sweeps=2, seed=11):
+    r = _engine(ns, n, nproj, 0, seed=seed, noisy=True)
+    if tracked:
+        r.copy_recon()
+        nrm = r.SART_tracked(0.7, sweeps)
+        return r.get_volume(VOL_RECON), nrm
+    r.SART(0.7, sweeps)
+    return r.get_volume(VOL_RECON), None
+
+
+@pytest.mark.parametrize("tracked", [False, True])
+@pytest.mark.parametrize("ns,n,nproj", [(64, 512, 12), (256, 256, 10), (200, 96, 9)])
+def test_a_sweep_that_gives_up_is_redone_by_the_streamed_chain(gpu, ns, n, nproj, tracked):
+    """"sart_resident_spin" = 0: every wait gives up at its first look, so no chunk commits; the call still returns the sweep
+    (the streamed chain's, to 1e-6; the tracked norm to 1e-5), counts the fallback, and the volume never holds garbage."""
+    want, want_nrm = _streamed(ns, n, nproj, tracked)
+    t = _engine(ns, n, nproj, 1, noisy=True)
+    t.set_option("sart_resident_spin", 0)
+    if tracked:
+        t.copy_recon()
+        nrm = t.SART_tracked(0.7, 2)
+        assert abs(nrm - want_nrm) <= 1e-5 * abs(want_nrm), (nrm, want_nrm)
+        assert t.matrix_2norm() == 0.0
+    else:
+        t.SART(0.7, 2)
+    assert t.get_option("sart_resident_fallbacks") == 1
+    assert t.get_option("sart_resident_fallback_chunks") == (ns + 63) // 64
+    got = t.get_volume(VOL_RECON)
+    assert _rel(got, want) <= 1e-6, _rel(got, want)
+    # with the waits back to normal the resident form runs again ("sart_resident" = 1 insists: no sitting out) and nothing more is counted
+    t.set_option("sart_resident_spin", -1)
+    t.SART(0.7, 1)
+    r = _engine(ns, n, nproj, 0, noisy=True)
+    r.SART(0.7, 3)
+    assert t.get_option("sart_resident_fallbacks") == 1
+    assert _rel(t.get_volume(VOL_RECON), r.get_volume(VOL_RECON)) <= 2e-6
+
+
+@pytest.mark.parametrize("tracked", [False, True])
+def test_one_chunk_that_does_not_commit_is_the_only_one_redone(gpu, tracked):
+    """Four chunks side by side (256^2: 64 tiles x 4 groups); tile 0 of chunk 2 refuses to commit ("sart_resident_test_fail"): the
+    other three chunks are stored by the resident kernel, chunk 2 by none of its workgroups -- the streamed chain sweeps exactly it."""
+    ns, n, nproj = 256, 256, 10
+    want, want_nrm = _streamed(ns, n, nproj, tracked)
+    t = _engine(ns, n, nproj, 1, noisy=True)
+    t.set_option("sart_resident_test_fail", 3)
+    if tracked:
+        t.copy_recon()
+        nrm = t.SART_tracked(0.7, 2)
+        assert abs(nrm - want_nrm) <= 1e-5 * abs(want_nrm), (nrm, want_nrm)
+    else:
+        t.SART(0.7, 2)
+    assert t.get_option("sart_resident_fallbacks") == 1 and t.get_option("sart_resident_fallback_chunks") == 1
+    got = t.get_volume(VOL_RECON)
+    assert _rel(got, want) <= 1e-6
+    # chunk 2 went through the streamed chain: bit-equal to the streamed engine there
+    assert np.array_equal(got[128:192].view(np.uint32), want[128:192].view(np.uint32))
+
+
+def test_automatic_mode_sits_out_after_a_failure_and_comes_back(gpu):
+    ns, n, nproj = 64, 128, 9
+    t = _engine(ns, n, nproj, -1, noisy=True)
+    assert t.get_option("form_sart") == 2
+    t.set_option("sart_resident_spin", 0)
+    t.SART(0.7, 1)
+    assert t.get_option("sart_resident_fallbacks") == 1 and t.get_option("sart_resident_skip") == 1
+    t.set_option("sart_resident_spin", -1)
+    t.SART(0.7, 1)                                   # sits this one out (streamed), no new failure
+    assert t.get_option("sart_resident_skip") == 0 and t.get_option("sart_resident_fallbacks") == 1
+    t.SART(0.7, 1)                                   # resident again
+    assert t.get_option("sart_resident_fallbacks") == 1
+    r = _engine(ns, n, nproj, 0, noisy=True)
+    r.SART(0.7, 3)
+    assert _rel(t.get_volume(VOL_RECON), r.get_volume(VOL_RECON)) <= 2e-6
+
+
+@pytest.mark.parametrize("tracked", [False, True])
+@pytest.mark.parametrize("spin", [400, -1])
+def test_sweep_beside_a_kernel_that_holds_part_of_the_chip(gpu, tracked, spin):
+    """A long-running kernel of the caller on another stream holds 64 CUs while a 512^2 sweep (256 workgroups, one per CU) starts.
+    With short waits the sweep gives up and the streamed chain does the work while the CUs are still held; with the default waits it
+    simply finishes once the CUs are free.  Either way the result is the sweep, and nothing hangs."""
+    import ctypes
+    import time
+    ns, n, nproj = 64, 512, 12
+    want, want_nrm = _streamed(ns, n, nproj, tracked)
+    t = _engine(ns, n, nproj, 1, noisy=True)
+    t.SART(0.7, 1)                                   # tables, buffers and the angle sequence are warm
+    t.restart_recon()
+    if tracked:
+        t.copy_recon()
+    t.set_option("sart_resident_spin", spin)
+    L = _pin_lib()
+    h = ctypes.c_void_p()
+    assert L.pin_start(0, 64, 250.0 if spin > 0 else 60.0, ctypes.byref(h)) == 0
+    time.sleep(0.01)
+    assert L.pin_running(h) == 1
+    t0 = time.time()
+    if tracked:
+        nrm = t.SART_tracked(0.7, 2)
+    else:
+        t.SART(0.7, 2)
+    dt = time.time() - t0
+    still = L.pin_running(h)
+    assert L.pin_wait(h) == 0
+    got = t.get_volume(VOL_RECON)
+    assert _rel(got, want) <= 1e-6, _rel(got, want)
+    if tracked:
+        assert abs(nrm - want_nrm) <= 1e-5 * abs(want_nrm)
+    if spin > 0:
+        assert t.get_option("sart_resident_fallbacks") >= 1, (dt, still)
+    else:
+        assert t.get_option("sart_resident_fallbacks") == 0 and dt >= 0.03, dt

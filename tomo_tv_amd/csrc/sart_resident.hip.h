@@ -21,8 +21,14 @@
 //   * buffers: tile sums single-buffered per (tile, window slot) -- a tile writes slot i for angle a+1 only after it has consumed
 //     the residual rows of angle a, which the reducers formed from its sums of angle a; residual rows per (ANGLE, ray) -- the tiles
 //     that trigger a rewrite (they sit on the ray of that angle) are exactly the tiles that consumed the old value.
-// Every spin is bounded: a workgroup that gives up sets *abort (so does every other one at its next look) and the sweep finishes
-// with garbage and a nonzero abort word, which the host turns into an error -- nothing hangs.
+// Every spin is bounded, and a sweep that cannot finish leaves the volume as it found it (round 6): a wave that gives up sets *abort
+// (every other workgroup stops at its next look) and marks its workgroup; after the last angle the workgroups of a chunk COMMIT --
+// a word per chunk {launch sequence, poison bit, count of clean workgroups}, joined by compare-and-swap: a clean workgroup adds one
+// and waits for the count to reach the number of tiles, one that is not clean (or gives up waiting: again a compare-and-swap on the
+// value it saw, so "full" and "poisoned" exclude each other) sets the poison bit.  Only a full, unpoisoned count lets the chunk's
+// workgroups store -- all of them or none -- and tile 0 then writes the launch sequence into the chunk's word of a pinned host array.
+// The host (launch_sart_resident, tomo_engine.hip) waits for the launch, reads that array and sweeps the chunks that did not commit
+// with the streamed chain (k_sart_tile): the sweep either happens or the volume is untouched, as in tomoengine.cpp:162-179.
 // The summation ORDER of a ray sum differs from k_sart_tile's (blocks of 8 x 8 inside tiles of 32 x 32 instead of segments of
 // 16 x 16 tiles): sweeps agree to ~1e-7 relative, not to the bit; the voxel update itself is bit-identical given the same rows.
 #pragma once
@@ -47,6 +53,10 @@ struct RsArgs {
     float *track;                   // nullptr, or the volume that receives a copy of the result (the sum of squared differences goes to part)
     double *part;
     int *abort_word, *abort_host;   // device word every spin looks at; pinned host word the host looks at (both set by the wave that gives up)
+    unsigned *commit;               // [64-slice chunk of the slab] seq << 12 | poison << 11 | workgroups that finished the chunk clean
+    int *done_host;                 // pinned [chunk]: the sequence number of the launch whose workgroups stored the chunk
+    unsigned seq;                   // this launch (1 .. 2^20 - 1)
+    int test_fail;                  // tests: chunk + 1 whose tile 0 declares itself not clean at the commit (0 = none)
     int n, sx, np, ntiles, tiles, rpt, steps, chunk0, nchunk;
     unsigned epoch0, spin_limit;
     float beta;
@@ -75,7 +85,7 @@ __device__ __forceinline__ int rs_abort_ld(const int *p)
 // one look at the give-up conditions every 32 polls (wave-uniform); true = stop spinning
 __device__ __forceinline__ bool rs_give_up(unsigned &spins, unsigned spin_limit, int *abort_word, int *abort_host, int lane, int code)
 {
-    if (((++spins) & 31u) != 0u) return false;
+    if (((++spins) & 31u) != 0u && spin_limit != 0u) return false;       // (a limit of 0: the first look that finds nothing gives up -- tests)
     if (spins > spin_limit) {
         if (lane == 0) {
             __hip_atomic_store((__attribute__((address_space(1))) int *)abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -84,6 +94,35 @@ __device__ __forceinline__ bool rs_give_up(unsigned &spins, unsigned spin_limit,
         return true;
     }
     return rs_abort_ld(abort_word) != 0;
+}
+
+// ---- all or nothing: the chunk's workgroups store only when every one of them finished clean (one lane per workgroup calls this) --------
+constexpr unsigned RS_POISON = 0x800u, RS_COUNT = 0x7FFu;
+__device__ __forceinline__ bool rs_commit(unsigned *w, unsigned seq, unsigned ntiles, bool clean, unsigned spin_limit, const int *abort_word)
+{
+    typedef __attribute__((address_space(1))) unsigned *gp;
+    unsigned seen = __hip_atomic_load((gp)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {      // join: +1 when clean, the poison bit otherwise (a word of an older launch counts as empty)
+        const unsigned cur = (seen >> 12) == seq ? seen : seq << 12;
+        const unsigned want = clean ? cur + 1u : cur | RS_POISON;
+        unsigned expected = seen;
+        if (__hip_atomic_compare_exchange_strong((gp)w, &expected, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { seen = want; break; }
+        seen = expected;
+    }
+    if (!clean) return false;
+    for (unsigned spins = 0;;) {
+        if (seen & RS_POISON) return false;
+        if ((seen & RS_COUNT) == ntiles) return true;
+        if (++spins > spin_limit || ((spins & 31u) == 0u && rs_abort_ld(abort_word) != 0)) {
+            // give up -- on the value last seen: if the count moved meanwhile (it may just have become full), look again
+            unsigned expected = seen;
+            if (__hip_atomic_compare_exchange_strong((gp)w, &expected, seen | RS_POISON, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            seen = expected;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        seen = __hip_atomic_load((gp)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- the two static loops over a wave's 64 pixels --------------------------------------------------------------------------------
@@ -206,6 +245,7 @@ void k_sart_resident(const RsArgs unused_by_name)
     __shared__ float rs_rbuf[RS_MAXWIN][64];             // the residual rows of the tile's window (12 KB)
     __shared__ float rs_sbuf[RS_WAVES][64];              // a reducer wave's share of a ray sum (4 KB)
     __shared__ float rs_dump[RS_WAVES][64];              // where the cell prefetches land (never read)
+    __shared__ int rs_dirty, rs_go, rs_store;                   // a wave of this workgroup left a spin without its data; the chunk's verdict
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v32f xlo, xhi;
@@ -222,6 +262,11 @@ void k_sart_resident(const RsArgs unused_by_name)
     }
     for (int it = 0; chunk < chunk_end; chunk += ngrp, ++it) {
         const uint32_t voff = (uint32_t)(chunk * 64 + lane) * 4u;
+        {   // a sweep that has given up touches no further chunk (the host redoes what did not commit)
+            if (threadIdx.x == 0) { rs_dirty = 0; rs_go = rs_abort_ld(rs_args()->abort_word) == 0 ? 1 : 0; }
+            __syncthreads();
+            if (rs_go == 0) break;
+        }
         {   // ---- the chunk comes in (a block outside the image holds zeros: its cells carry no weights)
             RsArgsP A = rs_args();
             rs_touch(A, tile, wave, lane, rs_angle(A, 0), rs_dump[wave]);
@@ -295,7 +340,7 @@ void k_sart_resident(const RsArgs unused_by_name)
                         if (i2 < nr) g2 = rs_gld(rrow + (size_t)i2 * 64);
                         bool ok = (i0 >= nr || (unsigned)(g0 >> 32) == ep) && (i1 >= nr || (unsigned)(g1 >> 32) == ep) && (i2 >= nr || (unsigned)(g2 >> 32) == ep);
                         if (__all(ok)) break;
-                        if (rs_give_up(spins, A->spin_limit, A->abort_word, A->abort_host, lane, 1)) break;
+                        if (rs_give_up(spins, A->spin_limit, A->abort_word, A->abort_host, lane, 1)) { rs_dirty = 1; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (i0 < nr) rs_rbuf[i0][lane] = __uint_as_float((uint32_t)g0);
@@ -396,7 +441,7 @@ void k_sart_resident(const RsArgs unused_by_name)
                                 bool ok = (unsigned)(g0 >> 32) == ep && (id1 == 0xFFFF || (unsigned)(g1 >> 32) == ep) &&
                                           (id2 == 0xFFFF || (unsigned)(g2 >> 32) == ep) && (id3 == 0xFFFF || (unsigned)(g3 >> 32) == ep);
                                 if (__all(ok)) break;
-                                if (rs_give_up(spins, A->spin_limit, A->abort_word, A->abort_host, lane, 2)) break;
+                                if (rs_give_up(spins, A->spin_limit, A->abort_word, A->abort_host, lane, 2)) { rs_dirty = 1; break; }
                                 __builtin_amdgcn_s_sleep(1);
                             }
                             acc += __uint_as_float((uint32_t)g0);
@@ -422,6 +467,19 @@ void k_sart_resident(const RsArgs unused_by_name)
                 RS_STAMP(6)
                 RS_TL(6)
             }
+        }
+        {   // ---- commit: every workgroup of the chunk stores, or none does
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                RsArgsP A = rs_args();
+                const bool clean = rs_dirty == 0 && rs_abort_ld(A->abort_word) == 0 && !(tile == 0 && A->test_fail == chunk + 1);
+                const bool ok = rs_commit(A->commit + chunk, A->seq, (unsigned)A->ntiles, clean, A->spin_limit, A->abort_word);
+                if (ok && tile == 0)
+                    __hip_atomic_store((__attribute__((address_space(1))) int *)(A->done_host + chunk), (int)A->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                rs_store = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (rs_store == 0) continue;       // (a sweep that gave up stops at the next chunk's first look)
         }
         {   // ---- the chunk goes back (and, tracked, into the snapshot volume with the squared step in part[])
             RsArgsP A = rs_args();

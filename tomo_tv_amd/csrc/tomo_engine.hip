@@ -52,11 +52,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(TOMO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));                 \
     } while (0)
 #define LAUNCHCHK() HIPCHK(hipGetLastError())
-#define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); if ((e)->geometry_released) return fail(TOMO_ERR_STATE, "engine geometry was released"); HIPCHK(hipSetDevice((e)->device)); RS_CHECK(e); } while (0)
-// a resident SART sweep whose workgroups could not all run at once gives up instead of hanging (sart_resident.hip.h): the volume it
-// swept is garbage, and the first call that looks (every entry point, and every read-back after its synchronisation) says so
-#define RS_CHECK(e) do { if ((e)->rs_abort && *(e)->rs_abort) return rs_gave_up(e); } while (0)
-
+#define NEED(e) do { if (!(e)) return fail(TOMO_ERR_ARG, "null engine"); if ((e)->geometry_released) return fail(TOMO_ERR_STATE, "engine geometry was released"); HIPCHK(hipSetDevice((e)->device)); } while (0)
 enum { PROF_MAX_KERNELS = 12, PROF_MAX_EVENTS = 1 << 19 };   // 262144 launches per kernel id between two reads
 
 struct ProfSlot {
@@ -232,6 +228,15 @@ struct tomo_engine {
     size_t rs_angs_cap = 0;
     std::vector<int> rs_angs_host;                 // (what d_rs_angs holds: an unchanged sequence is not uploaded again)
     int *rs_abort = nullptr, *d_rs_abort = nullptr; // pinned host word / device word a workgroup sets when a bounded spin gave up
+    // fail-safe (round 6): a chunk is stored by all of its workgroups or by none (rs_commit); d_rs_commit = the chunks' commit words,
+    // rs_done = pinned [chunk]: the sequence number of the launch that stored it.  Chunks that did not commit are swept by the streamed
+    // chain, and the resident form then sits out rs_skip sweeps (doubling up to 64 while the failures go on; "sart_resident" = 1 insists)
+    unsigned *d_rs_commit = nullptr;
+    int *rs_done = nullptr;
+    uint32_t rs_seq = 0;
+    size_t table_bytes = 0;                        // device bytes of the tables built at creation (everything but volumes, sinograms, halos)
+    double create_ms = 0.0;                        // wall clock of the creation (matrix, tables, uploads)
+    int rs_fallbacks = 0, rs_fallback_chunks = 0, rs_skip = 0, rs_backoff = 0, rs_last_code = 0, rs_test_fail = 0;
     uint32_t rs_epoch = 0;                         // tags handed out so far (a granule's tag is unique per sweep, chunk round and step)
     uint32_t rs_spin_limit = 1u << 21;
     int art_tile = 1;                              // chained ART sweep as fused tile steps (k_sart_tile ART) instead of k_fp_rows + k_bp_art per angle
@@ -307,19 +312,12 @@ struct tomo_engine {
 
 static inline double *gnorm_ptr(const tomo_engine *e) { return e->gnorm_override ? e->gnorm_override : e->d_scal + e->gnorm_slot; }
 
-static int rs_gave_up(tomo_engine *e)
-{
-    const int code = *e->rs_abort;
-    *e->rs_abort = 0;
-    if (e->d_rs_abort) (void)hipMemsetAsync(e->d_rs_abort, 0, sizeof(int), e->stream);
-    return fail(TOMO_ERR_STATE, std::string("the resident SART sweep gave up waiting for ") + (code == 1 ? "residual rows" : "tile sums") +
-                " (its workgroups were not all resident at once: another kernel held the device?); the swept volume is invalid -- "
-                "set the option \"sart_resident\" to 0 to use the streamed sweep");
-}
-
+// (bytes handed out while an engine is being created are counted for it: tomo_get_option "table_kib")
+static thread_local size_t *g_alloc_meter = nullptr;
 static int dev_alloc(void **p, size_t bytes, bool zero, hipStream_t st)
 {
     HIPCHK(hipMalloc(p, bytes ? bytes : 4));
+    if (g_alloc_meter) *g_alloc_meter += bytes;
     if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes ? bytes : 4, st));
     return TOMO_OK;
 }
@@ -981,6 +979,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_last = now();
     auto lap = [&](const char *what) { if (timing) { double x = now(); std::fprintf(stderr, "tomo_create: %-32s %.3f s\n", what, x - t_last); t_last = x; } };
+    struct Meter { Meter(size_t *p) { g_alloc_meter = p; } ~Meter() { g_alloc_meter = nullptr; } } meter(&e->table_bytes);
     sort_rows(m);
     lap("sort_rows");
     if (!build_tables(m, e->n, e->np, t, err)) return fail(TOMO_ERR_GEOMETRY, err);
@@ -1170,9 +1169,13 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
                 e->rs_cus = prop.multiProcessorCount;
                 Resident R;
                 build_sart_resident(e->n, e->np, t, e->rs_cus, R);
-                if (R.ok) {
+                // every workgroup of a launch must be on the chip at once: the runtime's own count of workgroups per CU for this kernel
+                // (registers, LDS) has to cover the launch; and the chunks of a sweep that could not finish go to the tile chain
+                int per_cu = 0;
+                if (R.ok) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_sart_resident, RS_THREADS, 0));
+                if (R.ok && e->st_ok && (int64_t)per_cu * e->rs_cus >= R.ntiles) {
                     e->rs_ntiles = R.ntiles; e->rs_tiles = R.tiles; e->rs_rpt = R.rpt;
-                    e->rs_groups = std::max(1, std::min(e->rs_cus / R.ntiles, e->sxc / 64));
+                    e->rs_groups = std::max(1, std::min(per_cu * e->rs_cus / R.ntiles, e->sxc / 64));
                     e->rs_pb_bytes = (size_t)e->rs_groups * R.ntiles * RS_MAXWIN * 64 * sizeof(rs_u64);
                     e->rs_rb_bytes = (size_t)e->rs_groups * e->np * e->n * 64 * sizeof(rs_u64);
                     if ((rc = dev_alloc((void **)&e->d_rs_hdr, R.hdr.size() * sizeof(RsHdrD), false, e->stream))) return rc;
@@ -1187,7 +1190,10 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
                     HIPCHK(hipMemcpy(e->d_rs_rl, R.rl.data(), R.rl.size() * 2, hipMemcpyHostToDevice));
                     if (!e->rs_abort) { HIPCHK(hipHostMalloc((void **)&e->rs_abort, sizeof(int), hipHostMallocMapped)); *e->rs_abort = 0; }
                     if ((rc = dev_alloc((void **)&e->d_rs_abort, sizeof(int), true, e->stream))) return rc;
-                    e->rs_epoch = 0;
+                    if ((rc = dev_alloc((void **)&e->d_rs_commit, (size_t)(e->sxc / 64) * sizeof(unsigned), true, e->stream))) return rc;
+                    if (!e->rs_done) { HIPCHK(hipHostMalloc((void **)&e->rs_done, (size_t)(e->sxc / 64) * sizeof(int), hipHostMallocMapped)); }
+                    std::memset(e->rs_done, 0, (size_t)(e->sxc / 64) * sizeof(int));
+                    e->rs_epoch = 0; e->rs_seq = 0;
                     e->rs_ok = true;
                 }
             }
@@ -1227,6 +1233,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
     lap("build_bp_lists + upload");
     static_assert(sizeof(Cell) == sizeof(CellD), "cell layout");
     HIPCHK(hipMemcpy(e->d_cell, t.cell.data(), t.cell.size() * sizeof(CellD), hipMemcpyHostToDevice));
+    g_alloc_meter = nullptr;                       // what follows are fields, not tables
     if ((rc = dev_alloc((void **)&e->d_scal_own, TOMO_S_COUNT * sizeof(double), true, e->stream))) return rc;
     if ((rc = dev_alloc((void **)&e->d_part, NPART * sizeof(double), true, e->stream))) return rc;
     e->d_scal = e->d_scal_own;
@@ -1244,9 +1251,10 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
 extern "C" int tomo_destroy(tomo_engine *e);
 
 // a half-built engine is torn down again (device buffers, stream) and the first error is the one reported
-static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out)
+static int finish_create(tomo_engine *e, Coo &m, tomo_engine **out, double t_begin)
 {
     int rc = finish_create_impl(e, m, out);
+    e->create_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_begin) * 1e3;
     if (rc) {
         std::string first = g_err;
         tomo_destroy(e);
@@ -1375,9 +1383,10 @@ int tomo_create(int nslice, int nray, int nproj, const double *angles_rad, int d
     int rc = check_dims(nslice, nray, nproj);
     if (rc) return rc;
     tomo_engine *e = new_engine(nslice, nray, nproj, device);
+    const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     Coo m;
     build_parallel_ray(nray, nproj, angles_rad, m);
-    return finish_create(e, m, out);
+    return finish_create(e, m, out, t_begin);
 }
 
 int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const float *rows, const float *cols,
@@ -1386,12 +1395,13 @@ int tomo_create_from_matrix(int nslice, int nray, int nproj, int64_t nnz, const 
     if (!rows || !cols || !vals || !out) return fail(TOMO_ERR_ARG, "null argument");
     int rc = check_dims(nslice, nray, nproj);
     if (rc) return rc;
+    const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     Coo m;
     std::string err;
     if (!coo_from_triplets((int64_t)nray * nproj, (int64_t)nray * nray, nnz, rows, cols, vals, m, err))
         return fail(TOMO_ERR_ARG, err);
     tomo_engine *e = new_engine(nslice, nray, nproj, device);
-    return finish_create(e, m, out);
+    return finish_create(e, m, out, t_begin);
 }
 
 // every device buffer that depends on the tilt geometry (tables, sinograms, scratch sized by it); volumes stay
@@ -1408,7 +1418,7 @@ static void free_geometry(tomo_engine *e)
                      (void **)&e->d_fs_gseg0, (void **)&e->d_fs_ent, (void **)&e->d_fs_zero, (void **)&e->d_fs_rsptr, (void **)&e->d_fs_rsidx, (void **)&e->fs_part, (void **)&e->fs_part_aux,
                      (void **)&e->d_fl_items, (void **)&e->d_fl_orient, (void **)&e->d_fl_shift, (void **)&e->d_fl_ent, (void **)&e->d_fl_ptr, (void **)&e->d_fl_fent, (void **)&e->d_fl_fptr,
                      (void **)&e->d_fl_rsptr, (void **)&e->d_fl_rsidx, (void **)&e->d_fl_zero, (void **)&e->fl_part, (void **)&e->fl_part_aux,
-                     (void **)&e->d_rs_hdr, (void **)&e->d_rs_cell, (void **)&e->d_rs_ts, (void **)&e->d_rs_rl, (void **)&e->rs_pb, (void **)&e->rs_rb, (void **)&e->d_rs_angs, (void **)&e->d_rs_abort};
+                     (void **)&e->d_rs_hdr, (void **)&e->d_rs_cell, (void **)&e->d_rs_ts, (void **)&e->d_rs_rl, (void **)&e->rs_pb, (void **)&e->rs_rb, (void **)&e->d_rs_angs, (void **)&e->d_rs_abort, (void **)&e->d_rs_commit};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     e->rs_ok = false; e->rs_angs_cap = 0; e->rs_angs_host.clear();
     for (int i = 0; i < TOMO_SINO_SLOTS; ++i) if (e->sino[i]) { (void)hipFree(e->sino[i]); e->sino[i] = nullptr; }
@@ -1433,6 +1443,7 @@ int tomo_destroy(tomo_engine *e)
     if (e->ev_snap) (void)hipEventDestroy(e->ev_snap);
     if (e->h_snap) (void)hipHostFree(e->h_snap);
     if (e->rs_abort) (void)hipHostFree(e->rs_abort);
+    if (e->rs_done) (void)hipHostFree(e->rs_done);
     free_geometry(e);
     void *ptrs[] = {e->tv_alt, e->halo_lo_alt, e->halo_hi_alt, e->d_part_tv, e->d_part_aux, e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], e->cg_p, e->cg_z, e->cg_sums, e->cg_part, e->cg_coef, e->sart_alt,
                     e->tvg, e->fgp_p[0], e->fgp_p[1], e->fgp_p[2], e->stage, e->d_scal_own, e->d_part, e->halo_lo_own, e->halo_hi_own};
@@ -1490,7 +1501,7 @@ int tomo_set_stream(tomo_engine *e, void *hip_stream)
     return TOMO_OK;
 }
 
-int tomo_synchronize(tomo_engine *e) { NEED(e); HIPCHK(hipStreamSynchronize(e->stream)); RS_CHECK(e); return TOMO_OK; }
+int tomo_synchronize(tomo_engine *e) { NEED(e); HIPCHK(hipStreamSynchronize(e->stream)); return TOMO_OK; }
 int tomo_get_device(tomo_engine *e, int *device) { if (!e || !device) return fail(TOMO_ERR_ARG, "null"); *device = e->device; return TOMO_OK; }
 int tomo_get_dims(tomo_engine *e, int *nslice, int *nray, int *nproj, int64_t *nnz)
 {
@@ -1533,7 +1544,6 @@ static int download(tomo_engine *e, const float *src, float *host, int64_t m)
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(host, e->stage, bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    RS_CHECK(e);
     return TOMO_OK;
 }
 
@@ -1713,8 +1723,12 @@ int tomo_sirt_data(tomo_engine *e, int vol, int sino_b, int niter)
 static std::mutex g_rs_mu;
 static hipEvent_t g_rs_last[64] = {};
 
-static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t steps, const std::function<int(int64_t)> &angle_at, float *track)
+// failed: the 64-slice chunk ranges {c0, nc} the launch did not store (empty = the whole sweep is in x); the call returns after the
+// launch has finished -- one host wait per sweep (~10 us against a sweep of milliseconds) is what knowing costs
+static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t steps, const std::function<int(int64_t)> &angle_at, float *track,
+                                std::vector<std::pair<int, int>> &failed)
 {
+    failed.clear();
     if (steps > (int64_t)1 << 24) return fail(TOMO_ERR_ARG, "too many SART steps in one call");
     const int c0 = e->sub_nc ? e->sub_c0 : 0, nc = e->sub_nc ? e->sub_nc : e->sxc / 64;
     const int groups = std::max(1, std::min(e->rs_groups, nc)), rounds = (nc + groups - 1) / groups;
@@ -1738,23 +1752,51 @@ static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t st
         HIPCHK(hipMemsetAsync(e->rs_rb, 0, e->rs_rb_bytes, e->stream));
         e->rs_epoch = 0;
     }
+    if (++e->rs_seq >= (1u << 20)) {                              // so does the launch sequence of the commit words (0 = never written)
+        HIPCHK(hipMemsetAsync(e->d_rs_commit, 0, (size_t)(e->sxc / 64) * sizeof(unsigned), e->stream));
+        std::memset(e->rs_done, 0, (size_t)(e->sxc / 64) * sizeof(int));
+        e->rs_seq = 1;
+    }
     RsArgs A{};
     A.x = x; A.b = e->cur_b; A.rowsum = e->d_rowsum; A.hdr = e->d_rs_hdr; A.cell = e->d_rs_cell; A.ts = e->d_rs_ts; A.rl = e->d_rs_rl;
     A.pb = e->rs_pb; A.rb = e->rs_rb; A.angs = e->d_rs_angs; A.track = track; A.part = e->d_part; A.abort_word = e->d_rs_abort; A.abort_host = e->rs_abort;
+    A.commit = e->d_rs_commit; A.done_host = e->rs_done; A.seq = e->rs_seq; A.test_fail = e->rs_test_fail;
     A.n = e->n; A.sx = e->sx; A.np = e->np; A.ntiles = e->rs_ntiles; A.tiles = e->rs_tiles; A.rpt = e->rs_rpt; A.steps = (int)steps; A.chunk0 = c0; A.nchunk = nc;
     A.epoch0 = e->rs_epoch; A.spin_limit = e->rs_spin_limit; A.beta = beta; A.prof = nullptr;
     e->rs_epoch += (uint32_t)need;
     if (e->device < 0 || e->device >= 64) return fail(TOMO_ERR_ARG, "device index");
-    std::lock_guard<std::mutex> lk(g_rs_mu);
-    hipEvent_t &last = g_rs_last[e->device];
-    if (!last) HIPCHK(hipEventCreateWithFlags(&last, hipEventDisableTiming));
-    else HIPCHK(hipStreamWaitEvent(e->stream, last, 0));
     {
-        ProfScope ps(e, TOMO_K_SART_RESIDENT);
-        hipLaunchKernelGGL(k_sart_resident, dim3((unsigned)(e->rs_ntiles * groups)), dim3(RS_THREADS), 0, e->stream, A);
-        LAUNCHCHK();
+        std::lock_guard<std::mutex> lk(g_rs_mu);
+        hipEvent_t &last = g_rs_last[e->device];
+        if (!last) HIPCHK(hipEventCreateWithFlags(&last, hipEventDisableTiming));
+        else HIPCHK(hipStreamWaitEvent(e->stream, last, 0));
+        {
+            ProfScope ps(e, TOMO_K_SART_RESIDENT);
+            hipLaunchKernelGGL(k_sart_resident, dim3((unsigned)(e->rs_ntiles * groups)), dim3(RS_THREADS), 0, e->stream, A);
+            LAUNCHCHK();
+        }
+        HIPCHK(hipEventRecord(last, e->stream));
     }
-    HIPCHK(hipEventRecord(last, e->stream));
+    // the verdict: which chunks carry this launch's sequence number
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int nfailed = 0;
+    for (int c = c0; c < c0 + nc; ++c) {
+        if (e->rs_done[c] == (int)e->rs_seq) continue;
+        ++nfailed;
+        if (!failed.empty() && failed.back().first + failed.back().second == c) ++failed.back().second;
+        else failed.emplace_back(c, 1);
+    }
+    if (nfailed) {
+        e->rs_last_code = *e->rs_abort;
+        *e->rs_abort = 0;
+        HIPCHK(hipMemsetAsync(e->d_rs_abort, 0, sizeof(int), e->stream));
+        ++e->rs_fallbacks;
+        e->rs_fallback_chunks += nfailed;
+        e->rs_backoff = std::min(64, std::max(1, 2 * e->rs_backoff));
+        e->rs_skip = e->rs_backoff;
+    } else {
+        e->rs_backoff = 0;
+    }
     return TOMO_OK;
 }
 
@@ -1804,27 +1846,28 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
     }
     // fused chain: FP(a0) ; [BP(a_k) + FP(a_k+1)] for every consecutive pair ; BP(a_last)
     if (steps <= 0) return TOMO_OK;
-    const int form = select_forms(e).sart;
-    if (form == TOMO_FORM_SART_RESIDENT) {      // the volume-resident sweep: one launch, the slab read and written once
-        if ((rc = launch_sart_resident(e, x, beta, steps, angle_at, track))) return rc;
-        return finish();
+    int form = select_forms(e).sart;
+    if (form == TOMO_FORM_SART_RESIDENT && e->rs_skip > 0 && e->sart_resident != 1) {   // sitting out after a sweep that could not finish
+        --e->rs_skip;
+        form = TOMO_FORM_SART_TILE;
     }
-    if (e->sart_resident == 1) return fail(TOMO_ERR_STATE, "\"sart_resident\" = 1, but this engine has no tables of the resident sweep (N not a multiple of 8, more 32 x 32 tiles than CUs, or a matrix whose ray windows do not fit)");
-    if (form == TOMO_FORM_SART_TILE) {   // tile form, in place
+    // the streamed tile form, in place: over the whole slab (as one chain or several), or over the chunk ranges a resident launch left
+    auto sweep_tiles = [&](const std::vector<std::pair<int, int>> *ranges) -> int {
         // cooperative chain (k_sart_tile COOP): needs consecutive angles to differ (np >= 2) and whole 64-slice chunks
-        const bool coop = e->sart_coop && e->np >= 2 && steps >= 2;
-        if ((rc = sart_tile_prepare(e, coop))) return rc;
+        const bool coop = e->sart_coop && e->np >= 2 && steps >= 2 && !ranges;
+        int rc2;
+        if ((rc2 = sart_tile_prepare(e, coop))) return rc2;
         const uint32_t epoch0 = e->st_epoch + 1;             // link k publishes with epoch0 + k (both sub-slab chains alike)
         if (coop) e->st_epoch += (uint32_t)(steps + 1);
         // link k of the chain: 0 = FP(a0); 1..steps-1 = BP(a_k-1) + FP(a_k); steps = BP(a_last)
         auto link = [&](int64_t k, const Sub &sb) -> int {
-            int rc2;
+            int rc3;
             if (coop) {
                 float *pk = (k & 1) ? e->st_partial2 : e->st_partial, *pk1 = (k & 1) ? e->st_partial : e->st_partial2;   // P[k&1], P[(k-1)&1]
                 if (k == 0) return launch_sart_tile<false>(e, sb, x, 0, angle_at(0), r, beta, pk, false);
                 if (k == steps) {
                     int last = angle_at(steps - 1);
-                    if ((rc2 = launch_resid_finish_tile(e, sb, pk1, last, r))) return rc2;
+                    if ((rc3 = launch_resid_finish_tile(e, sb, pk1, last, r))) return rc3;
                     return launch_bp_angle(e, sb, x, last, r + (size_t)last * e->n * e->sx, beta, track);
                 }
                 return launch_sart_coop(e, sb, x, angle_at(k - 1), angle_at(k), r, beta, pk1, pk, epoch0 + (uint32_t)k, k);
@@ -1833,16 +1876,33 @@ static int sart_impl(tomo_engine *e, int vol, int sino_b, float beta, int niter,
             if (k == steps) { int last = angle_at(steps - 1); return launch_bp_angle(e, sb, x, last, r + (size_t)last * e->n * e->sx, beta, track); }
             int prev = angle_at(k - 1), next = angle_at(k);
             if (prev == next) {
-                if ((rc2 = launch_bp_angle(e, sb, x, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc2;
+                if ((rc3 = launch_bp_angle(e, sb, x, prev, r + (size_t)prev * e->n * e->sx, beta))) return rc3;
                 return launch_sart_tile<false>(e, sb, x, 0, next, r, beta);
             }
             return launch_sart_tile<true>(e, sb, x, prev, next, r, beta, nullptr, true, k);
         };
         auto chain = [&](const Sub &sb) -> int {
-            for (int64_t k = 0; k <= steps; ++k) { int rc2 = link(k, sb); if (rc2) return rc2; }
+            for (int64_t k = 0; k <= steps; ++k) { int rc3 = link(k, sb); if (rc3) return rc3; }
             return TOMO_OK;
         };
-        if ((rc = run_chains(e, chain))) return rc;
+        if (!ranges) return run_chains(e, chain);
+        for (const auto &rg : *ranges) {     // one after the other on the engine's stream (they share the partial-sum buffer)
+            const int c0 = rg.first, nc = rg.second;
+            const int vec = (c0 % 4 == 0 && nc % 4 == 0) ? 4 : (c0 % 2 == 0 && nc % 2 == 0) ? 2 : 1;
+            if ((rc2 = chain(Sub{e->stream, c0, nc, vec}))) return rc2;
+        }
+        return TOMO_OK;
+    };
+    if (form == TOMO_FORM_SART_RESIDENT) {      // the volume-resident sweep: one launch, the slab read and written once
+        std::vector<std::pair<int, int>> failed;
+        if ((rc = launch_sart_resident(e, x, beta, steps, angle_at, track, failed))) return rc;
+        // chunks whose workgroups could not all finish (the device was shared) were not stored: the streamed chain sweeps them
+        if (!failed.empty() && (rc = sweep_tiles(&failed))) return rc;
+        return finish();
+    }
+    if (e->sart_resident == 1 && !e->rs_ok) return fail(TOMO_ERR_STATE, "\"sart_resident\" = 1, but this engine has no tables of the resident sweep (N not a multiple of 8, more 32 x 32 tiles than CUs, or a matrix whose ray windows do not fit)");
+    if (form == TOMO_FORM_SART_TILE) {   // tile form, in place
+        if ((rc = sweep_tiles(nullptr))) return rc;
         return finish();
     }
     float *alt;
@@ -2348,7 +2408,6 @@ int tomo_read_scalars(tomo_engine *e, double *out, int count)
     { int rc = tomo_async_wait(e); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(out, e->d_scal, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    RS_CHECK(e);
     return TOMO_OK;
 }
 
@@ -2377,7 +2436,6 @@ int tomo_scalars_snapshot_read(tomo_engine *e, double *out, int count)
     HIPCHK(hipEventSynchronize(e->ev_snap));
     std::memcpy(out, e->h_snap, count * sizeof(double));
     e->snap_pending = false;
-    RS_CHECK(e);
     return TOMO_OK;
 }
 
@@ -3237,6 +3295,13 @@ int tomo_get_option(tomo_engine *e, const char *name, int *value)
     if (std::strcmp(name, "sart_resident") == 0) { *value = e->sart_resident; return TOMO_OK; }
     if (std::strcmp(name, "sart_resident_ready") == 0) { *value = e->rs_ok ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_resident_active") == 0) { *value = (e->rs_ok && e->sart_resident != 0) ? 1 : 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident_spin") == 0) { *value = (int)std::min<uint32_t>(e->rs_spin_limit, 0x7FFFFFFFu); return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident_fallbacks") == 0) { *value = e->rs_fallbacks; return TOMO_OK; }            // sweeps that needed the streamed chain
+    if (std::strcmp(name, "sart_resident_fallback_chunks") == 0) { *value = e->rs_fallback_chunks; return TOMO_OK; } // ... and the 64-slice chunks it swept
+    if (std::strcmp(name, "sart_resident_skip") == 0) { *value = e->rs_skip; return TOMO_OK; }                       // sweeps the resident form still sits out
+    if (std::strcmp(name, "sart_resident_last_code") == 0) { *value = e->rs_last_code; return TOMO_OK; }             // 1 residual rows, 2 tile sums (0: the commit)
+    if (std::strcmp(name, "table_kib") == 0) { *value = (int)std::min<size_t>(e->table_bytes >> 10, 0x7FFFFFFF); return TOMO_OK; }   // device tables built at creation
+    if (std::strcmp(name, "create_ms") == 0) { *value = (int)std::min(e->create_ms + 0.5, 2147483647.0); return TOMO_OK; }           // what creating this engine took
     if (std::strcmp(name, "form_fp") == 0) { *value = select_forms(e).fp; return TOMO_OK; }
     if (std::strcmp(name, "form_bp") == 0) { *value = select_forms(e).bp; return TOMO_OK; }
     if (std::strcmp(name, "form_sart") == 0) { *value = select_forms(e).sart; return TOMO_OK; }
@@ -3254,8 +3319,9 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "fp_all_lpr") == 0) { e->fp_all_lpr = (value == 16 || value == 32) ? value : 0; return TOMO_OK; }
     if (std::strcmp(name, "art_chain") == 0) { e->art_chain = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_tile") == 0) { e->sart_tile = value ? 1 : 0; return TOMO_OK; }
-    if (std::strcmp(name, "sart_resident") == 0) { e->sart_resident = value < 0 ? -1 : (value ? 1 : 0); return TOMO_OK; }
-    if (std::strcmp(name, "sart_resident_spin") == 0) { e->rs_spin_limit = value <= 0 ? 64u : (uint32_t)value; return TOMO_OK; }   // (tests: a sweep that gives up)
+    if (std::strcmp(name, "sart_resident") == 0) { e->sart_resident = value < 0 ? -1 : (value ? 1 : 0); e->rs_skip = e->rs_backoff = 0; return TOMO_OK; }
+    if (std::strcmp(name, "sart_resident_spin") == 0) { e->rs_spin_limit = value < 0 ? (1u << 21) : (uint32_t)value; return TOMO_OK; }   // polls before a wait gives up (< 0: the default; tests: tiny, 0 = at the first look)
+    if (std::strcmp(name, "sart_resident_test_fail") == 0) { e->rs_test_fail = std::max(0, value); return TOMO_OK; }   // tests: chunk + 1 that refuses to commit
 #ifdef TOMO_WHATIF
     if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
 #endif

@@ -62,6 +62,10 @@ int main(int argc, char **argv)
     A.x = dx; A.b = db; A.rowsum = drs; A.hdr = dh; A.cell = dcell; A.ts = dts; A.rl = drl; A.pb = dpb; A.rb = drb; A.angs = nullptr; A.track = nullptr; A.part = dpart;
     A.abort_word = dab; A.n = N; A.sx = sx; A.np = P; A.ntiles = ntiles; A.tiles = R.tiles; A.rpt = R.rpt; A.steps = steps; A.chunk0 = 0; A.nchunk = nchunk;
     A.spin_limit = 1u << 20; A.beta = beta;
+    unsigned *dcommit; int *hdone;      // the commit words and the pinned per-chunk verdicts (round 6: a chunk is stored by all of its workgroups or by none)
+    CK(hipMalloc(&dcommit, nchunk * 4)); CK(hipMemset(dcommit, 0, nchunk * 4));
+    CK(hipHostMalloc((void **)&hdone, nchunk * sizeof(int), hipHostMallocMapped)); std::memset(hdone, 0, nchunk * sizeof(int));
+    A.commit = dcommit; A.done_host = hdone; A.seq = 0; A.test_fail = 0;
     std::vector<int> hang(steps); for (int k = 0; k < steps; ++k) hang[k] = k % P;
     int *dang; CK(hipMalloc(&dang, steps * 4)); CK(hipMemcpy(dang, hang.data(), steps * 4, hipMemcpyHostToDevice)); A.angs = dang;
     long long *dprof; CK(hipMalloc(&dprof, (2048 + 128) * 8)); CK(hipMemset(dprof, 0, (2048 + 128) * 8)); A.prof = dprof;
@@ -81,6 +85,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(dx, x0.data(), x0.size() * 4, hipMemcpyHostToDevice));
         if (tracked) { CK(hipMemcpy(dtk, tk0.data(), tk0.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(dpart, 0, NPART * 8)); }
         A.epoch0 = epoch; epoch += (unsigned)((nchunk + ngrp - 1) / ngrp) * (unsigned)steps;
+        ++A.seq;
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(k_sart_resident, dim3(ntiles * ngrp), dim3(RS_THREADS), 0, 0, A);
@@ -92,6 +97,7 @@ int main(int argc, char **argv)
         int ab; CK(hipMemcpy(&ab, dab, 4, hipMemcpyDeviceToHost));
         printf("rep %d: %.3f ms = %.2f us per angle and chunk-round; abort word %d\n", rep, ms, 1000.0 * ms / steps / ((nchunk + ngrp - 1) / ngrp), ab);
         if (ab) { printf("ABORTED\n"); return 2; }
+        for (int c = 0; c < nchunk; ++c) if (hdone[c] != (int)A.seq) { printf("chunk %d did not commit (%d, launch %u)\n", c, hdone[c], A.seq); return 2; }
     }
     CK(hipMemcpy(got.data(), dx, got.size() * 4, hipMemcpyDeviceToHost));
 #ifdef RS_PROF
