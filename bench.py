@@ -428,15 +428,17 @@ def attach_traffic(roofs, shape):
                 raw = hit[0].get("fetch_kib_raw")
                 if r["kernel"] == "k_sart_resident" and raw is not None:
                     # The guide's x2 is calibrated for 16-byte-per-lane streaming reads only.  This kernel reads by scalar loads (cells),
-                    # 8-byte-per-lane polls (granules) and 4-byte-per-lane loads (the chunk): which factor applies to those widths is
-                    # measured by tools/micro/fetch_calib.hip (profiles/r06_fetch_calibration.md); both readings are given.
+                    # 8-byte-per-lane polls (granules), 4-byte-per-lane loads (the chunk) and line touches; measured on those widths
+                    # (tools/micro/fetch_calib.hip, profiles/r06_fetch_calibration.md): every vector read is tallied at half its bytes
+                    # whatever its width, scalar loads exactly, writes exactly -- so x2 applies to all but scalar-load misses.
                     wr = hit[0].get("write_kib", 0.0) * 1024.0
                     r["traffic_fetch_raw_plus_write"] = raw * 1024.0 + wr
                     r["traffic_fetch_x2_plus_write"] = 2.0 * raw * 1024.0 + wr
                     must = r["hbm"]["bytes_the_launch_must_move"]
                     r["traffic_over_must_move"] = {"fetch_x2": r["traffic_fetch_x2_plus_write"] / must, "fetch_raw": r["traffic_fetch_raw_plus_write"] / must}
-                    r["traffic_note"] = ("FETCH_SIZE x2 is the guide's correction for 16-B-per-lane streaming reads; this kernel's reads are scalar "
-                                         "loads, 8-B polls and 4-B lane loads -- see profiles/r06_fetch_calibration.md for the factor measured on those widths")
+                    r["traffic_note"] = ("calibrated (profiles/r06_fetch_calibration.md): FETCH_SIZE tallies every vector read (4, 8, 16 B per lane, line "
+                                         "touches) at half its bytes and scalar loads in full, WRITE_SIZE is exact; the x2 figure is right unless cell "
+                                         "bytes reach the fabric through scalar-load misses (then at most one cell table less: the raw figure is a floor)")
         return
 
 

@@ -254,7 +254,7 @@ def test_sweep_beside_a_kernel_that_holds_part_of_the_chip(gpu, tracked, spin):
     ns, n, nproj = 64, 512, 12
     want, want_nrm = _streamed(ns, n, nproj, tracked)
     t = _engine(ns, n, nproj, 1, noisy=True)
-    t.SART(0.7, 1)                                   # tables, buffers and the angle sequence are warm
+    t.SART(0.7, 2)                                   # tables, buffers and the angle sequence (two sweeps) are warm: no allocation beside the held CUs
     t.restart_recon()
     if tracked:
         t.copy_recon()

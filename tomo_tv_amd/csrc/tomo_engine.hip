@@ -233,7 +233,8 @@ struct tomo_engine {
     // chain, and the resident form then sits out rs_skip sweeps (doubling up to 64 while the failures go on; "sart_resident" = 1 insists)
     unsigned *d_rs_commit = nullptr;
     int *rs_done = nullptr;
-    uint32_t rs_seq = 0;
+    uint32_t rs_seq = 0, rs_commit_base = 0;
+    bool rs_commit_dirty = false;
     size_t table_bytes = 0;                        // device bytes of the tables built at creation (everything but volumes, sinograms, halos)
     double create_ms = 0.0;                        // wall clock of the creation (matrix, tables, uploads)
     int rs_fallbacks = 0, rs_fallback_chunks = 0, rs_skip = 0, rs_backoff = 0, rs_last_code = 0, rs_test_fail = 0;
@@ -1193,7 +1194,7 @@ static int finish_create_impl(tomo_engine *e, Coo &m, tomo_engine **out)
                     if ((rc = dev_alloc((void **)&e->d_rs_commit, (size_t)(e->sxc / 64) * sizeof(unsigned), true, e->stream))) return rc;
                     if (!e->rs_done) { HIPCHK(hipHostMalloc((void **)&e->rs_done, (size_t)(e->sxc / 64) * sizeof(int), hipHostMallocMapped)); }
                     std::memset(e->rs_done, 0, (size_t)(e->sxc / 64) * sizeof(int));
-                    e->rs_epoch = 0; e->rs_seq = 0;
+                    e->rs_epoch = 0; e->rs_seq = 0; e->rs_commit_base = 0; e->rs_commit_dirty = false;
                     e->rs_ok = true;
                 }
             }
@@ -1752,15 +1753,18 @@ static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t st
         HIPCHK(hipMemsetAsync(e->rs_rb, 0, e->rs_rb_bytes, e->stream));
         e->rs_epoch = 0;
     }
-    if (++e->rs_seq >= (1u << 20)) {                              // so does the launch sequence of the commit words (0 = never written)
+    // commit words: all at rs_commit_base (every launch covers every chunk and adds the number of tiles to each word when it commits);
+    // cleared after a launch that did not commit, and before the count could reach the poison bit
+    if (c0 != 0 || nc != e->sxc / 64) return fail(TOMO_ERR_STATE, "the resident sweep covers the whole slab");
+    if (e->rs_commit_dirty || e->rs_commit_base > 0x7F000000u) {
         HIPCHK(hipMemsetAsync(e->d_rs_commit, 0, (size_t)(e->sxc / 64) * sizeof(unsigned), e->stream));
-        std::memset(e->rs_done, 0, (size_t)(e->sxc / 64) * sizeof(int));
-        e->rs_seq = 1;
+        e->rs_commit_base = 0; e->rs_commit_dirty = false;
     }
+    if (++e->rs_seq >= 0x7FFFFFF0u) { std::memset(e->rs_done, 0, (size_t)(e->sxc / 64) * sizeof(int)); e->rs_seq = 1; }
     RsArgs A{};
     A.x = x; A.b = e->cur_b; A.rowsum = e->d_rowsum; A.hdr = e->d_rs_hdr; A.cell = e->d_rs_cell; A.ts = e->d_rs_ts; A.rl = e->d_rs_rl;
     A.pb = e->rs_pb; A.rb = e->rs_rb; A.angs = e->d_rs_angs; A.track = track; A.part = e->d_part; A.abort_word = e->d_rs_abort; A.abort_host = e->rs_abort;
-    A.commit = e->d_rs_commit; A.done_host = e->rs_done; A.seq = e->rs_seq; A.test_fail = e->rs_test_fail;
+    A.commit = e->d_rs_commit; A.done_host = e->rs_done; A.seq = e->rs_seq; A.commit_base = e->rs_commit_base; A.test_fail = e->rs_test_fail;
     A.n = e->n; A.sx = e->sx; A.np = e->np; A.ntiles = e->rs_ntiles; A.tiles = e->rs_tiles; A.rpt = e->rs_rpt; A.steps = (int)steps; A.chunk0 = c0; A.nchunk = nc;
     A.epoch0 = e->rs_epoch; A.spin_limit = e->rs_spin_limit; A.beta = beta; A.prof = nullptr;
     e->rs_epoch += (uint32_t)need;
@@ -1787,6 +1791,7 @@ static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t st
         else failed.emplace_back(c, 1);
     }
     if (nfailed) {
+        e->rs_commit_dirty = true;
         e->rs_last_code = *e->rs_abort;
         *e->rs_abort = 0;
         HIPCHK(hipMemsetAsync(e->d_rs_abort, 0, sizeof(int), e->stream));
@@ -1795,6 +1800,7 @@ static int launch_sart_resident(tomo_engine *e, float *x, float beta, int64_t st
         e->rs_backoff = std::min(64, std::max(1, 2 * e->rs_backoff));
         e->rs_skip = e->rs_backoff;
     } else {
+        e->rs_commit_base += (unsigned)e->rs_ntiles;
         e->rs_backoff = 0;
     }
     return TOMO_OK;

@@ -65,7 +65,7 @@ int main(int argc, char **argv)
     unsigned *dcommit; int *hdone;      // the commit words and the pinned per-chunk verdicts (round 6: a chunk is stored by all of its workgroups or by none)
     CK(hipMalloc(&dcommit, nchunk * 4)); CK(hipMemset(dcommit, 0, nchunk * 4));
     CK(hipHostMalloc((void **)&hdone, nchunk * sizeof(int), hipHostMallocMapped)); std::memset(hdone, 0, nchunk * sizeof(int));
-    A.commit = dcommit; A.done_host = hdone; A.seq = 0; A.test_fail = 0;
+    A.commit = dcommit; A.done_host = hdone; A.seq = 0; A.commit_base = 0; A.test_fail = 0;
     std::vector<int> hang(steps); for (int k = 0; k < steps; ++k) hang[k] = k % P;
     int *dang; CK(hipMalloc(&dang, steps * 4)); CK(hipMemcpy(dang, hang.data(), steps * 4, hipMemcpyHostToDevice)); A.angs = dang;
     long long *dprof; CK(hipMalloc(&dprof, (2048 + 128) * 8)); CK(hipMemset(dprof, 0, (2048 + 128) * 8)); A.prof = dprof;
@@ -85,7 +85,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(dx, x0.data(), x0.size() * 4, hipMemcpyHostToDevice));
         if (tracked) { CK(hipMemcpy(dtk, tk0.data(), tk0.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(dpart, 0, NPART * 8)); }
         A.epoch0 = epoch; epoch += (unsigned)((nchunk + ngrp - 1) / ngrp) * (unsigned)steps;
-        ++A.seq;
+        ++A.seq; A.commit_base = (A.seq - 1) * (unsigned)ntiles;
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(k_sart_resident, dim3(ntiles * ngrp), dim3(RS_THREADS), 0, 0, A);
