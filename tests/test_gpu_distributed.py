@@ -51,3 +51,19 @@ def test_c_host_two_ranks_on_two_gpus(gpu, tmp_path):
                 q.kill()
             pytest.fail("two-rank C host timed out")
     assert all(p.returncode == 0 for p in procs) and "COMM_HOST_OK" in outs[0][0], str(outs)[-3000:]
+
+
+def test_one_device_engine_answers_the_multi_gpu_queries(gpu, capsys):
+    """``multigpuengine(...)`` / ``multigpufusion(...)`` return the plain one-device classes where one device is left; the
+    reference class's own queries (multigpuengine.cpp:385-421) must still work on what comes back."""
+    import numpy as np
+    from tomo_tv_amd.chemistry import multigpufusion
+    from tomo_tv_amd.engine import multigpuengine
+    ang = np.deg2rad(np.linspace(-60, 60, 5))
+    t = multigpuengine(4, 32, ang, devices=[0])
+    assert t.get_gpu_ids() == [0] and t.is_multi_gpu_enabled() is False
+    t.print_gpu_usage()
+    m = multigpufusion(4, 32, 2, ang, ang, devices=[0])
+    assert m.get_gpu_ids() == [0] and m.is_multi_gpu_enabled() is False
+    m.print_gpu_usage()
+    assert "device 0" in capsys.readouterr().out

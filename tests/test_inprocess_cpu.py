@@ -161,3 +161,52 @@ def test_driver_loops_run_on_the_rank_threads(monkeypatch):
         assert np.allclose(c3, c1, rtol=1e-5) and many.cost is not None
     finally:
         t.close()
+
+
+def test_stale_results_of_an_interrupted_call_are_dropped():
+    """a facade call interrupted on the calling thread leaves its workers running; their late (rank, value) entries must
+    not be consumed by the NEXT call as its own results.  Every job carries a sequence number (InProcWorld.run)."""
+    import time
+    from tomo_tv_amd.inprocess import InProcWorld
+    w = InProcWorld(3)
+    try:
+        # what an interrupted run() leaves behind: jobs handed out, nobody collecting
+        w._seq = seq = getattr(w, "_seq", 0) + 1
+        for q in w._jobs:
+            q.put((seq, lambda r: (time.sleep(0.05), "stale")[1]))
+        assert w.run(lambda r: ("fresh", r)) == [("fresh", 0), ("fresh", 1), ("fresh", 2)]
+        assert w.run(lambda r: r * 2) == [0, 2, 4]
+    finally:
+        w.close()
+
+
+def test_on_rank_threads_copies_back_whatever_the_driver_set():
+    """only cost / dd_vec / tv_vec came back from rank 0's clone; now every attribute the loop set or replaced does."""
+    from tomo_tv_amd import reconstructor
+
+    class FakeFacade(InProcessMultiGPU):
+        def __init__(self, n):
+            from tomo_tv_amd.inprocess import InProcWorld
+            object.__setattr__(self, "_engines", [object() for _ in range(n)])
+            object.__setattr__(self, "_world", InProcWorld(n))
+
+    class Driver:
+        def __init__(self, tomo):
+            self.tomo, self.kept, self.replaced = tomo, [1, 2], "old"
+
+        @reconstructor._on_rank_threads
+        def loop(self, k):
+            assert self._on_rank and not isinstance(self.tomo, InProcessMultiGPU)
+            self.replaced = "new"
+            self.fresh = np.arange(k)
+            return k + 1
+
+    f = FakeFacade(2)
+    try:
+        d = Driver(f)
+        kept = d.kept
+        assert d.loop(3) == 4
+        assert d.replaced == "new" and np.array_equal(d.fresh, np.arange(3)) and d.kept is kept
+        assert d.tomo is f and not getattr(d, "_on_rank", False)
+    finally:
+        f._world.close()

@@ -307,6 +307,26 @@ class multimodal:
         return out
 
 
+def _one_device_queries(cls):
+    """The multi-GPU queries of multigpufusion (multigpufusion.cpp:463-474), answered by the one-device class too:
+    ``multigpufusion(...)`` returns ``multimodal`` where one device is left."""
+    def get_gpu_ids(self):
+        return [int(self.ce.gpuID)]
+
+    def is_multi_gpu_enabled(self):
+        return False
+
+    def print_gpu_usage(self):
+        print(f"1 GPU (device {int(self.ce.gpuID)}): {self.Nslice_} slices")
+    for f in (get_gpu_ids, is_multi_gpu_enabled, print_gpu_usage):
+        if f.__name__ not in cls.__dict__:
+            setattr(cls, f.__name__, f)
+    return cls
+
+
+_one_device_queries(multimodal)
+
+
 class multigpufusion(multimodal):
     """``multigpufusion`` (chemistry/utils/multigpufusion.cpp:463-474): the slab-sharded ``multimodal`` -- construct it
     in every rank of a ``torchrun`` job with the GLOBAL sizes.  Unlike the reference (where only ``poisson_ml`` is really

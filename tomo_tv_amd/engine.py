@@ -924,6 +924,17 @@ class tomoengine(_EngineBase):
     def get_gpu_id(self):
         return self.gpuID
 
+    # The queries of the reference's multigpuengine (multigpuengine.cpp:385-421).  ``multigpuengine(...)`` returns THIS class where one
+    # device is left (a one-GPU box, Nslice == 1, devices=[d]), so a one-device engine answers them too; the sharded classes override.
+    def get_gpu_ids(self):
+        return [int(self.gpuID)]
+
+    def is_multi_gpu_enabled(self):
+        return False
+
+    def print_gpu_usage(self):
+        print(f"1 GPU (device {int(self.gpuID)}): {self.Nslice_} slices")
+
     # initialisers of the ASTRA objects (tomoengine.cpp:151-254): state only
     def initialize_SIRT(self):
         pass

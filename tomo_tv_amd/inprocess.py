@@ -33,14 +33,15 @@ class InProcWorld:
 
     def _loop(self, rank):
         while True:
-            fn = self._jobs[rank].get()
-            if fn is None:
+            job = self._jobs[rank].get()
+            if job is None:
                 return
+            seq, fn = job
             try:
-                self._done.put((rank, fn(rank), None))
+                self._done.put((seq, rank, fn(rank), None))
             except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
                 self.bar.abort()        # the other ranks may be waiting for this one inside a collective
-                self._done.put((rank, None, e))
+                self._done.put((seq, rank, None, e))
 
     def run(self, fn):
         """``fn(rank)`` on every worker at once; the list of results; the first real exception is re-raised.
@@ -51,14 +52,19 @@ class InProcWorld:
         the original error is raised with a note: the process should end (its worker threads are daemons)."""
         if getattr(self, "dead", None):
             raise RuntimeError(f"in-process multi-GPU world is dead: {self.dead}")
+        # every job carries a sequence number: results of a call that was interrupted on this thread (KeyboardInterrupt inside the
+        # wait below) arrive late and must not be taken for this call's (ADVICE r5)
+        self._seq = seq = getattr(self, "_seq", 0) + 1
         for q in self._jobs:
-            q.put(fn)
+            q.put((seq, fn))
         out, err = [None] * self.world, [None] * self.world
         got, failed = 0, False
         grace = float(os.environ.get("TOMO_INPROC_GRACE", "60"))
         while got < self.world:
             try:
-                r, v, e = self._done.get(timeout=grace if failed else None)
+                s, r, v, e = self._done.get(timeout=grace if failed else None)
+                if s != seq:
+                    continue            # a stale entry of an interrupted call
             except queue.Empty:
                 first = [x for x in err if x is not None][0]
                 self.dead = f"rank(s) {[i for i in range(self.world) if err[i] is None and out[i] is None]} did not return within {grace:.0f} s after: {first!r}"

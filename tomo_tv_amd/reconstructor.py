@@ -57,10 +57,14 @@ def _on_rank_threads(fn):
             c = copy.copy(self)
             c.tomo, c._on_rank = eng, True
             clones.append(c)
+        before = dict(self.__dict__)
         out = t._world.run(lambda r: fn(clones[r], *args, **kw))
-        for name in ("cost", "dd_vec", "tv_vec"):
-            if hasattr(clones[0], name):
-                setattr(self, name, getattr(clones[0], name))
+        # whatever rank 0's loop set or replaced on its clone (cost, dd_vec, tv_vec, ... -- not the engine, not the marker)
+        for name, val in clones[0].__dict__.items():
+            if name in ("tomo", "_on_rank"):
+                continue
+            if name not in before or before[name] is not val:
+                setattr(self, name, val)
         return out[0]
     return driver
 
