@@ -304,7 +304,22 @@ int tomo_mm_update(tomo_engine *ce, const int32_t *xvols, const int32_t *uvols, 
  *                     work spreads evenly enough over the waves; TOMO_FP_LIST = 0 / 1 overrides) and the slab is a whole number
  *                     of 128-slice pieces; 0 = k_fp_strip
  *   "fp_tile_pipe" (0): experimental, P >= 2: the tile projector runs as P groups of 64-slice chunks, the reduce pass of one
- *                     group on a second stream beside the tile pass of the next (no gain measured) */
+ *                     group on a second stream beside the tile pass of the next (no gain measured)
+ *   "sart_resident" (-1): the SART sweep as ONE launch of the volume-resident kernel (k_sart_resident: a 64-slice chunk of the whole
+ *                     image stays in vector registers over all angles, the workgroups exchange ray sums).  -1 = automatic: wherever
+ *                     the tables exist ("sart_resident_ready": N a multiple of 8, at most one 32 x 32 tile per CU, ray windows that
+ *                     fit, the tile tables of the streamed chain built too); after a sweep that could not finish (below) the form sits
+ *                     out 1, 2, 4 ... 64 sweeps before it is tried again.  0 = never (the streamed chain k_sart_tile), 1 = insist:
+ *                     an error where the tables do not exist, no sitting out.  Setting it clears the sitting-out state.
+ *                     FAIL-SAFE: every workgroup of the launch must be on the chip at once.  Where that cannot happen (another
+ *                     process or a long kernel of the caller holds CUs) the waits run out, the affected 64-slice chunks are NOT
+ *                     stored -- a chunk is stored by all of its workgroups or by none -- and tomo_sart / tomo_sart_tracked sweep
+ *                     them with the streamed chain before they return: the call returns TOMO_OK with the sweep done (the
+ *                     reference's sweep either happens or errors before touching recon, tomoengine.cpp:162-179).  The call waits
+ *                     for the launch on the host (that is what knowing costs: ~10 us per sweep)
+ *   "sart_resident_spin" (2097152): polls (~1 us each) a wait of the resident sweep makes before it gives up; < 0 = the default,
+ *                     0 = every wait gives up at its first unsuccessful look (tests)
+ *   "sart_resident_test_fail" (0): tests: chunk + 1 whose first workgroup refuses to commit (that chunk goes to the streamed chain) */
 int tomo_set_option(tomo_engine *e, const char *name, int value);
 /* read back a switch, or a fact about the engine: "fp_strip", "fp_list", "fp_tile", "bp_tile", "bp_list", "fgp_pair", "fp_reuse", "sart_tile", and
  * "fp_list_ready" (1: the list form of the strips was built),
@@ -313,7 +328,12 @@ int tomo_set_option(tomo_engine *e, const char *name, int value);
  * "fp_strip" = 1 takes effect), "fp_strip_slots" (accumulator slots per lane group the strip kernel runs with),
  * "comm_rounds" (RCCL rounds -- one ncclGroup or one lone collective each -- this engine has enqueued since creation),
  * "rccl_version" (ncclGetVersion's code of the librccl the library opened, e.g. 22707; 0 before the first communicator),
- * "sart_resident", "sart_resident_ready" (the tables of the volume-resident SART sweep were built), "sart_resident_active",
+ * "sart_resident", "sart_resident_ready" (the tables of the volume-resident SART sweep were built), "sart_resident_active"
+ * (ready and not switched off), "sart_resident_spin", "sart_resident_fallbacks" (sweeps of this engine that needed the streamed chain
+ * for chunks the resident launch did not store), "sart_resident_fallback_chunks" (how many 64-slice chunks that were),
+ * "sart_resident_skip" (sweeps the resident form still sits out), "sart_resident_last_code" (what the last give-up waited for:
+ * 1 residual rows, 2 tile sums, 0 the commit),
+ * "table_kib" (device memory of the tables built at creation: every kernel family's, eagerly), "create_ms" (what creation took),
  * "form_fp" / "form_bp" / "form_sart": which kernel family the all-angle forward projection, the all-angle back projection and the
  * SART sweep of THIS engine run as under the options in force (tomo_form; one function of the engine decides it for the launchers
  * and for this query: tomo_engine.hip select_forms) */

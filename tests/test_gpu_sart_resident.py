@@ -78,6 +78,38 @@ def test_resident_sweep_against_the_oracle(gpu, ns, n, nproj):
     assert _rel(got, ref.recon) <= 1e-5, _rel(got, ref.recon)
 
 
+def test_resident_sweep_random_order_and_tracked_norm_against_the_oracle(gpu):
+    """the resident form in a RANDOM angle order with the tracked step norm was only compared HIP-vs-HIP; here
+    against the oracle's SART in the same order (oracle/tomo_oracle.c: orc_sart takes the order), N = 64, 70 slices (two chunks, one
+    ragged), two sweeps."""
+    ns, n, nproj = 70, 64, 16
+    t = _engine(ns, n, nproj, 1)
+    assert t.get_option("form_sart") == 2
+    t.initialize_SART("random")
+    t._order_rng = np.random.default_rng(5)
+    order = np.random.default_rng(5).permutation(nproj).astype(np.int32)      # what the engine will draw
+    t.copy_recon()
+    nrm = t.SART_tracked(0.7, 2)
+    got = t.get_volume(VOL_RECON)
+    ref = oracle.ctvlib(ns, n, nproj)
+    ref.load_A(oracle.parallel_ray(n, tilt_angles(nproj)))
+    ref.original_volume = ellipsoids(ns, n, seed=11).copy()
+    ref.create_projections()
+    before = ref.recon.copy()
+    ref.SART(0.7, 2, order=order)
+    want_nrm = float(np.linalg.norm((ref.recon.astype(np.float64) - before).ravel()))
+    assert _rel(got, ref.recon) <= 1e-5, _rel(got, ref.recon)
+    assert abs(nrm - want_nrm) <= 1e-5 * want_nrm, (nrm, want_nrm)
+    assert t.matrix_2norm() == 0.0 and t.get_option("sart_resident_fallbacks") == 0
+    # and the sequential order gives something else (the order really was applied)
+    ref2 = oracle.ctvlib(ns, n, nproj)
+    ref2.load_A(oracle.parallel_ray(n, tilt_angles(nproj)))
+    ref2.original_volume = ellipsoids(ns, n, seed=11).copy()
+    ref2.create_projections()
+    ref2.SART(0.7, 2)
+    assert _rel(ref2.recon, ref.recon) > 1e-4
+
+
 def test_two_engines_on_one_device_do_not_starve_each_other(gpu):
     """Two resident sweeps enqueued side by side on two streams of one device: each launch needs every CU, so the library chains
     them (launch_sart_resident); both must come out right and nobody may give up."""
