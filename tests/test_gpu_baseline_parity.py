@@ -180,15 +180,20 @@ def tv_descent_stage(t, ref, start, dPOCS, label, seed=0, tol5=1e-6):
     return e_dev, e_ref
 
 
-def tv_ratio_over_slabs(start, dPOCS_of, label, firsts=(0, 64, 128, 192, 256, 320, 384, 448), width=64, bound=2.0):
+def tv_ratio_over_slabs(start, dPOCS_of, label, firsts=(0, 64, 128, 192, 256, 320, 384, 448), width=64, bound=2.7):
     """The ten-step TV descent on the EIGHT disjoint 64-slice slabs of a 512^3 state: per slab the ratio "HIP's distance to the
     binary64 trajectory / the oracle's" -- a draw from the chaotic amplification, not a property of the arithmetic: 0.62 ... 2.59 over
     eight slabs with geometric mean 1.22 in profiles/r04_tv_arith_variants.md (every slab swept by itself there); 0.99, 2.35, 2.18, 1.72
     on four slabs cut out of the swept 512^3 state here (geometric mean 1.71: the first version of this test, with VERDICT r4's bound
     of 1.5 on four slabs, failed on that draw).  With eight draws of log-sd ~0.5 the geometric mean scatters by a factor ~1.2 around
-    its expectation, so the bound is 2.0 on the geometric mean of eight: an arithmetic that is systematically 2 x further from
-    binary64 than the reference's (geometric mean ~2.4) fails it, one unlucky slab does not.  It replaces round 4's bound of 2 on ONE
-    draw.  Each slab is its own periodic volume on both sides (ctvlib.cpp:406-462)."""
+    its expectation.  Round 6 characterised the distribution ONCE, offline, instead of moving the bound after a
+    failing draw: tools/tv_ratio_distribution.py, 56 draws (the non-empty 64-slice slabs of eight SART-swept 512^3 x 90 states, eight
+    phantom seeds) -- median 1.22, geometric mean 1.41, log-sd 0.66, a heavy upper tail (5 of 56 above 4, one at 27: the chaos, not
+    the arithmetic; the oracle against itself from a one-ulp start scatters the same way) -- and the geometric mean of EIGHT such draws
+    (20,000 resamples): median 1.38, 90th percentile 1.92, 99th 2.69 (profiles/r06_tv_ratio_distribution.txt).  The bound is that 99th
+    percentile rounded up: 2.7.  An arithmetic systematically 2 x further from binary64 than the reference's would sit at a
+    geometric mean of ~2.8 and fail it; an unlucky set of slabs does so once in a hundred runs.  Each slab is its own periodic volume
+    on both sides (ctvlib.cpp:406-462)."""
     n = start.shape[1]
     ratios = []
     for f in firsts:

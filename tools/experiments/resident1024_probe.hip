@@ -139,7 +139,9 @@ int main(int argc, char **argv)
     const int N = argc > 1 ? atoi(argv[1]) : 1024, P = argc > 2 ? atoi(argv[2]) : 120;
     const int steps = argc > 3 ? atoi(argv[3]) : P, reps = argc > 4 ? atoi(argv[4]) : 3, mode = argc > 5 ? atoi(argv[5]) : 3;
     const float beta = 0.7f;
-    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    hipDeviceProp_t prop;
+    const bool host_only = hipGetDeviceProperties(&prop, 0) != hipSuccess;      // (no device: build and check the tables only)
+    if (host_only) { prop.multiProcessorCount = 256; std::snprintf(prop.name, sizeof(prop.name), "no device"); }
     const int tiles = N / T, ntiles = tiles * tiles;
     printf("%s: %d CUs; N %d P %d steps %d mode %d: %d tiles of %d x %d pixels x %d slices\n", prop.name, prop.multiProcessorCount, N, P, steps, mode, ntiles, T, T, SL);
     if (N % T || ntiles > prop.multiProcessorCount) { printf("needs N a multiple of %d and at most one tile per CU\n", T); return 1; }
@@ -163,7 +165,7 @@ int main(int argc, char **argv)
                     const int y = (k / tiles) * T + w * RPW + g, z = (k % tiles) * T + l;
                     const Cell &c = t.cell[(size_t)a * npix + (size_t)y * N + z];
                     if (c.w0 == 0.f && c.w1 == 0.f) continue;
-                    const int j0 = (int)c.r0 - a * N, j1 = c.w1 != 0.f ? (int)c.r1 - a * N : j0;
+                    const int j0 = (int)c.r0, j1 = c.w1 != 0.f ? (int)c.r1 : j0;      // (Cell::r0 / r1 count inside the angle)
                     wlo = std::min(wlo, j0); whi = std::max(whi, std::max(j1, j0 + 1));
                 }
                 whdr[((size_t)a * ntiles + k) * WAVES + w] = whi < 0 ? WHdr{-1, 0} : WHdr{wlo, whi - wlo + 1};
@@ -189,13 +191,14 @@ int main(int argc, char **argv)
                 q = PCell{std::max(h.jbase, wh.wbase), 0.f, 0.f, 1.f};       // any ray inside both windows: the weights are zero
             } else {
                 const float sum = c.w0 + c.w1;
-                q = PCell{(int32_t)c.r0 - a * N, c.w0, c.w1, 1.0f / sum};
+                q = PCell{(int32_t)c.r0, c.w0, c.w1, 1.0f / sum};
             }
             cells[(size_t)a * npix + p] = q;
         }
     }
     printf("widest tile window %d (limit %d), widest wave window %d (limit %d)\n", worst_win, MAXWIN, worst_wwin, WWIN);
     if (worst_win > MAXWIN || worst_wwin + 1 > WWIN) { printf("windows do not fit\n"); return 1; }
+    if (host_only) return 0;
     std::vector<float> x0(npix * SL), rows((size_t)P * N * SL);
     for (size_t i = 0; i < x0.size(); ++i) x0[i] = hashf(i, 1);
     for (size_t i = 0; i < rows.size(); ++i) rows[i] = 0.02f * (hashf(i, 2) - 0.5f);
