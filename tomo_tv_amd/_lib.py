@@ -4,6 +4,7 @@ There is no CPU fallback: if the HIP library is missing or fails to load, import
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtomo_hip.so")
@@ -153,6 +154,17 @@ def load():
         raise TomoError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C tomo_tv_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so) beside the system's, which this library links.  Both
+    # can live in one process only when torch's initialises FIRST: after this library has opened the device, a later `import torch`
+    # (the sharded classes import it lazily) finds "No HIP GPUs are available" (measured, round 6, ROCm 7.2 + torch 2.10+rocm7.0).
+    # So torch, where it is installed, is imported and asked for its device count before the library is opened; TOMO_TORCH_FIRST=0
+    # skips that (a host that never shards and wants to save the import).
+    if os.environ.get("TOMO_TORCH_FIRST", "1") != "0" and "torch" not in sys.modules:
+        try:
+            import torch
+            torch.cuda.device_count()
+        except Exception:  # noqa: BLE001 -- torch is optional: single-GPU use needs none of it
+            pass
     L = ctypes.CDLL(LIB_PATH)
     L.tomo_last_error.restype = ctypes.c_char_p
     L.tomo_last_error.argtypes = []

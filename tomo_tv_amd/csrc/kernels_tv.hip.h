@@ -417,7 +417,11 @@ inline unsigned tv_march_grid(int n, int tz, int nchunk, int nys)
 //   TVM_STORE   the round-1 form (g stored; k_tv_update applies it): kept for the A/B option and the other kernel forms.
 enum { TVM_STORE = 0, TVM_NORM = 1, TVM_UPDATE = 2, TVM_VALUE = 3 };   // TVM_VALUE (k_tv_march4 only): the TV value alone, no gradient
 struct TvUpd { float *x_out; const double *gnorm2; float dPOCS; int clamp; float *track; float *wrap_lo; float *wrap_hi;
-               int stream; };   // stream: non-temporal stores of x_new / the snapshot (slabs beyond the Infinity Cache: -3 %; thin slabs: +3 %)
+               int stream;      // stream: non-temporal stores of x_new / the snapshot (slabs beyond the Infinity Cache: -3 %; thin slabs: +3 %)
+               // slab-sharded descent (round 6): the update pass also advances the halo planes -- the neighbours' update of the slices they
+               // hold, k_halo_apply's expression on the gradient planes received from them -- into a SECOND pair of planes (this pass still
+               // reads the old ones), instead of one more launch per inner iteration (k_tv_march4 only; null = not asked for)
+               const float *hg_lo; const float *hg_hi; float *ho_lo; float *ho_hi; };
 
 template <int TZ, bool WITH_TV, bool GRAD = true, int MODE = TVM_STORE>
 __global__ __launch_bounds__(256) void k_tv_grad_reg(const float *__restrict__ x, Halo h, float *__restrict__ g,
@@ -862,6 +866,18 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 if (s == nx - 1) {
 #pragma unroll
                     for (int j = 1; j <= TZ; ++j) if (!EDGE || z0 + j - 1 < n) up.wrap_lo[pix0 + (j - 1)] = out[j];
+                }
+            }
+            if (MODE == TVM_UPDATE && up.hg_lo != nullptr && (EDGE || s0 == 0 || s0 + 64 == nx)) {
+                if (s == 0) {
+#pragma unroll
+                    for (int j = 1; j <= TZ; ++j)
+                        if (!EDGE || z0 + j - 1 < n) up.ho_lo[pix0 + (j - 1)] = fmaxf(tv_step(h.lo[pix0 + (j - 1)], up.hg_lo[pix0 + (j - 1)], nrm_), vmin);
+                }
+                if (s == nx - 1) {
+#pragma unroll
+                    for (int j = 1; j <= TZ; ++j)
+                        if (!EDGE || z0 + j - 1 < n) up.ho_hi[pix0 + (j - 1)] = fmaxf(tv_step(h.hi[pix0 + (j - 1)], up.hg_hi[pix0 + (j - 1)], nrm_), vmin);
                 }
             }
 #ifdef TV4_WHATIF_FUSED

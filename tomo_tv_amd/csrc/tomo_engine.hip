@@ -137,6 +137,7 @@ struct tomo_engine {
     int tv_recompute = 1, tv_tz = 8;              // tv_tz: z-columns per wave of the register march (8 or 4)
     int tv_yseg = 0;                              // rows per wave of the register march; 0 = by slab size (tv_rows_per_wave)
     int tv_march4 = 1;                            // norm / update passes by k_tv_march4 (no row rotation) instead of k_tv_grad_reg
+    int tv_halo_fold = 1;                         // slab-sharded descent: the update pass advances the halo planes itself (no k_halo_apply launch)
     int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
     double *gnorm_override = nullptr;             // tomo_comm_tv_gd: the all-reduced sum g^2 (the slot itself keeps the slab's partial sum)
     hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
@@ -2709,8 +2710,11 @@ int tomo_tv_halo_apply(tomo_engine *e, float dPOCS, int clamp, const void *g_lo,
 
 // wrap: also write the new last / first slice into the engine's halo planes (single slab, periodic); plane_last /
 // plane_first: into caller buffers instead (slab-sharded: the planes the ring exchange sends next)
+// hg_lo / hg_hi (slab-sharded descent): the gradient planes received from the ring neighbours; the halo planes are advanced with them
+// (k_halo_apply's expression) -- inside the update pass where it can write a second pair of planes ("tv_halo_fold", the march4 form, the
+// engine's own planes), by a k_halo_apply launch behind it otherwise
 static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol, int slot, bool wrap = false,
-                          float *plane_last = nullptr, float *plane_first = nullptr)
+                          float *plane_last = nullptr, float *plane_first = nullptr, const float *hg_lo = nullptr, const float *hg_hi = nullptr)
 {
     NEED(e);
     float *x, *g, *track = nullptr; int rc;
@@ -2742,7 +2746,17 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
             wh = e->halo_hi == e->halo_hi_own ? e->halo_hi_alt : e->halo_hi_own;
         }
         Halo h{e->halo_lo, e->halo_hi};
-        TvUpd up{alt, gnorm_ptr(e), dPOCS, clamp, track, wl, wh, slab_streams(e) ? 1 : 0};
+        TvUpd up{alt, gnorm_ptr(e), dPOCS, clamp, track, wl, wh, slab_streams(e) ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
+        const bool fold = hg_lo && hg_hi && e->tv_halo_fold && own_halo && !wrap && e->tv_tz != 4 && e->tv_march4;
+        if (fold) {
+            if (!e->halo_lo_alt) {
+                if ((rc = dev_alloc((void **)&e->halo_lo_alt, e->npix * sizeof(float), true, e->stream))) return rc;
+                if ((rc = dev_alloc((void **)&e->halo_hi_alt, e->npix * sizeof(float), true, e->stream))) return rc;
+            }
+            up.hg_lo = hg_lo; up.hg_hi = hg_hi;
+            up.ho_lo = e->halo_lo == e->halo_lo_own ? e->halo_lo_alt : e->halo_lo_own;
+            up.ho_hi = e->halo_hi == e->halo_hi_own ? e->halo_hi_alt : e->halo_hi_own;
+        }
         {
             ProfScope ps(e, TOMO_K_TV_UPDATE);
             const int yseg = tv_rows_per_wave(e, e->tv_tz == 4 ? 4 : 8);
@@ -2765,6 +2779,8 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
         e->vol[e->tv_target] = alt; e->tv_alt = x;              // the updated volume lives in the partner buffer
         if (wrap && own_halo) { e->halo_lo = wl; e->halo_hi = wh; }
         else if (wrap) { if ((rc = tomo_halo_local(e, e->tv_target))) return rc; }
+        if (fold) { e->halo_lo = up.ho_lo; e->halo_hi = up.ho_hi; }
+        else if (hg_lo && hg_hi && (rc = tomo_tv_halo_apply(e, dPOCS, clamp, hg_lo, hg_hi))) return rc;
         return track ? reduce_end(e, slot) : TOMO_OK;
     }
     int64_t n4 = e->vol_elems() / 4;
@@ -2775,6 +2791,7 @@ static int tv_update_impl(tomo_engine *e, float dPOCS, int clamp, int track_vol,
         else hipLaunchKernelGGL(k_tv_update<false>, dim3(grid_1d(n4)), dim3(256), 0, e->stream, (f4 *)x, (const f4 *)g, gnorm_ptr(e), dPOCS, clamp, n4, (f4 *)nullptr, (double *)nullptr, wl, wh, e->nx, e->sx / 4);
     }
     LAUNCHCHK();
+    if (hg_lo && hg_hi && (rc = tomo_tv_halo_apply(e, dPOCS, clamp, hg_lo, hg_hi))) return rc;
     return track ? reduce_end(e, slot) : TOMO_OK;
 }
 
@@ -3204,9 +3221,8 @@ int tomo_comm_exchange_halo(tomo_engine *e, int field)
 static int comm_sum_scalars(tomo_engine *e)
 {
     { int rc = tomo_async_wait(e); if (rc) return rc; }
-    HIPCHK(hipMemcpyAsync(e->comm_scal, e->d_scal, TOMO_S_COUNT * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    ++e->comm_rounds;
-    NCCLCHK(g_rccl.AllReduce(e->comm_scal, e->comm_scal, TOMO_S_COUNT, ncclFloat64, ncclSum, e->comm->comm, e->stream));
+    ++e->comm_rounds;       // (out of place: the copy into comm_scal that an in-place all-reduce needed is one launch less per step)
+    NCCLCHK(g_rccl.AllReduce(e->d_scal, e->comm_scal, TOMO_S_COUNT, ncclFloat64, ncclSum, e->comm->comm, e->stream));
     return TOMO_OK;
 }
 
@@ -3265,8 +3281,8 @@ int tomo_comm_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps, int track_vo
         if (g == ng - 1) {
             rc = track_vol >= 0 ? tomo_tv_update_tracked(e, dPOCS, 1, track_vol, slot) : tomo_tv_update(e, dPOCS, 1);
         } else {
-            rc = tomo_tv_update(e, dPOCS, 0);                                                    // reads the old halo planes ...
-            if (!rc) rc = tomo_tv_halo_apply(e, dPOCS, 0, e->comm_g_lo, e->comm_g_hi);          // ... which then follow the neighbours
+            // the update reads the old halo planes, which then follow the neighbours (inside the pass: a second pair of planes)
+            rc = tv_update_impl(e, dPOCS, 0, -1, 0, false, nullptr, nullptr, e->comm_g_lo, e->comm_g_hi);
         }
         e->gnorm_override = nullptr;
         if (rc) return rc;
@@ -3360,6 +3376,7 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
         e->gnorm_slot = value; return TOMO_OK;
     }
     if (std::strcmp(name, "tv_tz") == 0) { e->tv_tz = value == 4 ? 4 : 8; return TOMO_OK; }
+    if (std::strcmp(name, "tv_halo_fold") == 0) { e->tv_halo_fold = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_march4") == 0) { e->tv_march4 = value ? 1 : 0; return TOMO_OK; }
     if (std::strcmp(name, "tv_yseg") == 0) { e->tv_yseg = value < 0 ? 0 : value; return TOMO_OK; }
     if (std::strcmp(name, "tv_recompute") == 0) { e->tv_recompute = value ? 1 : 0; return TOMO_OK; }
