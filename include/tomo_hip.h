@@ -219,10 +219,17 @@ int tomo_fgp_end(tomo_engine *e, int iters);                            /* :272 
  * begin (A) and by every step (P) -- the caller exchanges send_last -> next.lo and send_first -> prev.hi before each
  * step and before end (tv_fgp.cu:57,81 need exactly these neighbours; mpi_ctvlib.cpp:400-422 is the reference ring). */
 int tomo_bind_fgp_halo(tomo_engine *e, void *lo, void *hi, void *send_first, void *send_last);
+/* The two-slice-deep set, for TWO fused iterations per pass on slabs (round 6; tv_fgp.cu:57,81 name the neighbours): lo 5 planes
+ * [P1(-1), A(-1), P2(-1), P3(-1), P1(-2)], hi 8 planes [A, P1, P2, P3](nx), [A, P1, P2, P3](nx + 1), send_first 8 planes (my slices
+ * 0 and 1: [A, P1, P2, P3] each), send_last 5 planes [P1(nx-1), A(nx-1), P2(nx-1), P3(nx-1), P1(nx-2)].  The one-deep planes above
+ * are the prefixes (1 / 4 / 4 / 1 planes), so tomo_fgp_fused_step and _end run on the same buffers. */
+int tomo_bind_fgp_halo2(tomo_engine *e, void *lo, void *hi, void *send_first, void *send_last);
 int tomo_fgp_fused_begin(tomo_engine *e, int vol);
 int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration);
 int tomo_fgp_fused_step2(tomo_engine *e, float lambda, int first_iteration);   /* TWO iterations in one pass (P stays on chip between
-                                                                                * them; the same bits as two steps); whole-volume slabs only */
+                                                                                * them; the same bits as two steps).  On a slab of a sharded
+                                                                                * volume: tomo_bind_fgp_halo2, one two-deep exchange before
+                                                                                * it, at least two slices on every slab of the ring */
 int tomo_fgp_fused_end(tomo_engine *e, float lambda);                   /* the last iteration: D over the input volume */
 int tomo_fgp_fused_last(tomo_engine *e, float lambda, int first_iteration);   /* one more step AND the end in one pass (the same bits);
                                                                                * whole-volume slabs only */
@@ -364,6 +371,8 @@ int tomo_comm_scalars_snapshot(tomo_engine *e);
 int tomo_comm_tv_gd(tomo_engine *e, int ng, float dPOCS, float eps, int track_vol, int slot);
 /* the plane exchange between two fused FGP iterations (buffers of tomo_bind_fgp_halo) */
 int tomo_comm_fgp_exchange(tomo_engine *e);
+/* ... and before a PAIR of them (tomo_fgp_fused_step2 on slabs): the two-slice-deep planes of tomo_bind_fgp_halo2, one round per two iterations */
+int tomo_comm_fgp_exchange2(tomo_engine *e);
 
 /* launch chains a SART / ART sweep of this engine's slab runs as under the current "sart_streams" (1 = one chain on the
  * engine's stream; 2..4 = that many sub-slabs of 64-slice chunks on their own streams).  What the reference hides inside

@@ -61,8 +61,9 @@ class OracleSlabBackend:
     def enable_torch(self):
         self.tdev = "cpu"
         npix = self.nray * self.nray
-        self.fgp_lo, self.fgp_hi = torch.zeros(npix), torch.zeros(4 * npix)
-        self.fgp_send_first, self.fgp_send_last = torch.zeros(4 * npix), torch.zeros(npix)
+        # the two-slice-deep set (include/tomo_hip.h: tomo_bind_fgp_halo2); the one-deep planes are the prefixes
+        self.fgp_lo, self.fgp_hi = torch.zeros(5 * npix), torch.zeros(8 * npix)
+        self.fgp_send_first, self.fgp_send_last = torch.zeros(8 * npix), torch.zeros(5 * npix)
 
     def scalar_tensor(self, slot):
         return self.scal[slot:slot + 1]
@@ -73,8 +74,11 @@ class OracleSlabBackend:
     def tensor(self, values, dtype=None):
         return torch.tensor(values, dtype=dtype or torch.float64)
 
-    def fgp_planes(self):
-        return self.fgp_send_first, self.fgp_send_last, self.fgp_lo, self.fgp_hi
+    def fgp_planes(self, deep=False):
+        if deep:
+            return self.fgp_send_first, self.fgp_send_last, self.fgp_lo, self.fgp_hi
+        npix = self.nray * self.nray
+        return self.fgp_send_first[:4 * npix], self.fgp_send_last[:npix], self.fgp_lo[:npix], self.fgp_hi[:4 * npix]
 
     def c_async_wait(self):
         pass
@@ -265,7 +269,11 @@ class OracleSlabBackend:
     def c_fgp_fused_begin(self, vid):
         self.c_fgp_begin_vol(vid)
         n = self.nray
-        self.fgp_send_first[:n * n] = torch.from_numpy(self._v(vid)[0].ravel().copy())
+        A = self._v(vid)
+        self.fgp_send_first[:n * n] = torch.from_numpy(A[0].ravel().copy())
+        if A.shape[0] >= 2:                                  # the deep set: A of slice 1 and of the last slice
+            self.fgp_send_first[4 * n * n:5 * n * n] = torch.from_numpy(A[1].ravel().copy())
+            self.fgp_send_last[n * n:2 * n * n] = torch.from_numpy(A[-1].ravel().copy())
 
     def _fgp_obj_with(self, lo_plane):
         keep = self.halo_lo
@@ -278,8 +286,8 @@ class OracleSlabBackend:
         self._lam = lam
         P1, P2, P3 = self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"]
         # D of the slab (P1 of the slice below from the lo plane; the first iteration knows P = 0 and reads no plane)
-        self._fgp_obj_with(torch.zeros_like(self.fgp_lo) if first_iteration else self.fgp_lo)
-        hi = self.fgp_hi.numpy().reshape(4, n, n)
+        self._fgp_obj_with(torch.zeros(n * n) if first_iteration else self.fgp_lo[:n * n])
+        hi = self.fgp_hi[:4 * n * n].numpy().reshape(4, n, n)
         a, p1, p2, p3 = hi[0], hi[1], hi[2], hi[3]
         if first_iteration:
             p1 = p2 = p3 = np.zeros((n, n), F)
@@ -291,13 +299,61 @@ class OracleSlabBackend:
         self.c_fgp_grad(lam)
         self.halo_hi = keep
         P1, P2, P3 = self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"]
-        sf = self.fgp_send_first.numpy().reshape(4, n, n)
+        sf = self.fgp_send_first.numpy().reshape(8, n, n)
         sf[1], sf[2], sf[3] = P1[0], P2[0], P3[0]
-        self.fgp_send_last[:] = torch.from_numpy(P1[-1].ravel().copy())
+        self.fgp_send_last[:n * n] = torch.from_numpy(P1[-1].ravel().copy())
+
+    def c_fgp_fused_step2(self, lam, first_iteration):
+        """TWO iterations on the slab extended by the two-slice-deep planes (tomo_fgp_fused_step2 on slabs): the same Obj / Grad
+        expressions on the extended block, whose outermost cells are wrong after each iteration and never used."""
+        n, F = self.nray, np.float32
+        A = self._v(self.fgp_target)
+        nx = A.shape[0]
+        P = [self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"]]
+        lo = self.fgp_lo.numpy().reshape(5, n, n)
+        hi = self.fgp_hi.numpy().reshape(8, n, n)
+        zero = np.zeros((1, n, n), F)
+        below = 0 if self.first_edge else 2
+        above = 0 if self.last_edge else 2
+        parts_a, parts_p = [], [[], [], []]
+        if below:
+            parts_a += [zero, lo[1:2]]                                   # A(-2) is never used; A(-1)
+            for k, (m2, m1) in enumerate(((lo[4:5], lo[0:1]), (zero, lo[2:3]), (zero, lo[3:4]))):
+                parts_p[k] += [m2, m1] if not first_iteration else [zero, zero]
+        parts_a.append(A)
+        for k in range(3):
+            parts_p[k].append(P[k])
+        if above:
+            parts_a += [hi[0:1], hi[4:5]]
+            for k in range(3):
+                parts_p[k] += [hi[1 + k:2 + k], hi[5 + k:6 + k]] if not first_iteration else [zero, zero]
+        Ae = np.concatenate(parts_a, axis=0).astype(F)
+        Pe = [np.concatenate(parts_p[k], axis=0).astype(F) for k in range(3)]
+        keep = (self.vol, self.fields, self.first_edge, self.last_edge, self.fgp_target)
+        try:
+            # run the block as if it were a whole volume (its own ends are edges: that is what makes the outermost cells wrong)
+            self.vol = {VOL_RECON: Ae}
+            self.fgp_target = VOL_RECON
+            self.fields = {FIELD_FGP_D: np.zeros_like(Ae), FIELD_FGP_P1: Pe[0], "P2": Pe[1], "P3": Pe[2]}
+            self.first_edge = self.last_edge = True
+            for _ in range(2):
+                self.c_fgp_obj(lam)
+                self.c_fgp_grad(lam)
+            out = [self.fields[FIELD_FGP_P1][below:below + nx], self.fields["P2"][below:below + nx], self.fields["P3"][below:below + nx]]
+        finally:
+            self.vol, self.fields, self.first_edge, self.last_edge, self.fgp_target = keep
+        self.fields[FIELD_FGP_P1], self.fields["P2"], self.fields["P3"] = (np.ascontiguousarray(o) for o in out)
+        P1, P2, P3 = out
+        sf = self.fgp_send_first.numpy().reshape(8, n, n)
+        sf[1], sf[2], sf[3] = P1[0], P2[0], P3[0]
+        sf[5], sf[6], sf[7] = P1[1], P2[1], P3[1]
+        sl = self.fgp_send_last.numpy().reshape(5, n, n)
+        sl[0], sl[2], sl[3], sl[4] = P1[-1], P2[-1], P3[-1], P1[-2]
 
     def c_fgp_fused_end(self, lam):
         self._lam = lam
-        self._fgp_obj_with(self.fgp_lo)
+        n = self.nray
+        self._fgp_obj_with(self.fgp_lo[:n * n])
         self._v(self.fgp_target)[:] = self.fields[FIELD_FGP_D]
 
     # ---- generic slots + multimodal primitives (tests/test_distributed_gloo.py::test_sharded_multimodal) -----

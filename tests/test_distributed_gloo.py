@@ -270,3 +270,55 @@ def test_engine_with_comm_lives_on_the_ranks_current_device(monkeypatch):
     del seen[:]
     MM(8, 16, 2, np.zeros(3), np.zeros(4), device=None, comm=comm)
     assert seen == [5, 5]
+
+
+def _fgp_pair_worker(rank, world, port, Nx, ng, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from slab_double import OracleSlabBackend
+        from tomo_tv_amd import engine
+        from tomo_tv_amd.distributed import SlabComm
+        from tomo_tv_amd.phantom import ellipsoids
+
+        class ShardedEngine(engine.tomoengine):
+            _backend_cls = OracleSlabBackend
+
+        N, P = 16, 5
+        ang = np.linspace(-65, 65, P)
+        rng = np.random.default_rng(3)
+        x = (ellipsoids(Nx, N, seed=21) + np.float32(0.05) * rng.random((Nx, N, N), dtype=np.float32)).astype(np.float32)
+        vols, tvs = [], []
+        for pair in (False, True):
+            t = ShardedEngine(Nx, N, ang * np.pi / 180, comm=SlabComm())
+            t.fgp_pair = pair
+            t.set_volume(x)
+            tvs.append(t.tv_fgp(ng, 0.05))
+            vols.append(t.get_volume())
+        full = oracle.ctvlib(Nx, N, P)
+        full.recon[:] = x
+        full.tv_fgp(ng, 0.05)
+        if rank == 0:
+            np.savez(out_path, one=vols[0], two=vols[1], tvs=np.array(tvs), ref=full.recon)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Nx,ng", [(2, 6, 5), (2, 7, 6), (3, 8, 4)])
+def test_two_fgp_iterations_per_exchange_equal_one(tmp_path, world, Nx, ng):
+    """The sharded FGP with TWO iterations per pass and exchange (two-slice-deep planes: engine.tomoengine.tv_fgp, round 6) against one
+    per pass, over gloo: bit-identical volumes (the per-slab arithmetic is tests/slab_double.py; what is under test is the protocol:
+    which planes travel, in which order, how deep), and equal to the single-process oracle."""
+    out = str(tmp_path / "fgp.npz")
+    mp.spawn(_fgp_pair_worker, args=(world, _free_port(), Nx, ng, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert r["tvs"][0] == r["tvs"][1]
+    assert np.array_equal(r["one"].view(np.uint32), r["two"].view(np.uint32))
+    assert np.allclose(r["two"], r["ref"], rtol=0, atol=2e-6)

@@ -465,3 +465,32 @@ def test_two_gpus_in_one_plain_process(gpu):
     a, b = many.tomo.get_volume(), one.tomo.get_volume()
     assert rel_l2(a, b) < 2e-6
     many.tomo.close()
+
+
+@pytest.mark.parametrize("world,nx,ng", [(2, 11, 5), (3, 11, 6), (3, 150, 7), (2, 130, 4), (2, 4, 6), (4, 70, 9)])
+def test_two_fgp_iterations_per_pass_on_slabs_equal_one_per_pass(gpu, world, nx, ng):
+    """k_fgp_fused2 on slabs (two-slice-deep halo planes, ONE exchange per two iterations) against the
+    one-iteration-per-pass sharded form: bit-identical, on even and uneven slabs, slabs of two slices, odd and even counts (the odd
+    iteration out runs as k_fgp_fused, the last as k_fgp_obj); and against the whole slab / the oracle to their usual bounds.
+    Reference: tv_fgp.cu:44-115 (Obj / Grad / Proj), :57,81 (the slice neighbours), mpi_ctvlib.cpp:400-422 (the ring)."""
+    n = 32
+    ang = np.deg2rad(np.linspace(-60, 60, 5))
+    x = noisy_phantom(nx, n, seed=7)
+
+    def script(pair):
+        def run(t):
+            t.fgp_pair = pair
+            return {"tv": t.tv_fgp(ng, 0.05), "vol": t.get_volume()}
+        return run
+    one = run_sharded(world, nx, n, ang, x, script(False))
+    two = run_sharded(world, nx, n, ang, x, script(True))
+    assert one["tv"] == two["tv"]
+    assert np.array_equal(one["vol"].view(np.uint32), two["vol"].view(np.uint32))
+    whole = tomoengine(nx, n, ang, device=0)
+    whole.set_volume(x, VOL_RECON)
+    whole.tv_fgp(ng, 0.05)
+    assert rel_l2(two["vol"], whole.get_volume()) < 2e-6
+    ref = oracle.ctvlib(nx, n, 5)
+    ref.recon[:] = x
+    ref.tv_fgp(ng, 0.05)
+    assert rel_l2(two["vol"], ref.recon) < 1e-5

@@ -114,6 +114,7 @@ SIGNATURES = {
     "tomo_fgp_begin_vol": [_p, _i],
     "tomo_tv_fgp_vol": [_p, _i, _i, _f],
     "tomo_bind_fgp_halo": [_p, _p, _p, _p, _p],
+    "tomo_bind_fgp_halo2": [_p, _p, _p, _p, _p],
     "tomo_fgp_fused_begin": [_p, _i],
     "tomo_fgp_fused_step": [_p, _f, _i],
     "tomo_fgp_fused_step2": [_p, _f, _i],
@@ -133,6 +134,7 @@ SIGNATURES = {
     "tomo_comm_scalars_snapshot": [_p],
     "tomo_comm_tv_gd": [_p, _i, _f, _f, _i, _i],
     "tomo_comm_fgp_exchange": [_p],
+    "tomo_comm_fgp_exchange2": [_p],
     "tomo_profile_enable": [_p, _i, _i],
     "tomo_profile_read": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
     "tomo_profile_read2": [_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],

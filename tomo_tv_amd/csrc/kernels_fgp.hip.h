@@ -241,12 +241,28 @@ constexpr int F2_TZ = F2_TZ_V, F2_R = F2_TZ + 4, F2_SC = F2_SC_V, F2_S = F2_SC +
 // FINAL: the call's last pass -- one iteration and then D = max(0, A - lambda div P) of the result, which is all the last iteration
 // of tv_fgp.cu needs (:272): D^(k+1) of the tile goes to P1o (a scratch volume: A's halo cells are other tiles' outputs, so the
 // result cannot land on A in place; the engine swaps the buffers), P^(k+1) is never stored.
-template <bool FINAL>
+//
+// SHARDED (round 6): the slab-sharded form.  Two iterations reach two slices across an interior slab face -- P^(k+2)(s) <- D^(k+1)(s),
+// D^(k+1)(s+1) <- P^(k+1)(s-1 .. s+1) <- D^k(s-1 .. s+2) <- P^k(s-2 .. s+2), A(s-1 .. s+2) -- so the halo is two slices deep and is
+// exchanged once per TWO iterations (tv_fgp.cu:57,81 name the neighbours; mpi_ctvlib.cpp:400-422 the ring):
+//   lo  (5 planes, from the slab below)   [P1(-1), A(-1), P2(-1), P3(-1), P1(-2)]
+//   hi  (8 planes, from the slab above)   [A, P1, P2, P3](nx), [A, P1, P2, P3](nx + 1)
+//   send_first (8 planes, my slices 0, 1) [A, P1, P2, P3](0), [A, P1, P2, P3](1)             -> the lower neighbour's hi
+//   send_last  (5 planes)                 [P1(nx-1), A(nx-1), P2(nx-1), P3(nx-1), P1(nx-2)]  -> the upper neighbour's lo
+// The planes the one-iteration form k_fgp_fused uses (P1(-1); [A, P1, P2, P3](nx); its send planes) are the PREFIXES of these, so one
+// set of buffers serves both.  The pass stores the P planes of its send buffers (the A planes are packed once per call).  Every slab
+// must hold at least two slices (the host checks); the halo cells are recomputed here, like the tile's own ring, by the same helpers
+// on the same operands: bit-identical to two one-iteration passes with an exchange between them.
+struct Fgp2Edge { const float *lo; const float *hi; float *send_first; float *send_last; int first, last; };
+
+template <bool FINAL, bool SHARDED = false>
 __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A, const float *__restrict__ P1i,
                                                      const float *__restrict__ P2i, const float *__restrict__ P3i,
                                                      float *__restrict__ P1o, float *__restrict__ P2o, float *__restrict__ P3o,
-                                                     float lambda, float multip, int n, int nx, int sx, int yseg, int zero_p)
+                                                     float lambda, float multip, int n, int nx, int sx, int yseg, int zero_p,
+                                                     Fgp2Edge ed = Fgp2Edge{})
 {
+    static_assert(!(FINAL && SHARDED), "the sharded odd iteration out runs as k_fgp_fused + k_fgp_obj");
     constexpr int PL = F2_R * F2_S;                     // a staged plane: element zi * F2_S + si
     __shared__ float pk[3][2][PL];                      // P^k, rows r (slot r & 1)
     __shared__ float ak[2][PL];                         // A
@@ -275,14 +291,26 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
     constexpr int NP = (F2_R - 2) * (F2_S - 2), RP = (NP + 255) / 256;
     constexpr int NN = (F2_R - 3) * (F2_S - 3), RN = (NN + 255) / 256;
     static_assert(F2_TZ * F2_SC == 256, "one output per thread and row");
-    int eo[NT]; size_t eg[NT]; bool einv[NT];           // staged element: plane offset (-1: none), offset in a volume row, inside in z and s
+    // staged element: plane offset (-1: none); where it comes from (ek: 0 the volume, 1 / 2 the slices -1 / -2 of the slab below,
+    // 3 / 4 the slices nx / nx + 1 of the slab above, -1 outside the global volume: zero); its offset in a volume row or its column
+    int eo[NT]; size_t eg[NT]; int ek[NT];
+    const size_t npix = (size_t)n * n;
+    const bool lo_face = SHARDED && !ed.first, hi_face = SHARDED && !ed.last;      // interior slab faces
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int e = tid + 256 * t, zi = e / F2_S, si = e - zi * F2_S;
         const int z = z0 - 2 + zi, s = s0 - 2 + si;
         eo[t] = e < PL ? e : -1;
-        einv[t] = e < PL && z >= 0 && z < n && s >= 0 && s < nx;
-        eg[t] = einv[t] ? (size_t)z * sx + s : 0;
+        int kind = -1;
+        if (e < PL && z >= 0 && z < n) {
+            if (s >= 0 && s < nx) kind = 0;
+            else if (lo_face && s == -1) kind = 1;
+            else if (lo_face && s == -2) kind = 2;
+            else if (hi_face && s == nx) kind = 3;
+            else if (hi_face && s == nx + 1) kind = 4;
+        }
+        ek[t] = kind;
+        eg[t] = kind == 0 ? (size_t)z * sx + s : (kind > 0 ? (size_t)z : 0);
     }
     int od[RD], op[RP], on[RN];
     unsigned pf_[RP];                                   // P^(k+1) element: bit 0 inside the volume in z and s, bit 1 s+1 < nx, bit 2 z+1 < n
@@ -293,13 +321,17 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
         const int e = tid + 256 * r, zq = e / (F2_S - 2), zi = zq + 1, si = e - zq * (F2_S - 2) + 1;
         const int z = z0 - 2 + zi, s = s0 - 2 + si;
         op[r] = e < NP ? zi * F2_S + si : -1;
-        pf_[r] = (z >= 0 && z < n && s >= 0 && s < nx ? 1u : 0u) | (s + 1 < nx ? 2u : 0u) | (z + 1 < n ? 4u : 0u);
+        // (sharded: slice -1 of the slab below and slice nx of the slab above are cells of the global volume too, and their upper
+        // neighbours exist -- every slab holds at least two slices)
+        const bool s_in = (s >= 0 && s < nx) || (lo_face && s == -1) || (hi_face && s == nx);
+        const bool s_up = s + 1 < nx || (hi_face && s + 1 <= nx + 1);
+        pf_[r] = (z >= 0 && z < n && s_in ? 1u : 0u) | (s_up ? 2u : 0u) | (z + 1 < n ? 4u : 0u);
     }
 #pragma unroll
     for (int r = 0; r < RN; ++r) { const int e = tid + 256 * r, zq = e / (F2_S - 3); on[r] = e < NN ? (zq + 2) * F2_S + (e - zq * (F2_S - 3)) + 2 : -1; }
     const int ozi = 2 + tid / F2_SC, osi = 2 + tid % F2_SC, oo = ozi * F2_S + osi;
     const int oz = z0 - 2 + ozi, os = s0 - 2 + osi;
-    const bool oin = oz < n && os < nx, os1 = os + 1 < nx, oz1 = oz + 1 < n;
+    const bool oin = oz < n && os < nx, os1 = os + 1 < nx || hi_face, oz1 = oz + 1 < n;
     const size_t og = (size_t)oz * sx + os;
     float rg[4][NT];
     auto fetch = [&](int y) {
@@ -307,12 +339,26 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
         const size_t row = yin ? (size_t)y * n * sx : 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const bool ok = yin && einv[t];
+            const bool ok = yin && ek[t] == 0;
             const size_t o = row + eg[t];
             rg[0][t] = (ok && !zero_p) ? P1i[o] : 0.f;
             rg[1][t] = (ok && !zero_p) ? P2i[o] : 0.f;
             rg[2][t] = (ok && !zero_p) ? P3i[o] : 0.f;
             rg[3][t] = ok ? A[o] : 0.f;
+            if (SHARDED && yin && ek[t] > 0) {          // a cell of a neighbouring slab: from the exchanged planes
+                const size_t pix = (size_t)y * n + eg[t];
+                const int kd = ek[t];
+                if (kd == 1) {
+                    rg[3][t] = ed.lo[npix + pix];
+                    if (!zero_p) { rg[0][t] = ed.lo[pix]; rg[1][t] = ed.lo[2 * npix + pix]; rg[2][t] = ed.lo[3 * npix + pix]; }
+                } else if (kd == 2) {
+                    if (!zero_p) rg[0][t] = ed.lo[4 * npix + pix];          // only P1(-2) is ever used (by D^k(-1))
+                } else {
+                    const float *hp = ed.hi + (kd == 3 ? 0 : 4) * npix + pix;
+                    rg[3][t] = hp[0];
+                    if (!zero_p) { rg[0][t] = hp[npix]; rg[1][t] = hp[2 * npix]; rg[2][t] = hp[3 * npix]; }
+                }
+            }
         }
     };
     auto stash = [&](int par) {
@@ -400,6 +446,13 @@ __global__ __launch_bounds__(256) void k_fgp_fused2(const float *__restrict__ A,
             fgp_p_of(a, b, c, multip, v1, v2, v3);
             const size_t o = (size_t)y * n * sx + og;
             nt_st<256>(a, P1o + o); nt_st<256>(b, P2o + o); nt_st<256>(c, P3o + o);
+            if (SHARDED) {                              // what the next exchange sends (either depth)
+                const size_t pix = (size_t)y * n + oz;
+                if (os == 0) { ed.send_first[npix + pix] = a; ed.send_first[2 * npix + pix] = b; ed.send_first[3 * npix + pix] = c; }
+                if (os == 1) { ed.send_first[5 * npix + pix] = a; ed.send_first[6 * npix + pix] = b; ed.send_first[7 * npix + pix] = c; }
+                if (os == nx - 1) { ed.send_last[pix] = a; ed.send_last[2 * npix + pix] = b; ed.send_last[3 * npix + pix] = c; }
+                if (os == nx - 2) ed.send_last[4 * npix + pix] = a;
+            }
         }
         // (the next iteration's stash / D^k / P^(k+1) phases write slots this phase does not read; its D^(k+1) phase, which does,
         // comes behind three barriers)

@@ -305,6 +305,7 @@ struct tomo_engine {
     float *halo_lo = nullptr, *halo_hi = nullptr, *halo_lo_own = nullptr, *halo_hi_own = nullptr;
     // planes of the fused slab-sharded FGP iteration (caller-owned device buffers, tomo_bind_fgp_halo)
     float *fgp_lo = nullptr, *fgp_hi = nullptr, *fgp_send_first = nullptr, *fgp_send_last = nullptr;
+    bool fgp_planes2 = false;                     // the bound planes are the two-slice-deep set (5 / 8 / 8 / 5 planes: tomo_bind_fgp_halo2)
     int is_first = 1, is_last = 1;
     ProfSlot prof[PROF_MAX_KERNELS];
     std::mutex prof_mu;
@@ -2908,6 +2909,18 @@ int tomo_bind_fgp_halo(tomo_engine *e, void *lo, void *hi, void *send_first, voi
     if (!lo || !hi || !send_first || !send_last) return fail(TOMO_ERR_ARG, "null plane buffer");
     HIPCHK(hipStreamSynchronize(e->stream));
     e->fgp_lo = (float *)lo; e->fgp_hi = (float *)hi; e->fgp_send_first = (float *)send_first; e->fgp_send_last = (float *)send_last;
+    e->fgp_planes2 = false;
+    return TOMO_OK;
+}
+
+// the two-slice-deep set (k_fgp_fused2<.., SHARDED>): lo 5 planes [P1(-1), A(-1), P2(-1), P3(-1), P1(-2)], hi 8 planes
+// [A, P1, P2, P3](nx), [..](nx + 1), send_first 8 planes [A, P1, P2, P3](0), [..](1), send_last 5 planes [P1(nx-1), A(nx-1), P2(nx-1),
+// P3(nx-1), P1(nx-2)].  The one-deep planes of tomo_bind_fgp_halo are the prefixes (1 / 4 / 4 / 1), so both step forms run on it.
+int tomo_bind_fgp_halo2(tomo_engine *e, void *lo, void *hi, void *send_first, void *send_last)
+{
+    int rc = tomo_bind_fgp_halo(e, lo, hi, send_first, send_last);
+    if (rc) return rc;
+    e->fgp_planes2 = true;
     return TOMO_OK;
 }
 
@@ -2925,6 +2938,11 @@ int tomo_fgp_fused_begin(tomo_engine *e, int vol)
         // plane 0 of send_first: the first slice of the prox input (constant over the call)
         hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, e->vol[vol], e->fgp_send_first, (int)e->npix, e->sx, 0);
         LAUNCHCHK();
+        if (e->fgp_planes2 && e->nx >= 2) {      // the deep set: A of slice 1 (send_first plane 4) and of the last slice (send_last plane 1)
+            hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, e->vol[vol], e->fgp_send_first + 4 * e->npix, (int)e->npix, e->sx, 1);
+            hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((e->npix + 255) / 256)), dim3(256), 0, e->stream, e->vol[vol], e->fgp_send_last + e->npix, (int)e->npix, e->sx, e->nx - 1);
+            LAUNCHCHK();
+        }
     }
     return TOMO_OK;
 }
@@ -2955,20 +2973,27 @@ int tomo_fgp_fused_step(tomo_engine *e, float lambda, int first_iteration)
     return TOMO_OK;
 }
 
-// two iterations in one pass (k_fgp_fused2: P stays on chip between them; single slab only -- a sharded slab would need two-deep halos)
+// two iterations in one pass (k_fgp_fused2: P stays on chip between them).  A sharded slab needs the two-slice-deep planes
+// (tomo_bind_fgp_halo2, exchanged once before the call: tomo_comm_fgp_exchange2) and at least two slices on EVERY slab of the ring.
 int tomo_fgp_fused_step2(tomo_engine *e, float lambda, int first_iteration)
 {
     NEED(e);
     if (!e->fgp_q[2] || !e->fgp_p[2]) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_begin has not been called");
-    if (fgp_sharded(e)) return fail(TOMO_ERR_STATE, "tomo_fgp_fused_step2 is for a slab that is the whole volume");
+    if (fgp_sharded(e) && (!e->fgp_planes2 || !e->fgp_lo)) return fail(TOMO_ERR_STATE, "a sharded tomo_fgp_fused_step2 needs the two-slice-deep planes (tomo_bind_fgp_halo2)");
+    if (fgp_sharded(e) && e->nx < 2) return fail(TOMO_ERR_STATE, "a sharded tomo_fgp_fused_step2 needs at least two slices per slab");
     const int yseg = 32;                                 // (16 ... 64 within 3 %; 128 and more lose to the tail)
     const int nzb = (e->n + F2_TZ - 1) / F2_TZ, nys = (e->n + yseg - 1) / yseg, nchunk = (e->nx + F2_SC - 1) / F2_SC;
     dim3 grid((nzb & 7) == 0 ? 8u * (unsigned)((nzb >> 3) * nchunk * nys) : (unsigned)(nzb * nchunk * nys));
     const float multip = 1.0f / (26.0f * lambda);
     {
         ProfScope ps(e, TOMO_K_FGP_GRAD);
-        hipLaunchKernelGGL(k_fgp_fused2<false>, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
-                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0);
+        if (fgp_sharded(e)) {
+            Fgp2Edge ed{e->fgp_lo, e->fgp_hi, e->fgp_send_first, e->fgp_send_last, e->is_first, e->is_last};
+            hipLaunchKernelGGL((k_fgp_fused2<false, true>), grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                               e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0, ed);
+        } else
+        hipLaunchKernelGGL((k_fgp_fused2<false, false>), grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0, Fgp2Edge{});
     }
     LAUNCHCHK();
     for (int k = 0; k < 3; ++k) std::swap(e->fgp_p[k], e->fgp_q[k]);
@@ -2989,8 +3014,8 @@ int tomo_fgp_fused_last(tomo_engine *e, float lambda, int first_iteration)
     const float multip = 1.0f / (26.0f * lambda);
     {
         ProfScope ps(e, TOMO_K_FGP_OBJ);
-        hipLaunchKernelGGL(k_fgp_fused2<true>, grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
-                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0);
+        hipLaunchKernelGGL((k_fgp_fused2<true, false>), grid, dim3(256), 0, e->stream, e->vol[e->fgp_target], e->fgp_p[0], e->fgp_p[1], e->fgp_p[2],
+                           e->fgp_q[0], e->fgp_q[1], e->fgp_q[2], lambda, multip, e->n, e->nx, e->sx, yseg, first_iteration ? 1 : 0, Fgp2Edge{});
     }
     LAUNCHCHK();
     std::swap(e->vol[e->fgp_target], e->fgp_q[0]);         // the prox result's buffer becomes the volume; the old one is scratch now
@@ -3108,7 +3133,7 @@ static void comm_release(tomo_engine *e)
         delete e->comm;
     }
     e->comm = nullptr;
-    if (e->comm_fgp && e->fgp_lo == e->comm_fgp) e->fgp_lo = e->fgp_hi = e->fgp_send_first = e->fgp_send_last = nullptr;
+    if (e->comm_fgp && e->fgp_lo == e->comm_fgp) { e->fgp_lo = e->fgp_hi = e->fgp_send_first = e->fgp_send_last = nullptr; e->fgp_planes2 = false; }
     void *ptrs[] = {e->comm_send_first, e->comm_send_last, e->comm_g_lo, e->comm_g_hi, e->comm_scal, e->comm_fgp};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     e->comm_fgp = nullptr;
@@ -3122,9 +3147,10 @@ static int comm_buffers(tomo_engine *e)
     int rc;
     float **planes[] = {&e->comm_send_first, &e->comm_send_last, &e->comm_g_lo, &e->comm_g_hi};
     for (float **p : planes) if ((rc = dev_alloc((void **)p, e->npix * sizeof(float), true, e->stream))) return rc;
-    if (!e->fgp_lo) {        // a host that binds no planes of its own (tomo_bind_fgp_halo) gets the engine's: lo 1, hi 4, send_first 4, send_last 1
-        if ((rc = dev_alloc((void **)&e->comm_fgp, 10 * e->npix * sizeof(float), true, e->stream))) return rc;
-        e->fgp_lo = e->comm_fgp; e->fgp_hi = e->comm_fgp + e->npix; e->fgp_send_first = e->comm_fgp + 5 * e->npix; e->fgp_send_last = e->comm_fgp + 9 * e->npix;
+    if (!e->fgp_lo) {        // a host that binds no planes of its own (tomo_bind_fgp_halo / _halo2) gets the engine's, the deep set: lo 5, hi 8, send_first 8, send_last 5
+        if ((rc = dev_alloc((void **)&e->comm_fgp, 26 * e->npix * sizeof(float), true, e->stream))) return rc;
+        e->fgp_lo = e->comm_fgp; e->fgp_hi = e->comm_fgp + 5 * e->npix; e->fgp_send_first = e->comm_fgp + 13 * e->npix; e->fgp_send_last = e->comm_fgp + 21 * e->npix;
+        e->fgp_planes2 = true;
     }
     return dev_alloc((void **)&e->comm_scal, TOMO_S_COUNT * sizeof(double), true, e->stream);
 }
@@ -3297,6 +3323,15 @@ int tomo_comm_fgp_exchange(tomo_engine *e)
     NEED_COMM(e);
     if (!e->fgp_lo) return fail(TOMO_ERR_STATE, "slab-sharded fused FGP needs tomo_bind_fgp_halo");
     return comm_group(e, "fgp exchange", [&] { return comm_ring(e, e->fgp_send_first, 4 * (size_t)e->npix, e->fgp_send_last, (size_t)e->npix, e->fgp_lo, e->fgp_hi); });
+}
+
+// ... and between two PAIRS of fused iterations (tomo_fgp_fused_step2 on slabs): the two-slice-deep planes, one exchange per two
+// iterations: send_last (5 planes) -> next's lo, send_first (8 planes) -> prev's hi
+int tomo_comm_fgp_exchange2(tomo_engine *e)
+{
+    NEED_COMM(e);
+    if (!e->fgp_lo || !e->fgp_planes2) return fail(TOMO_ERR_STATE, "the two-deep FGP exchange needs the two-slice-deep planes (tomo_bind_fgp_halo2)");
+    return comm_group(e, "fgp exchange (two deep)", [&] { return comm_ring(e, e->fgp_send_first, 8 * (size_t)e->npix, e->fgp_send_last, 5 * (size_t)e->npix, e->fgp_lo, e->fgp_hi); });
 }
 
 int tomo_get_option(tomo_engine *e, const char *name, int *value)

@@ -90,12 +90,13 @@ class _SlabBackend:
         z = lambda k=1: torch.zeros(k * npix, dtype=torch.float32, device=dev)  # noqa: E731
         self._halo_lo, self._halo_hi, self._send_lo, self._send_hi = z(), z(), z(), z()
         self._g_lo, self._g_hi = z(), z()          # received gradient planes (one-round TV descent)
-        # planes of the fused FGP iteration: lo = P1 below, hi = {A, P1, P2, P3} above, and what this slab sends
-        self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last = z(), z(4), z(4), z()
+        # planes of the fused FGP iteration, the two-slice-deep set (include/tomo_hip.h: tomo_bind_fgp_halo2): lo = [P1(-1), A(-1),
+        # P2(-1), P3(-1), P1(-2)], hi = [A, P1, P2, P3](nx), [..](nx+1), and what this slab sends; the one-deep planes are the prefixes
+        self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last = z(5), z(8), z(8), z(5)
         self.c("bind_scalar_buffer", ctypes.c_void_p(self._scal_t.data_ptr()))
         self.c("bind_halo", ctypes.c_void_p(self._halo_lo.data_ptr()), ctypes.c_void_p(self._halo_hi.data_ptr()))
-        self.c("bind_fgp_halo", *(ctypes.c_void_p(t.data_ptr()) for t in
-                                  (self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last)))
+        self.c("bind_fgp_halo2", *(ctypes.c_void_p(t.data_ptr()) for t in
+                                   (self._fgp_lo, self._fgp_hi, self._fgp_send_first, self._fgp_send_last)))
 
     def enable_native_comm(self, comm):
         """A native RCCL communicator for this engine (include/tomo_hip.h: tomo_comm_*): rank 0 makes the id, the process
@@ -172,9 +173,13 @@ class _SlabBackend:
         self.c("tv_halo_apply", float(dPOCS), int(clamp), ctypes.c_void_p(self._g_lo.data_ptr()),
                ctypes.c_void_p(self._g_hi.data_ptr()))
 
-    def fgp_planes(self):
-        """(send_first, send_last, lo, hi) of the fused FGP iteration."""
-        return self._fgp_send_first, self._fgp_send_last, self._fgp_lo, self._fgp_hi
+    def fgp_planes(self, deep=False):
+        """(send_first, send_last, lo, hi) of the fused FGP iteration: the one-deep planes (4 / 1 / 1 / 4: views of the prefixes), or
+        with ``deep`` the whole two-slice-deep set (8 / 5 / 5 / 8) a pair of iterations needs."""
+        if deep:
+            return self._fgp_send_first, self._fgp_send_last, self._fgp_lo, self._fgp_hi
+        npix = self.nray * self.nray
+        return self._fgp_send_first[:4 * npix], self._fgp_send_last[:npix], self._fgp_lo[:npix], self._fgp_hi[:4 * npix]
 
     def new_plane(self):
         import torch
@@ -777,6 +782,12 @@ class _EngineBase:
                 self.be.tv_halo_apply(dPOCS, 0)                        # ... which then follow the neighbours' slices
 
     fgp_fused = True   # sharded FGP: one fused kernel + one ring exchange per iteration (False: Obj / Grad pair, two)
+    fgp_pair = True    # ... and two iterations per pass and exchange where every slab holds two slices (False: one per pass)
+
+    def _min_slab_slices(self):
+        """The thinnest slab of the ring (every rank computes the same number: distributed.slab_partition)."""
+        from .distributed import slab_partition
+        return min(slab_partition(self.Nslice_, self.comm.world, r)[1] for r in range(self.comm.world))
 
     def tv_fgp(self, ng, lam, vol=VOL_RECON):
         """FGP-TV prox on recon (tv_fgp.cu:192-281), or on another volume slot; returns TV of the input."""
@@ -791,9 +802,21 @@ class _EngineBase:
             self.be.c("fgp_fused_begin", vol)
             first, last, lo, hi = self.be.fgp_planes()
             xchg = (lambda: self.be.c("comm_fgp_exchange")) if self._native() else (lambda: self.comm.exchange_planes(first, last, lo, hi))
-            for i in range(ng - 1):
+            i = 0
+            if self.fgp_pair and self._min_slab_slices() >= 2 and ng > 2:
+                # TWO iterations per pass (k_fgp_fused2 on slabs, round 6): P stays on chip between them, the halo is two slices deep
+                # and ONE exchange serves both iterations.  Every slab of the ring must hold two slices (all ranks agree: the
+                # partition is a function of the global size and the world).
+                first2, last2, lo2, hi2 = self.be.fgp_planes(deep=True)
+                xchg2 = (lambda: self.be.c("comm_fgp_exchange2")) if self._native() else (lambda: self.comm.exchange_planes(first2, last2, lo2, hi2))
+                while i + 2 < ng:
+                    xchg2()
+                    self.be.c("fgp_fused_step2", lam, int(i == 0))
+                    i += 2
+            while i + 1 < ng:
                 xchg()
                 self.be.c("fgp_fused_step", lam, int(i == 0))
+                i += 1
             xchg()
             self.be.c("fgp_fused_end", lam)
             return tv0
