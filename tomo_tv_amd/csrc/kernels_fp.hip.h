@@ -315,9 +315,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_fp_tile(const float *__restrict_
 constexpr int FS_W = 16, FS_H = 16, FS_PIX = FS_W * FS_H, FS_THREADS = 512, FS_WAVES = FS_THREADS / 64, FS_GROUPS = FS_THREADS / 16;
 constexpr int FS_RING = 7;                               // entry batches in flight per lane group (LDS ring slots of 64 B)
 struct FsItemD { int pass, v0; uint32_t tile0, ntiles, cnt0, g0, work, pad; };
-#ifndef FS_WHATIF
-#define FS_WHATIF 0
-#endif
 #ifndef FS_DMA_STAGE
 #define FS_DMA_STAGE 1
 #endif
@@ -403,11 +400,7 @@ void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, 
                 const int vv = I.v0 + sh[min(u, n - 1)] + q % FS_W;
                 const bool ok = u < n && (unsigned)vv < (unsigned)n;
                 const size_t pix = o ? (size_t)vv * n + u : (size_t)u * n + vv;
-#if FS_WHATIF & 2
-                v[i] = (ok && tt == 0) ? nt_ld<16>(reinterpret_cast<const V *>(xc + pix * sx)) : vzero<4>();   // timing experiment: one tile staged
-#else
                 v[i] = ok ? nt_ld<16>(reinterpret_cast<const V *>(xc + pix * sx)) : vzero<4>();
-#endif
             }
 #pragma unroll
             for (int i = 0; i < FS_PIX / FS_GROUPS; ++i) fs_tile[(g + FS_GROUPS * i) * 16 + gl] = v[i];
@@ -419,15 +412,11 @@ void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, 
         // batch of 8 entries; !FULL: a half batch, 4 entries stored twice in the unit, so the first four rotations meet all of them.
 #define FS_LD1(J) xv[J] = *reinterpret_cast<const V *>(base + row_ror<J>(off));
 #define FS_FM1(J) acc[k] += __uint_as_float(row_ror<J>(wb)) * xv[J];
-#if FS_WHATIF & 1
-#define FS_NEXT slot = slot == FS_RING - 1 ? 0u : slot + 1u;
-#else
 #define FS_NEXT                                                                                           \
         FS_DMA(slot)           /* this unit's slot is free (its entry is in registers): fetch the unit FS_RING ahead into it */ \
         slot = slot == FS_RING - 1 ? 0u : slot + 1u;                                                      \
         /* the NEXT unit's entry: its DMA is the oldest of the FS_RING now in flight */                    \
         asm volatile("s_waitcnt vmcnt(%1)\n\tds_read_b64 %0, %2" : "=v"(en) : "n"(FS_RING - 1), "v"(ring_l + slot * 256u) : "memory");
-#endif
 #define FS_UNIT(FULL)                                                                                     \
         {                                                                                                 \
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(en) : : "memory");   /* the ring read issued one unit ago */ \
@@ -439,7 +428,7 @@ void k_fp_strip(const float *__restrict__ x, const FsItemD *__restrict__ items, 
             if (FULL) { FS_LD1(4) FS_LD1(5) FS_LD1(6) FS_LD1(7) }                                         \
             FS_FM1(0) FS_FM1(1) FS_FM1(2) FS_FM1(3)                                                       \
             if (FULL) { FS_FM1(4) FS_FM1(5) FS_FM1(6) FS_FM1(7) }                                         \
-            if (!(FS_WHATIF & 1) && (e.x >> 31)) {   /* the ray leaves the strip: its sum is this group's next partial sum */ \
+            if (e.x >> 31) {   /* the ray leaves the strip: its sum is this group's next partial sum */ \
                 nt_st<32>(acc[k], reinterpret_cast<V *>(pp));                                             \
                 acc[k] = vzero<4>();                                                                      \
                 pp += pstep;                                                                              \

@@ -160,12 +160,6 @@ constexpr int ST_LDS_V = (ST_PIX + 1) * 16 + (ST_MAXR + 1) * 16 + ST_PIX;     //
 // launch (round 2; the kernel is not HBM-bound, see above).  Cells with host-normalised weights (two FMAs per component, no
 // division at all) measured the same 215 us, so the cells keep the raw weights and the formula of k_bp_angle / k_sart_seg:
 // the three forms are bit-identical.
-#ifdef TOMO_WHATIF   // measurement builds only (make EXTRA=-DTOMO_WHATIF): switch parts of k_sart_tile off, results are WRONG
-__device__ int g_sart_whatif = 0;   // 1 no x stores, 2 no BP arithmetic, 4 no FP phase, 8 no window / cell staging, 16 no tile loads
-#define ST_WI(bit) (wi_ & (bit))
-#else
-#define ST_WI(bit) 0
-#endif
 
 // ---- cooperative residual rows (COOP) -----------------------------------------------------------------------------
 // The chain "tile step; k_resid_finish; tile step; ..." pays one short kernel and two launch boundaries per angle for the
@@ -270,9 +264,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
                                                            int skip_same, StCoop co)
 {
     typedef VecOf<4>::T V;
-#ifdef TOMO_WHATIF
-    const int wi_ = g_sart_whatif;
-#endif
     static_assert(!COOP || FUSED, "the cooperative residual rows feed the voxel update");
     if (COOP && (int)blockIdx.x < co.nred) {
         // reducer duty (before anything this workgroup could wait for): items (row, chunk), one wave each
@@ -323,7 +314,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
     V xv[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
-        xv[J] = (y < n && z0 + J < n && !ST_WI(16)) ? st_xload<NT>(reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off)) : vzero<4>();
+        xv[J] = (y < n && z0 + J < n) ? st_xload<NT>(reinterpret_cast<const V *>(x_old + ((size_t)y * n + z0 + J) * sx + off)) : vzero<4>();
     uint2 eb[ST_SPG][ST_MAXB];
 #pragma unroll
     for (int q = 0; q < ST_SPG; ++q) {
@@ -359,7 +350,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
                 if (ln < 16) win[j * 16 + ln] = rr;
             }
         }
-    } else if (FUSED && !ST_WI(8)) {
+    } else if (FUSED) {
         uint32_t w = wins[tile];
         for (int i = t; i < (ST_MAXR + 1) * 16; i += ST_THREADS) {
             int j = i >> 4;
@@ -368,7 +359,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
         if (t < ST_PIX) cel[t] = cells[(size_t)tile * ST_PIX + t];
     }
     if (t < 16) img[ST_PIX * 16 + t] = vzero<4>();
-    if (FUSED && !ST_WI(2)) {
+    if (FUSED) {
         __syncthreads();
         const char *wb = reinterpret_cast<const char *>(win) + gl * 16;
 #pragma unroll
@@ -408,15 +399,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_sart_tile(const float *x_old, fl
                                    (__float_as_uint(nv[2]) ^ __float_as_uint(ov[2])) | (__float_as_uint(nv[3]) ^ __float_as_uint(ov[3]))) != 0u;
                 wr = ((__ballot(mine) >> (t & 48)) & 0xFFFFull) != 0;
             }
-            if (y < n && z0 + J < n && wr && !ST_WI(1)) st_xstore<NT>(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
+            if (y < n && z0 + J < n && wr) st_xstore<NT>(nv, reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off));
         }
-    }
-    if (ST_WI(4)) {
-        if (FUSED && ST_WI(2) && !ST_WI(1)) {   // copy-through when the update is off but the stores are on
-#pragma unroll
-            for (int J = 0; J < 8; ++J) if (y < n && z0 + J < n) *reinterpret_cast<V *>(x_new + ((size_t)y * n + z0 + J) * sx + off) = xv[J];
-        }
-        return;
     }
 #pragma unroll
     for (int J = 0; J < 8; ++J) img[(g * 8 + J) * 16 + gl] = xv[J];

@@ -715,21 +715,10 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
         auto col = [&](float packed, int j) {                   // column j's value of a packed register, wave-uniform
             return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, packed), j));
         };
-#ifdef TV4_WHATIF_FUSED
-        float xprev[TZ + 2], Wa[TZ + 1], Wb[TZ + 1];
-        double acc2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < TZ + 2; ++j) xprev[j] = 0.f;
-#pragma unroll
-        for (int j = 0; j < TZ + 1; ++j) Wa[j] = 0.f;
-#endif
         // one row: c0 / cp = rows y, y+1; cn receives row y+2; Tp = the -y terms formed in row y-1, Tn receives this row's.
         // (tv_gval's expression, term by term: G1 = v1n R(p); t2 = (x_ip - c) R of the slice below, shifted in; Tp; Tk of column j-1)
         auto row = [&](int y, const float *c0, const float *cp, float *cn, float pe0, float pf0, float pc0, float pep,
                        float &pen, float &pfn, float &pcn, const float *Tp, float *Tn
-#ifdef TV4_WHATIF_FUSED
-                       , const float *Wp, float *Wn
-#endif
                        ) __attribute__((always_inline)) {
             if (y + 1 < y1) fetch(y + 2, cn, pen, pfn, pcn);    // in flight while this row is computed
             float TEp = 0.f;
@@ -880,23 +869,6 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                         if (!EDGE || z0 + j - 1 < n) up.ho_hi[pix0 + (j - 1)] = fmaxf(tv_step(h.hi[pix0 + (j - 1)], up.hg_hi[pix0 + (j - 1)], nrm_), vmin);
                 }
             }
-#ifdef TV4_WHATIF_FUSED
-            // WHAT-IF (results wrong): the norm pass's arithmetic of iteration i+1 on the rows of x_new this wave has in registers --
-            // the LOWER bound of a temporally blocked tv_gd (no ring columns, no edge marches for the slices s0-1 / s0+64).
-            if (MODE == TVM_UPDATE) {
-                float wa1[TZ + 2];
-                wa1[0] = out[TZ]; wa1[TZ + 1] = out[1];
-#pragma unroll
-                for (int j = 1; j <= TZ; ++j) wa1[j] = out[j];
-                const float *wa0 = xprev;
-                {
-#include "kernels_tv_whatif.inc"
-                    (void)wout;
-                }
-#pragma unroll
-                for (int j = 0; j < TZ + 2; ++j) xprev[j] = wa1[j];
-            }
-#endif
         };
         fetch(y0 - 1, rows[0], pe[0], pf[0], pc[0]);
         fetch(y0, rows[1], pe[1], pf[1], pc[1]);
@@ -909,13 +881,7 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
             (void)dd; (void)d1; (void)d3;
             Ta[j] = nc_mul(d2, r);
         }
-#ifdef TV4_WHATIF_FUSED
-#define TV4_ROW(S0, SP, SN, TP, TN) row(y, rows[S0], rows[SP], rows[SN], pe[S0], pf[S0], pc[S0], pe[SP], pe[SN], pf[SN], pc[SN], TP, TN, W##TP, W##TN)
-#define WTa Wa
-#define WTb Wb
-#else
 #define TV4_ROW(S0, SP, SN, TP, TN) row(y, rows[S0], rows[SP], rows[SN], pe[S0], pf[S0], pc[S0], pe[SP], pe[SN], pf[SN], pc[SN], TP, TN)
-#endif
         for (int y = y0; y < y1;) {
             TV4_ROW(1, 2, 3, Ta, Tb); if (++y >= y1) break;
             TV4_ROW(2, 3, 0, Tb, Ta); if (++y >= y1) break;
@@ -923,9 +889,6 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
             TV4_ROW(0, 1, 2, Tb, Ta); ++y;
         }
 #undef TV4_ROW
-#ifdef TV4_WHATIF_FUSED
-        acc += acc2;
-#endif
 #undef TV4_RINV
     }
     if (MODE != TVM_VALUE) block_accumulate(acc, part);

@@ -137,14 +137,7 @@ __device__ __forceinline__ bool rs_commit(unsigned *w, unsigned base, unsigned n
     "s_load_dwordx16 s[52:67], %[cp], " #OFF "+0x40\n"                                                    \
     "s_load_dwordx16 s[68:83], %[cp], " #OFF "+0x80\n"                                                    \
     "s_load_dwordx16 s[84:99], %[cp], " #OFF "+0xc0\n"
-#ifndef RS_WHATIF
-#define RS_WHATIF 0            // measurement builds only (results are WRONG): 1 no index changes, 2 no cell loads after the first batch
-#endif
-#if RS_WHATIF & 1
-#define RS_IDX(SB, K)
-#else
 #define RS_IDX(SB, K) "s_set_gpr_idx_idx s[" #SB "+4*" #K "]\n"
-#endif
 // back-projection, cell {s0, w0, w1, inv}; index mode on SRC1; rows in v[32:47] (v46 = v47 = 0: where a pixel without rays points)
 #define RS_BP1(SB, K, Q)                                                                                  \
     RS_IDX(SB, K)                                                                                         \
@@ -163,12 +156,8 @@ __device__ __forceinline__ bool rs_commit(unsigned *w, unsigned base, unsigned n
     OP(36, 0, 16*B+0) OP(36, 1, 16*B+1) OP(36, 2, 16*B+2) OP(36, 3, 16*B+3) OP(36, 4, 16*B+4) OP(36, 5, 16*B+5) OP(36, 6, 16*B+6) OP(36, 7, 16*B+7) \
     OP(36, 8, 16*B+8) OP(36, 9, 16*B+9) OP(36, 10, 16*B+10) OP(36, 11, 16*B+11) OP(36, 12, 16*B+12) OP(36, 13, 16*B+13) OP(36, 14, 16*B+14) OP(36, 15, 16*B+15)
 #define RS_WAIT "s_waitcnt lgkmcnt(0)\n"
-#if RS_WHATIF & 2
-#define RS_SWEEP(OP) RS_BATCH(OP, 0) RS_BATCH(OP, 1) RS_BATCH(OP, 2) RS_BATCH(OP, 3)
-#else
 #define RS_SWEEP(OP)                                                                                      \
     RS_BATCH(OP, 0) RS_LD(0x100) RS_WAIT RS_BATCH(OP, 1) RS_LD(0x200) RS_WAIT RS_BATCH(OP, 2) RS_LD(0x300) RS_WAIT RS_BATCH(OP, 3)
-#endif
 // Register assumptions of the asm blocks (x in v[64:127], rows / sums in v[32:47], v[48:59] scratch, s[33], s[36:99] cells; 128 VGPRs at
 // amdgpu_waves_per_eu(4, 4)): written against and verified on ROCm 7.2.0 (hipcc = AMD clang 20, gfx950).  Another toolchain: a register the
 // compiler needs elsewhere is a BUILD error (constraint conflict); tools/experiments/resident_probe.hip replays the kernel bit for bit against a

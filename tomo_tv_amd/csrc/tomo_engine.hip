@@ -2635,9 +2635,6 @@ static int tv_grad_impl(tomo_engine *e, float eps, bool with_tv, float *g_first 
                 const bool edge = e->nx % 64 != 0 || e->n % 8 != 0;      // lanes without a voxel exist: the predicated form
 #define TV4_NORM(WTV, EDGE, PTV) hipLaunchKernelGGL((k_tv_march4<8, WTV, TVM_NORM, EDGE>), grid, dim3(256), 0, e->stream, x, h, e->d_part, eps, e->n, e->nx, e->sx, yseg, PTV, gp)
                 if (with_tv) { if (edge) TV4_NORM(true, true, e->d_part_tv); else TV4_NORM(true, false, e->d_part_tv); }
-#ifdef TV4_WHATIF_FUSED
-                else if (std::getenv("TOMO_WHATIF_SKIP_NORM")) { /* what-if: iteration i's update pass did this pass's arithmetic */ }
-#endif
                 else { if (edge) TV4_NORM(false, true, (double *)nullptr); else TV4_NORM(false, false, (double *)nullptr); }
 #undef TV4_NORM
             }
@@ -3379,9 +3376,6 @@ int tomo_set_option(tomo_engine *e, const char *name, int value)
     if (std::strcmp(name, "sart_resident") == 0) { e->sart_resident = value < 0 ? -1 : (value ? 1 : 0); e->rs_skip = e->rs_backoff = 0; return TOMO_OK; }
     if (std::strcmp(name, "sart_resident_spin") == 0) { e->rs_spin_limit = value < 0 ? (1u << 21) : (uint32_t)value; return TOMO_OK; }   // polls before a wait gives up (< 0: the default; tests: tiny, 0 = at the first look)
     if (std::strcmp(name, "sart_resident_test_fail") == 0) { e->rs_test_fail = std::max(0, value); return TOMO_OK; }   // tests: chunk + 1 that refuses to commit
-#ifdef TOMO_WHATIF
-    if (std::strcmp(name, "sart_whatif") == 0) { HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sart_whatif), &value, sizeof(int))); return TOMO_OK; }
-#endif
     if (std::strcmp(name, "fp_reuse") == 0) { e->fp_reuse = value != 0; g_clear(e); e->yk_claim.valid = false; return TOMO_OK; }
     if (std::strcmp(name, "fp_tile_pipe") == 0) { e->fp_tile_pipe = std::max(0, value); return TOMO_OK; }
     if (std::strcmp(name, "sart_streams") == 0) { e->sart_streams = value >= 2 ? std::min(value, (int)tomo_engine::MAX_CHAINS) : (value == 1 ? 1 : 0); return TOMO_OK; }
