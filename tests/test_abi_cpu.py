@@ -125,7 +125,7 @@ def test_product_never_imports_the_oracle():
     subprocess.check_call([sys.executable, "-c", code])
     for dirpath, _, files in os.walk(os.path.join(ROOT, "tomo_tv_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "tomo_oracle" not in src, f
 
