@@ -149,6 +149,8 @@ struct tomo_engine {
     uint32_t *d_row_first = nullptr, *d_row_nseg = nullptr;
     float *seg_partial = nullptr;
     uint32_t max_items = 0;
+    bool seg_ready = false;                       // the walk / segment tables above are on the device (built at creation or on first use)
+    std::vector<double> angles;                   // the tilt angles of an engine created from angles (tomo_create): tables built on first use come from them
     float *sart_alt = nullptr;                    // ping-pong partner of the volume being swept
     // tile-stationary all-angle FP (k_fp_tile): tables, partial-sum scratch (one per stream that can run it)
     int fp_tile = 1, ft_tiles_z = 0, ft_ntiles = 0;
