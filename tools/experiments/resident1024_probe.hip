@@ -16,7 +16,11 @@
 // bit-compared with a CPU replay in the kernel's order (conflicting lanes of one ds_add_f32 applied in ascending lane order).
 // The exchange itself (two hand-offs per angle) is what k_sart_resident already pays: ~5 us (profiles/r06_resident_phases.txt).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../tomo_tv_amd/csrc resident1024_probe.hip ../../tomo_tv_amd/csrc/sysmat.cpp -lpthread -o resident1024_probe
-//   ./resident1024_probe [N=1024] [P=120] [steps=P] [reps=3] [mode=3: bit 0 back projection, bit 1 forward projection, bit 2 forward without the LDS adds]
+//   ./resident1024_probe [N=1024] [P=120] [steps=P] [reps=3] [mode=3: bit 0 back projection, bit 1 forward projection by LDS float adds,
+//                        bit 2 forward without the LDS adds, bit 3 forward projection WITHOUT atomics (mode 9 = full step in that form, bit-compared):
+//                        the lanes of an image row are sorted by ray and runs of equal rays are <= 4 lanes (|theta| <= 70 deg: a line 20 deg off the row direction crosses <= 4 pixels of a row), so three DPP
+//                        shifts with 0 / 1 masks form the run totals in the run's last lane, which adds them to the wave's OWN LDS rows by a
+//                        plain read - add - write (distinct rays per instruction; the wave's four rows one after the other)]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,9 +47,10 @@ static inline float hashf(uint64_t i, uint32_t salt)
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+template <int mode>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_probe(float *__restrict__ xg, const PCell *__restrict__ cells, const THdr *__restrict__ thdr, const WHdr *__restrict__ whdr,
-             const float *__restrict__ rows, float *__restrict__ tsum, int n, int tiles, int nproj, int steps, float beta, int mode)
+             const float *__restrict__ rows, float *__restrict__ tsum, int n, int tiles, int nproj, int steps, float beta)
 {
     __shared__ float r_lds[MAXWIN + 2][SL];                      // residual rows of the tile's window (+ a zero row pair for pixels without rays)
     __shared__ float acc[WAVES][WWIN][SL];                       // per wave: the sums of the rays through its four rows
@@ -73,7 +78,7 @@ void k_probe(float *__restrict__ xg, const PCell *__restrict__ cells, const THdr
             for (int g = 0; g < RPW; ++g) {
                 const int y = ty * T + wave * RPW + g;
                 const PCell c = cells[((size_t)a * n + y) * n + z];
-                const float4 *rp = reinterpret_cast<const float4 *>(&r_lds[c.s0 - h.jbase][0]);
+                const float4 *rp = reinterpret_cast<const float4 *>(&r_lds[max(c.s0, h.jbase) - h.jbase][0]);      // (a pixel without rays: s0 = -1, weights 0)
                 float r0[SL], r1[SL];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { float4 v = rp[q]; r0[4 * q] = v.x; r0[4 * q + 1] = v.y; r0[4 * q + 2] = v.z; r0[4 * q + 3] = v.w; }
@@ -88,7 +93,7 @@ void k_probe(float *__restrict__ xg, const PCell *__restrict__ cells, const THdr
                 }
             }
         }
-        if (k + 1 < steps && (mode & 6)) {
+        if (k + 1 < steps && (mode & 14)) {
             // ---- forward projection of angle a + 1: per-wave ray sums by LDS adds, then the tile's sums per window ray (the publish)
             const int a = (k + 1) % nproj;
             const THdr h = thdr[(size_t)a * ntiles + tile];
@@ -99,8 +104,40 @@ void k_probe(float *__restrict__ xg, const PCell *__restrict__ cells, const THdr
             for (int g = 0; g < RPW; ++g) {
                 const int y = ty * T + wave * RPW + g;
                 const PCell c = cells[((size_t)a * n + y) * n + z];
-                float *ap = &acc[wave][c.s0 - wh.wbase][0];
-                if (mode & 2) {
+                float *ap = &acc[wave][max(c.s0, wh.wbase) - wh.wbase][0];
+                if (mode & 8) {
+                    // run structure of this row: lanes sorted by ray; m1 / m2: the lane one / two to the left is on the same ray; tail: last of its run
+                    const int s0 = c.s0;
+                    const int l1 = __builtin_amdgcn_update_dpp(-2, s0, 0x138, 0xf, 0xf, false);        // wave_shr:1 (lane 0 keeps -2)
+                    const int l2 = __builtin_amdgcn_update_dpp(-2, l1, 0x138, 0xf, 0xf, false);
+                    const int l3 = __builtin_amdgcn_update_dpp(-2, l2, 0x138, 0xf, 0xf, false);
+                    const int r1 = __builtin_amdgcn_update_dpp(-2, s0, 0x130, 0xf, 0xf, false);        // wave_shl:1 (lane 63 keeps -2)
+                    const float m1 = (s0 >= 0 && l1 == s0) ? 1.f : 0.f, m2 = (s0 >= 0 && l2 == s0) ? 1.f : 0.f, m3 = (s0 >= 0 && l3 == s0) ? 1.f : 0.f;
+                    const bool tail = s0 >= 0 && r1 != s0;
+#pragma unroll
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const float w = pass ? c.w1 : c.w0;
+                        float4 *q4 = reinterpret_cast<float4 *>(ap + pass * SL);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {               // four slices at a time: one 16-byte read - add - write per run
+                            float tot[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float v = w * x[g][4 * q + u];
+                                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+                                const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0x138, 0xf, 0xf, false));
+                                const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a2), 0x138, 0xf, 0xf, false));
+                                tot[u] = __builtin_fmaf(m3, a3, __builtin_fmaf(m2, a2, __builtin_fmaf(m1, a1, v)));
+                            }
+                            if (tail) {
+                                float4 o = q4[q];
+                                o.x += tot[0]; o.y += tot[1]; o.z += tot[2]; o.w += tot[3];
+                                q4[q] = o;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else if (mode & 2) {
 #pragma unroll
                     for (int s = 0; s < SL; ++s) { __hip_atomic_fetch_add(ap + s, c.w0 * x[g][s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #pragma unroll
@@ -188,7 +225,8 @@ int main(int argc, char **argv)
                 const int k = (int)((p / N) / T) * tiles + (int)((p % N) / T);
                 const THdr &h = thdr[(size_t)a * ntiles + k];
                 const WHdr &wh = whdr[((size_t)a * ntiles + k) * WAVES + (int)(((p / N) % T) / RPW)];
-                q = PCell{std::max(h.jbase, wh.wbase), 0.f, 0.f, 1.f};       // any ray inside both windows: the weights are zero
+                (void)h; (void)wh;
+                q = PCell{-1, 0.f, 0.f, 1.f};                                  // no ray: the kernel clamps the index, the weights are zero
             } else {
                 const float sum = c.w0 + c.w1;
                 q = PCell{(int32_t)c.r0, c.w0, c.w1, 1.0f / sum};
@@ -196,7 +234,25 @@ int main(int argc, char **argv)
             cells[(size_t)a * npix + p] = q;
         }
     }
+    // the no-atomics form needs: rays non-decreasing along a row of a tile, runs of equal rays <= 4 lanes, pixels without rays only at the ends
+    int longest_run = 0, order_bad = 0;
+    for (int a = 0; a < P; ++a)
+        for (size_t y = 0; y < (size_t)N; ++y)
+            for (int z0 = 0; z0 < N; z0 += T) {
+                int run = 0, prev = -1, seen_real = 0, ended = 0;
+                for (int l = 0; l < T; ++l) {
+                    const int s0 = cells[(size_t)a * npix + y * N + z0 + l].s0;
+                    if (s0 < 0) { if (seen_real) ended = 1; run = 0; prev = -1; continue; }
+                    if (ended) ++order_bad;                       // a real pixel behind a gap
+                    if (prev >= 0 && s0 < prev) ++order_bad;
+                    run = (s0 == prev) ? run + 1 : 1;
+                    longest_run = std::max(longest_run, run);
+                    prev = s0; seen_real = 1;
+                }
+            }
+    printf("rows of a tile: longest run of lanes on one ray %d (limit 4), order violations %d\n", longest_run, order_bad);
     printf("widest tile window %d (limit %d), widest wave window %d (limit %d)\n", worst_win, MAXWIN, worst_wwin, WWIN);
+    if ((mode & 8) && (longest_run > 4 || order_bad)) { printf("the no-atomics form cannot run on this geometry\n"); return 1; }
     if (worst_win > MAXWIN || worst_wwin + 1 > WWIN) { printf("windows do not fit\n"); return 1; }
     if (host_only) return 0;
     std::vector<float> x0(npix * SL), rows((size_t)P * N * SL);
@@ -216,7 +272,9 @@ int main(int argc, char **argv)
         CK(hipMemcpy(dx, x0.data(), x0.size() * 4, hipMemcpyHostToDevice));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_probe, dim3(ntiles), dim3(1024), 0, 0, dx, dc, dth, dwh, drows, dts, N, tiles, P, steps, beta, mode);
+#define LAUNCH(M) case M: hipLaunchKernelGGL(k_probe<M>, dim3(ntiles), dim3(1024), 0, 0, dx, dc, dth, dwh, drows, dts, N, tiles, P, steps, beta); break;
+        switch (mode) { LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(8) LAUNCH(9) default: printf("mode %d is not built\n", mode); return 1; }
+#undef LAUNCH
         CK(hipEventRecord(e1));
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
@@ -228,7 +286,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(got.data(), dx, got.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(gts.data(), dts, gts.size() * 4, hipMemcpyDeviceToHost));
     int bad = 0, bad_ts = 0;
-    if (mode == 3) {
+    if (mode == 3 || mode == 9) {
         // ---- CPU replay of three tiles in the kernel's order (a ds_add_f32's conflicting lanes in ascending lane order)
         const int check_tiles[] = {0, ntiles / 2 + tiles / 3, ntiles - 1};
         for (int ct = 0; ct < 3; ++ct) {
@@ -244,10 +302,11 @@ int main(int argc, char **argv)
                     for (int y = 0; y < T; ++y) for (int zz = 0; zz < T; ++zz) {
                         const PCell &c = cells[(size_t)a * npix + (size_t)(ty * T + y) * N + tz * T + zz];
                         for (int s = 0; s < SL; ++s) {
-                            const float r0 = rows[((size_t)a * N + c.s0) * SL + s];
-                            const float r1 = c.s0 + 1 < N ? rows[((size_t)a * N + c.s0 + 1) * SL + s] : 0.f;
                             const THdr &h = thdr[(size_t)a * ntiles + k];
-                            const float r0w = (c.s0 - h.jbase) < h.nr ? r0 : 0.f, r1w = (c.s0 + 1 - h.jbase) < h.nr ? r1 : 0.f;
+                            const int j0 = std::max(c.s0, h.jbase);
+                            const float r0 = rows[((size_t)a * N + j0) * SL + s];
+                            const float r1 = j0 + 1 < N ? rows[((size_t)a * N + j0 + 1) * SL + s] : 0.f;
+                            const float r0w = (j0 - h.jbase) < h.nr ? r0 : 0.f, r1w = (j0 + 1 - h.jbase) < h.nr ? r1 : 0.f;
                             float tt = c.w0 * r0w;
                             tt = fmaf(c.w1, r1w, tt);
                             tt = tt * c.inv;
@@ -264,9 +323,29 @@ int main(int argc, char **argv)
                     for (int w = 0; w < WAVES; ++w) {
                         const WHdr &wh = whdr[((size_t)a * ntiles + k) * WAVES + w];
                         for (int g = 0; g < RPW; ++g) {
+                            if (mode & 8) {       // run totals (last lane + the one / two lanes before it), one read - add - write per run
+                                const int y = w * RPW + g;
+                                for (int pass = 0; pass < 2; ++pass) for (int s = 0; s < SL; ++s) for (int l = 0; l < 64; ++l) {
+                                    const PCell &c = cells[(size_t)a * npix + (size_t)(ty * T + y) * N + tz * T + l];
+                                    if (c.s0 < 0) continue;
+                                    const bool tail = l == 63 || cells[(size_t)a * npix + (size_t)(ty * T + y) * N + tz * T + l + 1].s0 != c.s0;
+                                    if (!tail) continue;
+                                    auto val = [&](int ll) { const PCell &cc = cells[(size_t)a * npix + (size_t)(ty * T + y) * N + tz * T + ll];
+                                                             const volatile float pr = (pass ? cc.w1 : cc.w0) * x[((size_t)y * T + ll) * SL + s]; return (float)pr; };
+                                    auto same = [&](int ll) { return ll >= 0 && cells[(size_t)a * npix + (size_t)(ty * T + y) * N + tz * T + ll].s0 == c.s0; };
+                                    float tot = val(l);
+                                    if (same(l - 1)) tot = tot + val(l - 1);
+                                    if (same(l - 2)) tot = tot + val(l - 2);
+                                    if (same(l - 3)) tot = tot + val(l - 3);
+                                    float &dst = wacc[((size_t)w * WWIN + (c.s0 - wh.wbase) + pass) * SL + s];
+                                    dst = dst + tot;
+                                }
+                                continue;
+                            }
                             for (int pass = 0; pass < 2; ++pass) for (int s = 0; s < SL; ++s) for (int l = 0; l < 64; ++l) {
                                 const int y = w * RPW + g;
                                 const PCell &c = cells[(size_t)a * npix + (size_t)(ty * T + y) * N + tz * T + l];
+                                if (c.s0 < 0) continue;
                                 const float xv = x[((size_t)y * T + l) * SL + s];
                                 const volatile float prod = (pass ? c.w1 : c.w0) * xv;          // (rounded product, then the add: no contraction)
                                 float &dst = wacc[((size_t)w * WWIN + (c.s0 - wh.wbase) + pass) * SL + s];
