@@ -484,6 +484,22 @@ def _shard_step(nloc, n, nproj, steps=10):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def _sharded_fgp(nloc, n):
+    """The slab-sharded FGP-TV prox per inner iteration, two iterations per pass and exchange (k_fgp_fused2 on slabs, round 6) against
+    one: tools/bench_fgp_sharded.py in a child process on a world-1 RCCL group, every exchange issued."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_fgp_sharded.py"), "--json", "--nslice", str(nloc), "--n", str(n)]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": f"child exited {p.returncode}: {p.stderr[-400:]}"}
+        return json.loads(line[-1])
+    except Exception as e:  # noqa: BLE001 -- a secondary figure must not take the headline down
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def _time_steps(t, fn, steps, warmup=1):
     for _ in range(warmup):
         fn()
@@ -655,6 +671,7 @@ def secondary_configs(nnz_per_pixel_angle=1.22):
     # ---- the slab ONE rank of an 8-GPU strong-scaling run of the headline owns (64 x 512^2, 90 tilts), through the slab-sharded
     # engine with its real collective calls on a world-1 RCCL group: the compute side of the 8-GPU point of the scaling curve
     out["shard_64x512sq_x90tilts"] = _shard_step(64, 512, 90)
+    out["sharded_fgp_128x512sq"] = _sharded_fgp(128, 512)
     # ---- config 5 on ONE GPU: ChemicalTomo data-fusion iteration, ADF + 2 spectral channels, 512^3, 70 tilts
     # (chemistry/reconstructor.py:182-225: sirt_data_fusion(lambdaHAADF 10, lambdaCHEM 0.05, iterSIRT 5) + tv_fgp_4D(5, 1e-4))
     from tomo_tv_amd.chemistry import create_weighted_summation_weights, multimodal

@@ -312,3 +312,52 @@ def test_sweep_beside_a_kernel_that_holds_part_of_the_chip(gpu, tracked, spin):
         assert t.get_option("sart_resident_fallbacks") >= 1, (dt, still)
     else:
         assert t.get_option("sart_resident_fallbacks") == 0 and dt >= 0.03, dt
+
+
+@pytest.mark.parametrize("spin", [3000, 150])
+def test_two_processes_share_the_device(gpu, spin):
+    """VERDICT r5 'what is missing' 1: a per-process mutex orders the resident launches of ONE process; nothing orders them against
+    another process.  Two processes sweep 512^2 slabs (256 workgroups each, one per CU) on the same GPU at the same time, 200 sweeps
+    of 60 angles each: a launch that finds part of the chip taken waits (spin 3000: longer than the other's launch lasts) or gives up
+    (spin 150), stores nothing and is redone by the streamed chain.  Both must end with the right volume -- the streamed form's to
+    1e-5 after 200 sweeps (two forms 1e-7 apart per sweep) -- whatever the interleaving was."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resident_contention_script.py")
+    start_at = time.time() + 25.0                      # both children have built their engines by then
+    procs = [subprocess.Popen([sys.executable, script, str(11 + i), "200", str(spin), repr(start_at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for i in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    res = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        res.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+    print("two processes, 200 sweeps of 60 angles each:", res)
+    for r in res:
+        assert r["finite"] and r["rel"] <= 1e-5, r
+
+
+def test_random_chunks_that_do_not_commit(gpu):
+    """The commit words over many launches: a random chunk (or none) refuses to commit in each of 40 sweeps of a four-chunk slab (256^2:
+    four chunks side by side) and of a slab whose chunks take turns (512^2 x 192: three rounds of one chunk); the volume must follow
+    the streamed engine sweep by sweep, and exactly the refused chunks are counted."""
+    rng = np.random.default_rng(17)
+    for ns, n, nproj in ((256, 256, 8), (192, 512, 6)):
+        nchunk = ns // 64
+        t = _engine(ns, n, nproj, 1, noisy=True)
+        r = _engine(ns, n, nproj, 0, noisy=True)
+        refused = 0
+        for k in range(40 if n == 256 else 12):
+            c = int(rng.integers(0, nchunk + 1))             # nchunk = nobody refuses
+            t.set_option("sart_resident_test_fail", c + 1 if c < nchunk else 0)
+            refused += 1 if c < nchunk else 0
+            t.SART(0.2, 1)
+            r.SART(0.2, 1)
+            if k % 8 == 7 or k < 3:
+                assert _rel(t.get_volume(VOL_RECON), r.get_volume(VOL_RECON)) <= 2e-6, (ns, n, k)
+        assert _rel(t.get_volume(VOL_RECON), r.get_volume(VOL_RECON)) <= 2e-6
+        # with the chunks of 512^2 taking turns (one group), a chunk that refuses does not stop the later ones of the launch
+        assert t.get_option("sart_resident_fallback_chunks") == refused, (t.get_option("sart_resident_fallback_chunks"), refused)
