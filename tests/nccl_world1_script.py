@@ -38,8 +38,15 @@ def torch_collectives():
     return t
 
 
+def folded_halo_advance():
+    """the native path with the halo planes advanced INSIDE the update pass ("tv_halo_fold" = 1; off by default: measured slower)"""
+    t = multigpuengine(Nx, N, ang, force_collectives=True)
+    t.set_option("tv_halo_fold", 1)
+    return t
+
+
 for make in (lambda: tomoengine(Nx, N, ang), lambda: multigpuengine(Nx, N, ang),
-             lambda: multigpuengine(Nx, N, ang, force_collectives=True), torch_collectives):
+             lambda: multigpuengine(Nx, N, ang, force_collectives=True), torch_collectives, folded_halo_advance):
     t = make()
     t.set_volume(x, VOL_ORIGINAL)
     t.create_projections()

@@ -137,7 +137,10 @@ struct tomo_engine {
     int tv_recompute = 1, tv_tz = 8;              // tv_tz: z-columns per wave of the register march (8 or 4)
     int tv_yseg = 0;                              // rows per wave of the register march; 0 = by slab size (tv_rows_per_wave)
     int tv_march4 = 1;                            // norm / update passes by k_tv_march4 (no row rotation) instead of k_tv_grad_reg
-    int tv_halo_fold = 1;                         // slab-sharded descent: the update pass advances the halo planes itself (no k_halo_apply launch)
+    // slab-sharded descent: 1 = the update pass advances the halo planes itself instead of a k_halo_apply launch per inner iteration.
+    // Off: measured on the 64-slice shard (round 6) 2.165 against 2.012 ms per step -- on a one-chunk slab EVERY wave of the pass holds
+    // slice 0 and slice nx-1, and the single-lane plane accesses cost each of them more than the 4.8-us launch they replace.
+    int tv_halo_fold = 0;
     int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
     double *gnorm_override = nullptr;             // tomo_comm_tv_gd: the all-reduced sum g^2 (the slot itself keeps the slab's partial sum)
     hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
