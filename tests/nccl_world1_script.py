@@ -39,14 +39,20 @@ def torch_collectives():
 
 
 def folded_halo_advance():
-    """the native path with the halo planes advanced INSIDE the update pass ("tv_halo_fold" = 1; off by default: measured slower)"""
+    """the native path with the halo planes advanced INSIDE the update pass ("tv_halo_fold" = 1; automatic: slabs of two chunks or more)"""
     t = multigpuengine(Nx, N, ang, force_collectives=True)
     t.set_option("tv_halo_fold", 1)
     return t
 
 
+def unfolded_halo_advance():
+    t = multigpuengine(Nx, N, ang, force_collectives=True)
+    t.set_option("tv_halo_fold", 0)
+    return t
+
+
 for make in (lambda: tomoengine(Nx, N, ang), lambda: multigpuengine(Nx, N, ang),
-             lambda: multigpuengine(Nx, N, ang, force_collectives=True), torch_collectives, folded_halo_advance):
+             lambda: multigpuengine(Nx, N, ang, force_collectives=True), torch_collectives, folded_halo_advance, unfolded_halo_advance):
     t = make()
     t.set_volume(x, VOL_ORIGINAL)
     t.create_projections()

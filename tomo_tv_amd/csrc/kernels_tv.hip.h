@@ -858,15 +858,26 @@ __global__ __launch_bounds__(256) TV4_OCC void k_tv_march4(const float *__restri
                 }
             }
             if (MODE == TVM_UPDATE && up.hg_lo != nullptr && (EDGE || s0 == 0 || s0 + 64 == nx)) {
-                if (s == 0) {
+                if (!EDGE) {
+                    // the old planes' values of this row are already here: lane j of the packed edge registers holds column z0 - 1 + j
+                    // of slice s0 - 1 (pe0) / s0 + 64 (pf0) -- the halo planes themselves in the chunks that touch them.  Lanes 1 .. TZ
+                    // advance the row's eight pixels of each plane at once: one 32-byte load of the received gradient plane, one store.
+                    const unsigned hp = (unsigned)(y * n) + (unsigned)zl;
+                    if (lane >= 1 && lane <= TZ) {
+                        if (s0 == 0) up.ho_lo[hp] = fmaxf(tv_step(pe0, up.hg_lo[hp], nrm_), vmin);
+                        if (s0 + 64 == nx) up.ho_hi[hp] = fmaxf(tv_step(pf0, up.hg_hi[hp], nrm_), vmin);
+                    }
+                } else {
+                    if (s == 0) {
 #pragma unroll
-                    for (int j = 1; j <= TZ; ++j)
-                        if (!EDGE || z0 + j - 1 < n) up.ho_lo[pix0 + (j - 1)] = fmaxf(tv_step(h.lo[pix0 + (j - 1)], up.hg_lo[pix0 + (j - 1)], nrm_), vmin);
-                }
-                if (s == nx - 1) {
+                        for (int j = 1; j <= TZ; ++j)
+                            if (z0 + j - 1 < n) up.ho_lo[pix0 + (j - 1)] = fmaxf(tv_step(h.lo[pix0 + (j - 1)], up.hg_lo[pix0 + (j - 1)], nrm_), vmin);
+                    }
+                    if (s == nx - 1) {
 #pragma unroll
-                    for (int j = 1; j <= TZ; ++j)
-                        if (!EDGE || z0 + j - 1 < n) up.ho_hi[pix0 + (j - 1)] = fmaxf(tv_step(h.hi[pix0 + (j - 1)], up.hg_hi[pix0 + (j - 1)], nrm_), vmin);
+                        for (int j = 1; j <= TZ; ++j)
+                            if (z0 + j - 1 < n) up.ho_hi[pix0 + (j - 1)] = fmaxf(tv_step(h.hi[pix0 + (j - 1)], up.hg_hi[pix0 + (j - 1)], nrm_), vmin);
+                    }
                 }
             }
         };

@@ -137,10 +137,12 @@ struct tomo_engine {
     int tv_recompute = 1, tv_tz = 8;              // tv_tz: z-columns per wave of the register march (8 or 4)
     int tv_yseg = 0;                              // rows per wave of the register march; 0 = by slab size (tv_rows_per_wave)
     int tv_march4 = 1;                            // norm / update passes by k_tv_march4 (no row rotation) instead of k_tv_grad_reg
-    // slab-sharded descent: 1 = the update pass advances the halo planes itself instead of a k_halo_apply launch per inner iteration.
-    // Off: measured on the 64-slice shard (round 6) 2.165 against 2.012 ms per step -- on a one-chunk slab EVERY wave of the pass holds
-    // slice 0 and slice nx-1, and the single-lane plane accesses cost each of them more than the 4.8-us launch they replace.
-    int tv_halo_fold = 0;
+    // slab-sharded descent: the update pass advances the halo planes itself (lanes 1..8 of the packed edge registers: one 32-byte load of
+    // the received gradient plane and one store per row and plane) instead of a k_halo_apply launch per inner iteration.  -1 = automatic:
+    // where the slab has two chunks or more.  Measured (round 6, bench.py --force-dist, world-1 RCCL group): 128 slices 3.53 against 3.62 ms
+    // per step; 64 slices (ONE chunk: every wave of the pass holds both planes) 2.04 against 2.01 -- so a one-chunk slab keeps the launch.
+    // (The first form, one lane looping over the row's eight pixels: 2.165 against 2.012 at 64 slices.)  1 / 0 force it.
+    int tv_halo_fold = -1;
     int gnorm_slot = TOMO_S_GNORM;                // scalar slot the TV update takes ||g||^2 from (slab groups: TOMO_S_GNORM_ALL)
     double *gnorm_override = nullptr;             // tomo_comm_tv_gd: the all-reduced sum g^2 (the slot itself keeps the slab's partial sum)
     hipEvent_t ev_peer = nullptr;                 // tomo_wait_for: "everything enqueued on this engine so far"
